@@ -1,0 +1,1233 @@
+// mapalign.hip — MI355X (gfx950 / CDNA4) map-alignment engine: kernels + C ABI.
+//
+// Hot path (the reference body src/map_alignment/align.py is
+// absent, call site /root/reference/task_def.py:175-187):
+//   k_nn_accum   a4+a5  per source point: rigid transform (fp64), exact nearest gold
+//                       point through a uniform grid stored in HBM (ring-expanding row
+//                       walk with distance pruning), distance gate, fp64 accumulation of
+//                       {W, s_p, s_q, S, E}; wavefront shuffle reduction -> one fp64
+//                       partial per workgroup (no float atomics => bitwise reproducible)
+//   k_reduce_solve a5-a7 fixed-order sum of the partials, 3x3 Jacobi-SVD Kabsch step,
+//                       transform composition and convergence test, all on the device so
+//                       the loop never synchronises with the host
+//   k_unproject  a8     depth image -> world points written straight into the source
+//                       cloud buffer (order-preserving compaction of valid pixels)
+// Everything is written for 64-wide wavefronts; there is no MFMA because the path is a
+// gather + reduction (<0.5 flop/B), and no CPU fallback.
+//
+// Memory layout in HBM (all owned by the ctx):
+//   gold   float4[M]   cell-sorted (x fastest), coordinates relative to the centring
+//                      origin, .w = original index (bit pattern)
+//   cstart u32[ncells+1] exclusive prefix of points per cell: the points of the x-run
+//                      [x0,x1] of row (y,z) are gold[cstart[row+x0] .. cstart[row+x1+1])
+//   src    float4[N]   cell-sorted in its own frame for spatial coherence of a wavefront,
+//                      .w = per-point weight
+//   partials f64[19][G], state (R,t,flags), trace f64[iters][20]
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kabsch.h"
+#include "mapalign.h"
+
+namespace {
+
+constexpr int kBlock = 256;           // 4 wavefronts
+constexpr int kWave = 64;
+constexpr int kNAcc = 19;             // 17 accumulators + rows visited + candidates
+constexpr int kMaxGrid = 2048;        // 256 CUs x 8 resident workgroups
+constexpr uint64_t kMaxCells = 1ull << 27;
+constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
+
+struct GridP {
+  float ox, oy, oz;  // min corner of the grid in the centred frame
+  float c, inv_c;    // cell edge and its reciprocal
+  float delta;       // boundary slack (a few ulp of the largest coordinate)
+  int nx, ny, nz;
+};
+
+struct DevState {
+  double R[9];
+  double t[3];       // centred frame: p'_c = R p_c + t
+  double prev_rmse;
+  double last_rmse;
+  double last_W;
+  int iter;
+  int done;
+  int converged;
+  int degenerate;
+};
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t cell_of(float x, float y, float z, const GridP& g) {
+  int ix = (int)floorf((x - g.ox) * g.inv_c);
+  int iy = (int)floorf((y - g.oy) * g.inv_c);
+  int iz = (int)floorf((z - g.oz) * g.inv_c);
+  ix = min(max(ix, 0), g.nx - 1);
+  iy = min(max(iy, 0), g.ny - 1);
+  iz = min(max(iz, 0), g.nz - 1);
+  return (uint32_t)((iz * g.ny + iy) * g.nx + ix);
+}
+
+// ---------------------------------------------------------------------------------------
+// grid build (once per cloud; not part of the timed loop)
+// ---------------------------------------------------------------------------------------
+// Per-workgroup min / max / non-finite count of an n x 3 fp32 cloud.
+__global__ __launch_bounds__(kBlock) void k_minmax(const float* __restrict__ xyz, uint32_t n,
+                                                   float* __restrict__ out /*[grid][8]*/) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  float bad = 0.f;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
+      lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
+      lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
+    } else {
+      bad += 1.f;
+    }
+  }
+  __shared__ float red[kBlock / kWave][8];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fminf(lo[a], __shfl_down(lo[a], off, kWave));
+      hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, kWave));
+    }
+    bad += __shfl_down(bad, off, kWave);
+  }
+  if (lane == 0) {
+    for (int a = 0; a < 3; ++a) { red[wv][a] = lo[a]; red[wv][3 + a] = hi[a]; }
+    red[wv][6] = bad; red[wv][7] = 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int k = threadIdx.x;
+    float v = red[0][k];
+    for (int w = 1; w < kBlock / kWave; ++w) {
+      const float u = red[w][k];
+      v = (k < 3) ? fminf(v, u) : (k < 6 ? fmaxf(v, u) : v + u);
+    }
+    out[blockIdx.x * 8 + k] = v;
+  }
+}
+
+// key = cell id, val = original index; also the per-cell histogram (integer atomics:
+// the counts are order-independent, hence deterministic).
+__global__ __launch_bounds__(kBlock) void k_cell_keys(const float* __restrict__ xyz, uint32_t n,
+                                                      double o0, double o1, double o2, GridP g,
+                                                      uint32_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ vals,
+                                                      uint32_t* __restrict__ counts) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float x = (float)((double)xyz[3 * (size_t)i] - o0);
+  const float y = (float)((double)xyz[3 * (size_t)i + 1] - o1);
+  const float z = (float)((double)xyz[3 * (size_t)i + 2] - o2);
+  const uint32_t c = cell_of(x, y, z, g);
+  keys[i] = c;
+  vals[i] = i;
+  if (counts) atomicAdd(&counts[c], 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_occupied(const uint32_t* __restrict__ counts,
+                                                           uint32_t ncells,
+                                                           unsigned long long* __restrict__ out) {
+  uint32_t c = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ncells; i += gridDim.x * kBlock)
+    c += counts[i] != 0u;
+  double v = wave_sum((double)c);
+  if ((threadIdx.x & (kWave - 1)) == 0 && v > 0) atomicAdd(out, (unsigned long long)v);
+}
+
+// sorted[pos] = centred(xyz[perm[pos]]), .w = original index (gold) or weight (source).
+__global__ __launch_bounds__(kBlock) void k_gather(const float* __restrict__ xyz,
+                                                   const float* __restrict__ weights,
+                                                   const uint32_t* __restrict__ perm, uint32_t n,
+                                                   double o0, double o1, double o2, int w_is_index,
+                                                   float4* __restrict__ out) {
+  const uint32_t pos = blockIdx.x * kBlock + threadIdx.x;
+  if (pos >= n) return;
+  const uint32_t i = perm ? perm[pos] : pos;
+  float4 v;
+  v.x = (float)((double)xyz[3 * (size_t)i] - o0);
+  v.y = (float)((double)xyz[3 * (size_t)i + 1] - o1);
+  v.z = (float)((double)xyz[3 * (size_t)i + 2] - o2);
+  v.w = w_is_index ? __uint_as_float(i) : (weights ? weights[i] : 1.0f);
+  out[pos] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// a4: exact nearest neighbour through the grid
+// ---------------------------------------------------------------------------------------
+// Rows (y,z) of the grid are visited in square rings of growing Chebyshev radius r around
+// the query's row.  Every point of ring r is at least (r-1)*c away, so the walk stops as
+// soon as that bound reaches the best distance found (or the gate).  Inside a row only the
+// x-run of cells that the current best sphere can reach is scanned; with the x-fastest
+// cell sort that run is ONE contiguous slice of the gold array (two cstart reads).
+template <bool COUNT>
+__device__ __forceinline__ void nn_search(const float px, const float py, const float pz,
+                                          const float4* __restrict__ gold,
+                                          const uint32_t* __restrict__ cstart, const GridP& g,
+                                          const float best2_init, float& best2, uint32_t& bestj,
+                                          uint32_t& nrows, uint32_t& ncand) {
+  best2 = best2_init;
+  bestj = kNoMatch;
+  if (!(isfinite(px) && isfinite(py) && isfinite(pz))) return;
+  // centre row, clamped to one cell outside the grid: for a query outside the grid the
+  // ring bound (r-1)*c then under-estimates the true distance, which keeps it valid.
+  const float uy = fminf(fmaxf((py - g.oy) * g.inv_c, -1.f), (float)g.ny);
+  const float uz = fminf(fmaxf((pz - g.oz) * g.inv_c, -1.f), (float)g.nz);
+  const int cy = (int)floorf(uy), cz = (int)floorf(uz);
+  const int r0 = max(0, max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1))));
+  const int rmax = max(max(cy, g.ny - 1 - cy), max(cz, g.nz - 1 - cz));
+  for (int r = r0; r <= rmax; ++r) {
+    if (r >= 2) {
+      const float lb = (float)(r - 1) * g.c - g.delta;
+      if (lb * lb >= best2) break;
+    }
+    const int nside = r ? 4 : 1, len = r ? 2 * r : 1;
+    for (int s = 0; s < nside; ++s) {
+      for (int o = 0; o < len; ++o) {
+        int dy, dz;
+        if (s == 0)      { dy = o - r; dz = -r; }
+        else if (s == 1) { dy = r;     dz = o - r; }
+        else if (s == 2) { dy = r - o; dz = r; }
+        else             { dy = -r;    dz = r - o; }
+        const int y = cy + dy, z = cz + dz;
+        if ((unsigned)y >= (unsigned)g.ny || (unsigned)z >= (unsigned)g.nz) continue;
+        const float ylo = g.oy + (float)y * g.c, zlo = g.oz + (float)z * g.c;
+        const float dyq = fmaxf(0.f, fmaxf(ylo - g.delta - py, py - (ylo + g.c + g.delta)));
+        const float dzq = fmaxf(0.f, fmaxf(zlo - g.delta - pz, pz - (zlo + g.c + g.delta)));
+        const float d2yz = dyq * dyq + dzq * dzq;
+        if (d2yz >= best2) continue;
+        const float rx = sqrtf(best2 - d2yz) + g.delta;  // +inf while ungated and unmatched
+        const float fx0 = floorf((px - rx - g.ox) * g.inv_c);
+        const float fx1 = floorf((px + rx - g.ox) * g.inv_c);
+        const int x0 = (int)fmaxf(fx0, 0.f);
+        const int x1 = (int)fminf(fx1, (float)(g.nx - 1));
+        if (x0 > x1) continue;
+        const uint32_t row = (uint32_t)((z * g.ny + y) * g.nx);
+        const uint32_t a = cstart[row + x0], b = cstart[row + x1 + 1];
+        if (COUNT) { nrows += 1u; ncand += b - a; }
+        for (uint32_t j = a; j < b; ++j) {
+          const float4 q = gold[j];
+          const float dx = px - q.x, dyy = py - q.y, dzz = pz - q.z;
+          const float d2 = dx * dx + dyy * dyy + dzz * dzz;
+          if (d2 < best2) { best2 = d2; bestj = j; }
+        }
+      }
+    }
+  }
+}
+
+// XCD-aware chunk order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
+// and b+8 share an L2.  Chunk (b%8)*(G/8) + b/8 gives every XCD one contiguous eighth of
+// the (cell-sorted) source cloud, i.e. one slab of the gold grid in its private L2.
+__device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t G) {
+  return (G % 8u == 0u) ? (b % 8u) * (G / 8u) + b / 8u : b;
+}
+
+// a4 + a5 fused.  MODE 0: accumulate only; MODE 1: also write per-point (idx, d2).
+template <bool COUNT, int MODE>
+__global__ __launch_bounds__(kBlock) void k_nn_accum(
+    const float4* __restrict__ src, const uint32_t n, const uint32_t chunk,
+    const float4* __restrict__ gold, const uint32_t* __restrict__ cstart, const GridP g,
+    const DevState* __restrict__ st, const float best2_init, double* __restrict__ partials,
+    uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2) {
+  if (MODE == 0 && st->done) return;
+  const uint32_t G = gridDim.x;
+  const uint32_t cb = xcd_chunk(blockIdx.x, G);
+  const uint32_t begin = min(cb * chunk, n), end = min(begin + chunk, n);
+  double R[9], t[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = st->R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = st->t[i];
+
+  double acc[kNAcc];
+#pragma unroll
+  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
+  uint32_t nrows = 0, ncand = 0;
+
+  for (uint32_t i = begin + threadIdx.x; i < end; i += kBlock) {
+    const float4 s = src[i];
+    const double Px = R[0] * s.x + R[1] * s.y + R[2] * s.z + t[0];
+    const double Py = R[3] * s.x + R[4] * s.y + R[5] * s.z + t[1];
+    const double Pz = R[6] * s.x + R[7] * s.y + R[8] * s.z + t[2];
+    float best2;
+    uint32_t bestj;
+    nn_search<COUNT>((float)Px, (float)Py, (float)Pz, gold, cstart, g, best2_init, best2, bestj,
+                     nrows, ncand);
+    if (bestj != kNoMatch) {
+      const float4 q = gold[bestj];
+      if (MODE == 1) { nn_idx[i] = __float_as_uint(q.w); nn_d2[i] = best2; }
+      const double w = (double)s.w;
+      const double qx = q.x, qy = q.y, qz = q.z;
+      const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
+      const double wPx = w * Px, wPy = w * Py, wPz = w * Pz;
+      acc[0] += w;
+      acc[1] += wPx; acc[2] += wPy; acc[3] += wPz;
+      acc[4] += w * qx; acc[5] += w * qy; acc[6] += w * qz;
+      acc[7] += wPx * qx;  acc[8] += wPx * qy;  acc[9] += wPx * qz;
+      acc[10] += wPy * qx; acc[11] += wPy * qy; acc[12] += wPy * qz;
+      acc[13] += wPz * qx; acc[14] += wPz * qy; acc[15] += wPz * qz;
+      acc[16] += w * (dx * dx + dy * dy + dz * dz);
+    } else if (MODE == 1) {
+      nn_idx[i] = kNoMatch;
+      nn_d2[i] = INFINITY;
+    }
+  }
+  if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
+
+  // wavefront shuffle reduction, then a fixed-order sum over the 4 wavefronts
+  __shared__ double red[kBlock / kWave][kNAcc];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < kNAcc; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) red[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNAcc) {
+    const int k = threadIdx.x;
+    partials[(size_t)k * G + blockIdx.x] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+  }
+}
+
+// a5 (final sum) + a6 + a7.  One workgroup.
+//   do_reduce: acc = fixed-order sum of partials[k][0..G); optionally stored to acc_out
+//   else     : acc = acc_in[0..19)
+//   do_solve : Kabsch step, composition, convergence test, trace row
+__global__ __launch_bounds__(kBlock) void k_reduce_solve(
+    const double* __restrict__ partials, const int G, const double* __restrict__ acc_in,
+    double* __restrict__ acc_out, DevState* __restrict__ st, double* __restrict__ trace,
+    const int trace_cap, const double tol, const int do_reduce, const int do_solve) {
+  if (st->done) return;
+  __shared__ double red[kBlock / kWave][kNAcc];
+  __shared__ double acc[kNAcc];
+  if (do_reduce) {
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    for (int k = 0; k < kNAcc; ++k) {
+      double v = 0.0;
+      for (int b = threadIdx.x; b < G; b += kBlock) v += partials[(size_t)k * G + b];
+      v = wave_sum(v);
+      if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNAcc) {
+      const int k = threadIdx.x;
+      const double v = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+      acc[k] = v;
+      if (acc_out) acc_out[k] = v;
+    }
+  } else if (threadIdx.x < kNAcc) {
+    acc[threadIdx.x] = acc_in[threadIdx.x];
+  }
+  __syncthreads();
+  if (!do_solve || threadIdx.x != 0) return;
+
+  double a[ma::kAccLen];
+  for (int k = 0; k < ma::kAccLen; ++k) a[k] = acc[k];
+  const int it = st->iter;
+  const double W = a[0];
+  const double rmse = W > 0.0 ? sqrt(a[16] / W) : NAN;
+  if (it < trace_cap) {
+    double* row = trace + (size_t)it * MA_TRACE_STRIDE;
+    for (int k = 0; k < ma::kAccLen; ++k) row[k] = a[k];
+    row[17] = rmse; row[18] = acc[17]; row[19] = acc[18];
+  }
+  st->iter = it + 1;
+  st->last_rmse = rmse;
+  st->last_W = W;
+  double dR[9], dt[3];
+  if (ma::kabsch_from_acc(a, dR, dt)) {
+    st->degenerate = 1;
+    st->done = 1;
+    return;
+  }
+  double Rn[9], tn[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c)
+      Rn[3 * r + c] = dR[3 * r] * st->R[c] + dR[3 * r + 1] * st->R[3 + c] + dR[3 * r + 2] * st->R[6 + c];
+    tn[r] = dR[3 * r] * st->t[0] + dR[3 * r + 1] * st->t[1] + dR[3 * r + 2] * st->t[2] + dt[r];
+  }
+  for (int i = 0; i < 9; ++i) st->R[i] = Rn[i];
+  for (int i = 0; i < 3; ++i) st->t[i] = tn[i];
+  if (it >= 1 && fabs(rmse - st->prev_rmse) < tol) {
+    st->converged = 1;
+    st->done = 1;
+  }
+  st->prev_rmse = rmse;
+}
+
+// ---------------------------------------------------------------------------------------
+// a8: depth -> world points, order-preserving compaction
+// ---------------------------------------------------------------------------------------
+constexpr int kPxPerThread = 4;
+constexpr int kPxPerBlock = kBlock * kPxPerThread;
+
+template <typename T>
+__device__ __forceinline__ double depth_z(const T* __restrict__ depth, uint32_t i, double inv_scale) {
+  return (double)depth[i] * inv_scale;
+}
+
+struct Pinhole {
+  double fx_inv, fy_inv, cx, cy, inv_scale;
+  double T[12];  // camera->world rows 0..2, translation already minus the centring origin
+};
+
+// PASS 0: per-workgroup count of valid pixels.  PASS 1: write points at the scanned offsets.
+template <typename T, int PASS>
+__global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ depth, const int width,
+                                                      const uint32_t npx, const Pinhole cam,
+                                                      uint32_t* __restrict__ block_counts,
+                                                      const uint32_t* __restrict__ block_offsets,
+                                                      float4* __restrict__ out) {
+  const uint32_t first = blockIdx.x * kPxPerBlock + threadIdx.x * kPxPerThread;
+  double z[kPxPerThread];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int k = 0; k < kPxPerThread; ++k) {
+    const uint32_t i = first + k;
+    z[k] = i < npx ? depth_z(depth, i, cam.inv_scale) : 0.0;
+    if (!(isfinite(z[k]) && z[k] > 0.0)) z[k] = 0.0;
+    cnt += z[k] > 0.0;
+  }
+  // exclusive scan of cnt over the workgroup (wavefront shuffles + LDS)
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const uint32_t u = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += u;
+  }
+  __shared__ uint32_t wsum[kBlock / kWave];
+  if (lane == kWave - 1) wsum[wv] = incl;
+  __syncthreads();
+  uint32_t wbase = 0, total = 0;
+  for (int w = 0; w < kBlock / kWave; ++w) {
+    if (w < wv) wbase += wsum[w];
+    total += wsum[w];
+  }
+  if (PASS == 0) {
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+    return;
+  }
+  uint32_t pos = block_offsets[blockIdx.x] + wbase + (incl - cnt);
+#pragma unroll
+  for (int k = 0; k < kPxPerThread; ++k) {
+    if (z[k] > 0.0) {
+      const uint32_t i = first + k;
+      const double u = (double)(i % (uint32_t)width), v = (double)(i / (uint32_t)width);
+      const double X = (u - cam.cx) * z[k] * cam.fx_inv;
+      const double Y = (v - cam.cy) * z[k] * cam.fy_inv;
+      float4 p;
+      p.x = (float)(cam.T[0] * X + cam.T[1] * Y + cam.T[2] * z[k] + cam.T[3]);
+      p.y = (float)(cam.T[4] * X + cam.T[5] * Y + cam.T[6] * z[k] + cam.T[7]);
+      p.z = (float)(cam.T[8] * X + cam.T[9] * Y + cam.T[10] * z[k] + cam.T[11]);
+      p.w = 1.0f;
+      out[pos++] = p;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_uncentre(const float4* __restrict__ src, uint32_t n,
+                                                     double o0, double o1, double o2,
+                                                     float* __restrict__ xyz) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 s = src[i];
+  xyz[3 * (size_t)i] = (float)((double)s.x + o0);
+  xyz[3 * (size_t)i + 1] = (float)((double)s.y + o1);
+  xyz[3 * (size_t)i + 2] = (float)((double)s.z + o2);
+}
+
+// out[perm[pos]] = in[pos] (undo the source cell sort for ma_nn)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_unpermute(const T* __restrict__ in,
+                                                      const uint32_t* __restrict__ perm, uint32_t n,
+                                                      T* __restrict__ out) {
+  const uint32_t pos = blockIdx.x * kBlock + threadIdx.x;
+  if (pos >= n) return;
+  out[perm ? perm[pos] : pos] = in[pos];
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+thread_local std::string g_create_error;
+
+inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+}  // namespace
+
+struct ma_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+
+  // gold map
+  bool have_gold = false;
+  uint32_t m = 0;
+  double origin[3] = {0, 0, 0};
+  GridP grid{};
+  uint64_t ncells = 0, noccupied = 0;
+  double build_ms = 0;
+  DevBuf gold, cstart;
+
+  // source cloud
+  bool have_src = false;
+  bool src_sorted = false;
+  uint32_t n = 0;
+  DevBuf src, src_perm;
+
+  // scratch for builds
+  DevBuf raw, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
+
+  // loop state
+  DevBuf state, partials, trace, acc19, nn_idx, nn_d2, nn_tmp;
+  int trace_cap = 0;
+  int last_G = 0;
+
+  int fail(int code, const std::string& msg) {
+    err = msg;
+    return code;
+  }
+};
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return ctx->fail(MA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+  } while (0)
+
+namespace {
+
+int check_params(ma_ctx* ctx, const ma_params* p) {
+  if (!p) return ctx->fail(MA_ERR_INVALID, "params is NULL");
+  if (p->max_iter < 1) return ctx->fail(MA_ERR_INVALID, "max_iter must be >= 1");
+  if (!(p->tol >= 0.0) || !std::isfinite(p->tol)) return ctx->fail(MA_ERR_INVALID, "tol must be finite and >= 0");
+  if (!(p->max_corr_dist > 0.0)) return ctx->fail(MA_ERR_INVALID, "max_corr_dist must be > 0 (or +inf)");
+  return MA_OK;
+}
+
+// strict '<' acceptance against this value implements the inclusive gate d^2 <= gate^2
+float open_gate2(double gate) {
+  if (!std::isfinite(gate)) return std::numeric_limits<float>::infinity();
+  const float g2 = (float)(gate * gate);
+  return std::nextafterf(g2, std::numeric_limits<float>::infinity());
+}
+
+int need_ready(ma_ctx* ctx) {
+  if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "gold map not set (ma_set_gold)");
+  if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set (ma_set_source)");
+  return MA_OK;
+}
+
+// world 4x4 (row-major) -> centred-frame state
+void world_to_centred(const double* T, const double o[3], DevState& s) {
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+  if (T) {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) R[3 * r + c] = T[4 * r + c];
+      t[r] = T[4 * r + 3];
+    }
+  }
+  for (int i = 0; i < 9; ++i) s.R[i] = R[i];
+  for (int r = 0; r < 3; ++r)
+    s.t[r] = R[3 * r] * o[0] + R[3 * r + 1] * o[1] + R[3 * r + 2] * o[2] + t[r] - o[r];
+}
+
+void centred_to_world(const DevState& s, const double o[3], double* T) {
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) T[4 * r + c] = s.R[3 * r + c];
+    T[4 * r + 3] = s.t[r] - (s.R[3 * r] * o[0] + s.R[3 * r + 1] * o[1] + s.R[3 * r + 2] * o[2]) + o[r];
+  }
+  T[12] = T[13] = T[14] = 0.0;
+  T[15] = 1.0;
+}
+
+// centred-frame accumulators -> world-frame accumulators (p = p_c + o, q = q_c + o)
+void acc_to_world(const double* a, const double o[3], double* out) {
+  const double W = a[0];
+  out[0] = W;
+  for (int i = 0; i < 3; ++i) {
+    out[1 + i] = a[1 + i] + W * o[i];
+    out[4 + i] = a[4 + i] + W * o[i];
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      out[7 + 3 * r + c] = a[7 + 3 * r + c] + a[1 + r] * o[c] + o[r] * a[4 + c] + W * o[r] * o[c];
+  out[16] = a[16];
+}
+
+// bounding box (and finiteness check) of a device-resident n x 3 cloud
+int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3]) {
+  const int nb = std::min<uint32_t>(div_up(n, kBlock), 1024);
+  HIPCHK(ctx->misc.ensure((size_t)nb * 8 * sizeof(float)));
+  hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, ctx->misc.as<float>());
+  HIPCHK(hipGetLastError());
+  std::vector<float> h((size_t)nb * 8);
+  HIPCHK(hipMemcpyAsync(h.data(), ctx->misc.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double bad = 0;
+  for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+  for (int b = 0; b < nb; ++b) {
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = std::min(lo[a], h[(size_t)b * 8 + a]);
+      hi[a] = std::max(hi[a], h[(size_t)b * 8 + 3 + a]);
+    }
+    bad += h[(size_t)b * 8 + 6];
+  }
+  if (bad > 0) return ctx->fail(MA_ERR_INVALID, "cloud has non-finite coordinates (filter them first, as the reference's read_point_cloud(remove_nan_points=True, remove_infinite_points=True) does)");
+  return MA_OK;
+}
+
+GridP make_grid(const float lo[3], const float hi[3], const double o[3], float c) {
+  GridP g{};
+  g.ox = (float)((double)lo[0] - o[0]);
+  g.oy = (float)((double)lo[1] - o[1]);
+  g.oz = (float)((double)lo[2] - o[2]);
+  g.c = c;
+  g.inv_c = 1.0f / c;
+  const double ex = (double)hi[0] - lo[0], ey = (double)hi[1] - lo[1], ez = (double)hi[2] - lo[2];
+  g.nx = (int)std::floor(ex / c) + 1;
+  g.ny = (int)std::floor(ey / c) + 1;
+  g.nz = (int)std::floor(ez / c) + 1;
+  double maxabs = 0;
+  for (int a = 0; a < 3; ++a) maxabs = std::max({maxabs, std::fabs((double)lo[a] - o[a]), std::fabs((double)hi[a] - o[a])});
+  const float ulp = std::nextafterf((float)maxabs, INFINITY) - (float)maxabs;
+  g.delta = 8.0f * ulp + 1e-6f * c;
+  return g;
+}
+
+float clamp_cell_to_budget(const float lo[3], const float hi[3], float c, uint64_t max_cells) {
+  for (int it = 0; it < 64; ++it) {
+    const double nx = std::floor(((double)hi[0] - lo[0]) / c) + 1, ny = std::floor(((double)hi[1] - lo[1]) / c) + 1,
+                 nz = std::floor(((double)hi[2] - lo[2]) / c) + 1;
+    if (nx * ny * nz <= (double)max_cells && nx < 2e9 && ny < 2e9 && nz < 2e9) return c;
+    c *= 1.26f;
+  }
+  return c;
+}
+
+// keys/vals for `n` raw points + optional histogram; then a stable radix sort by cell id.
+// On return vals_b holds the permutation (sorted position -> original index).
+int sort_by_cell(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, const double o[3],
+                 uint32_t* d_counts) {
+  HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
+  HIPCHK(ctx->keys_b.ensure((size_t)n * 4));
+  HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
+  HIPCHK(ctx->vals_b.ensure((size_t)n * 4));
+  hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0],
+                     o[1], o[2], g, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), d_counts);
+  HIPCHK(hipGetLastError());
+  const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
+  int bits = 1;
+  while (bits < 32 && (1ull << bits) < ncells) ++bits;
+  size_t tmp_bytes = 0;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(),
+                                            ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, bits, ctx->stream));
+  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(),
+                                            ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, bits, ctx->stream));
+  return MA_OK;
+}
+
+// histogram of the raw gold points at cell edge c -> number of occupied cells
+int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, const double o[3],
+                   uint64_t* out) {
+  const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
+  HIPCHK(ctx->cstart.ensure((ncells + 1) * 4));
+  HIPCHK(hipMemsetAsync(ctx->cstart.p, 0, (ncells + 1) * 4, ctx->stream));
+  HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
+  HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
+  hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0],
+                     o[1], o[2], g, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                     ctx->cstart.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(ctx->misc.ensure(64));
+  HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(k_count_occupied, dim3(std::min<uint32_t>(div_up(ncells, kBlock), 4096)), dim3(kBlock), 0,
+                     ctx->stream, ctx->cstart.as<uint32_t>(), (uint32_t)ncells,
+                     ctx->misc.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  unsigned long long h = 0;
+  HIPCHK(hipMemcpyAsync(&h, ctx->misc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *out = h;
+  return MA_OK;
+}
+
+int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
+  HIPCHK(ctx->state.ensure(sizeof(DevState)));
+  HIPCHK(ctx->partials.ensure((size_t)kNAcc * kMaxGrid * sizeof(double)));
+  HIPCHK(ctx->acc19.ensure(kNAcc * sizeof(double)));
+  if (trace_rows > ctx->trace_cap) {
+    HIPCHK(ctx->trace.ensure((size_t)trace_rows * MA_TRACE_STRIDE * sizeof(double)));
+    ctx->trace_cap = trace_rows;
+  }
+  return MA_OK;
+}
+
+int upload_state(ma_ctx* ctx, const double* T) {
+  int rc = ensure_loop_buffers(ctx, std::max(ctx->trace_cap, 64));
+  if (rc) return rc;
+  DevState s{};
+  world_to_centred(T, ctx->origin, s);
+  s.prev_rmse = NAN; s.last_rmse = NAN; s.last_W = 0;
+  s.iter = 0; s.done = 0; s.converged = 0; s.degenerate = 0;
+  // pageable source: hipMemcpyAsync stages it before returning, so `s` may go out of scope
+  HIPCHK(hipMemcpyAsync(ctx->state.p, &s, sizeof(s), hipMemcpyHostToDevice, ctx->stream));
+  return MA_OK;
+}
+
+struct LaunchGeom { uint32_t G, chunk; };
+
+LaunchGeom geom_for(uint32_t n) {
+  uint32_t G = std::min<uint32_t>(div_up(n, kBlock), kMaxGrid);
+  G = std::max<uint32_t>(8, (G + 7u) / 8u * 8u);
+  uint32_t chunk = div_up(n, G);
+  chunk = (chunk + kBlock - 1) / kBlock * kBlock;
+  return {G, chunk};
+}
+
+template <int MODE>
+int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2) {
+  const LaunchGeom lg = geom_for(ctx->n);
+  ctx->last_G = (int)lg.G;
+  auto args = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(lg.G), dim3(kBlock), 0, ctx->stream, ctx->src.as<float4>(), ctx->n, lg.chunk,
+                       ctx->gold.as<float4>(), ctx->cstart.as<uint32_t>(), ctx->grid,
+                       ctx->state.as<DevState>(), best2_init, ctx->partials.as<double>(), nn_idx, nn_d2);
+  };
+  if (count) args(k_nn_accum<true, MODE>);
+  else args(k_nn_accum<false, MODE>);
+  HIPCHK(hipGetLastError());
+  return MA_OK;
+}
+
+int launch_reduce_solve(ma_ctx* ctx, const double* acc_in, double* acc_out, double tol, int do_reduce,
+                        int do_solve) {
+  hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
+                     ctx->last_G, acc_in, acc_out, ctx->state.as<DevState>(), ctx->trace.as<double>(),
+                     ctx->trace_cap, tol, do_reduce, do_solve);
+  HIPCHK(hipGetLastError());
+  return MA_OK;
+}
+
+int fetch_state(ma_ctx* ctx, DevState* s) {
+  HIPCHK(hipMemcpyAsync(s, ctx->state.p, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+}
+
+void fill_stats(const DevState& s, double gpu_ms, ma_stats* st) {
+  if (!st) return;
+  st->iterations = s.iter;
+  st->converged = s.converged;
+  st->degenerate = s.degenerate;
+  st->reserved = 0;
+  st->rmse = s.last_rmse;
+  st->inliers = s.last_W;
+  st->gpu_ms = gpu_ms;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int ma_version(void) { return MA_VERSION; }
+
+const char* ma_status_string(int status) {
+  switch (status) {
+    case MA_OK: return "ok";
+    case MA_ERR_INVALID: return "invalid argument";
+    case MA_ERR_NO_DEVICE: return "no usable HIP device";
+    case MA_ERR_HIP: return "HIP runtime error";
+    case MA_ERR_EMPTY: return "empty cloud";
+    case MA_ERR_STATE: return "call-order error";
+    case MA_ERR_DEGENERATE: return "degenerate correspondences";
+    case MA_ERR_TOO_LARGE: return "cloud too large";
+    default: return "unknown status";
+  }
+}
+
+const char* ma_last_error(const ma_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int ma_create(int device, ma_ctx** out) {
+  if (!out) { g_create_error = "out is NULL"; return MA_ERR_INVALID; }
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_create_error = std::string("no HIP device available (") + hipGetErrorString(e) +
+                     "); libmapalign has no CPU fallback";
+    return MA_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= count) {
+    g_create_error = "device ordinal out of range";
+    return MA_ERR_NO_DEVICE;
+  }
+  ma_ctx* ctx = new (std::nothrow) ma_ctx();
+  if (!ctx) { g_create_error = "out of host memory"; return MA_ERR_INVALID; }
+  ctx->device = device;
+  auto bail = [&](const char* what, hipError_t err) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+    delete ctx;
+    return MA_ERR_HIP;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  ctx->stream = ctx->own_stream;
+  if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+  *out = ctx;
+  return MA_OK;
+}
+
+int ma_destroy(ma_ctx* ctx) {
+  if (!ctx) return MA_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (DevBuf* b : {&ctx->gold, &ctx->cstart, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
+                    &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc, &ctx->depth_in,
+                    &ctx->state, &ctx->partials, &ctx->trace, &ctx->acc19, &ctx->nn_idx, &ctx->nn_d2,
+                    &ctx->nn_tmp})
+    b->release();
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return MA_OK;
+}
+
+int ma_set_stream(ma_ctx* ctx, void* hip_stream) {
+  if (!ctx) return MA_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return MA_OK;
+}
+
+int ma_sync(ma_ctx* ctx) {
+  if (!ctx) return MA_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+}
+
+int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!xyz && m) return ctx->fail(MA_ERR_INVALID, "xyz is NULL");
+  if (m == 0) return ctx->fail(MA_ERR_EMPTY, "gold cloud is empty");
+  if (m >= 0xFFFFFFFEull) return ctx->fail(MA_ERR_TOO_LARGE, "gold cloud has more than 2^32-2 points");
+  if (std::isnan(cell) || std::isinf(cell)) return ctx->fail(MA_ERR_INVALID, "cell must be finite");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->have_gold = false;
+  ctx->have_src = false;
+  const uint32_t n = (uint32_t)m;
+  HIPCHK(ctx->raw.ensure((size_t)n * 12));
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+  float lo[3], hi[3];
+  int rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, lo, hi);
+  if (rc) return rc;
+  // centring origin: bounding-box centre, rounded to fp32 so that (x - o) is exact-ish
+  for (int a = 0; a < 3; ++a) ctx->origin[a] = (double)(float)(0.5 * ((double)lo[a] + (double)hi[a]));
+
+  float c = cell;
+  if (!(c > 0.f)) {
+    // density-driven cell edge: aim at ~2 points per occupied cell.  Scans are surfaces,
+    // so occupancy grows ~ c^2; two histogram probes estimate the exponent.
+    const double target = 2.0;
+    const double ext = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-6});
+    float c0 = clamp_cell_to_budget(lo, hi, (float)(ext / 256.0), kMaxCells / 8);
+    uint64_t occ = 0;
+    GridP g0 = make_grid(lo, hi, ctx->origin, c0);
+    if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g0, ctx->origin, &occ))) return rc;
+    double rho0 = (double)n / (double)std::max<uint64_t>(occ, 1);
+    double expo = 2.0;
+    float c1 = (float)(c0 * std::pow(target / rho0, 1.0 / expo));
+    c1 = std::min(std::max(c1, c0 / 16.f), c0 * 16.f);
+    c1 = clamp_cell_to_budget(lo, hi, c1, kMaxCells / 8);
+    if (std::fabs(c1 / c0 - 1.f) > 0.05f) {
+      GridP g1 = make_grid(lo, hi, ctx->origin, c1);
+      if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g1, ctx->origin, &occ))) return rc;
+      const double rho1 = (double)n / (double)std::max<uint64_t>(occ, 1);
+      if (rho1 != rho0 && rho1 > 0 && rho0 > 0) {
+        const double e = std::log(rho1 / rho0) / std::log((double)c1 / c0);
+        if (e > 0.5 && e < 3.5) expo = e;
+      }
+      float c2 = (float)(c1 * std::pow(target / rho1, 1.0 / expo));
+      c2 = std::min(std::max(c2, c1 / 4.f), c1 * 4.f);
+      c = clamp_cell_to_budget(lo, hi, c2, kMaxCells / 8);
+    } else {
+      c = c1;
+    }
+  }
+  c = clamp_cell_to_budget(lo, hi, c, kMaxCells);
+  if (!(c > 0.f) || !std::isfinite(c)) return ctx->fail(MA_ERR_INVALID, "could not choose a cell edge");
+
+  const GridP g = make_grid(lo, hi, ctx->origin, c);
+  const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
+  HIPCHK(ctx->cstart.ensure((ncells + 1) * 4));
+  // histogram -> exclusive scan -> cstart
+  DevBuf& hist = ctx->misc;
+  HIPCHK(hist.ensure((ncells + 1) * 4 + 64));
+  uint32_t* d_hist = reinterpret_cast<uint32_t*>(static_cast<char*>(hist.p) + 64);
+  HIPCHK(hipMemsetAsync(hist.p, 0, (ncells + 1) * 4 + 64, ctx->stream));
+  if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, d_hist))) return rc;
+  size_t tmp_bytes = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_hist, ctx->cstart.as<uint32_t>(),
+                                          (int)(ncells + 1), ctx->stream));
+  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart.as<uint32_t>(),
+                                          (int)(ncells + 1), ctx->stream));
+  hipLaunchKernelGGL(k_count_occupied, dim3(std::min<uint32_t>(div_up(ncells, kBlock), 4096)), dim3(kBlock), 0,
+                     ctx->stream, d_hist, (uint32_t)ncells, static_cast<unsigned long long*>(hist.p));
+  HIPCHK(hipGetLastError());
+  HIPCHK(ctx->gold.ensure((size_t)n * sizeof(float4)));
+  hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->raw.as<float>(),
+                     (const float*)nullptr, ctx->vals_b.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1],
+                     ctx->origin[2], 1, ctx->gold.as<float4>());
+  HIPCHK(hipGetLastError());
+  unsigned long long occ = 0;
+  HIPCHK(hipMemcpyAsync(&occ, hist.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  ctx->build_ms = ms;
+  ctx->grid = g;
+  ctx->ncells = ncells;
+  ctx->noccupied = occ;
+  ctx->m = n;
+  ctx->have_gold = true;
+  return MA_OK;
+}
+
+int ma_grid_info_get(const ma_ctx* ctx, ma_grid_info* out) {
+  if (!ctx || !out) return MA_ERR_INVALID;
+  if (!ctx->have_gold) return MA_ERR_STATE;
+  out->cell = ctx->grid.c;
+  out->nx = ctx->grid.nx; out->ny = ctx->grid.ny; out->nz = ctx->grid.nz;
+  out->n_cells = ctx->ncells;
+  out->n_occupied = ctx->noccupied;
+  for (int a = 0; a < 3; ++a) out->origin[a] = ctx->origin[a];
+  out->build_ms = ctx->build_ms;
+  return MA_OK;
+}
+
+int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t n64) {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "set the gold map before the source cloud");
+  if (!xyz && n64) return ctx->fail(MA_ERR_INVALID, "xyz is NULL");
+  if (n64 == 0) return ctx->fail(MA_ERR_EMPTY, "source cloud is empty");
+  if (n64 >= 0xFFFFFFFEull) return ctx->fail(MA_ERR_TOO_LARGE, "source cloud has more than 2^32-2 points");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->have_src = false;
+  const uint32_t n = (uint32_t)n64;
+  HIPCHK(ctx->raw.ensure((size_t)n * 12));
+  HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+  const float* d_w = nullptr;
+  if (weights) {
+    HIPCHK(ctx->wts.ensure((size_t)n * 4));
+    HIPCHK(hipMemcpyAsync(ctx->wts.p, weights, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    d_w = ctx->wts.as<float>();
+  }
+  float lo[3], hi[3];
+  int rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, lo, hi);
+  if (rc) return rc;
+  // sort in the cloud's own frame with the gold map's cell edge (coarsened to fit 2^27
+  // cells): consecutive lanes then query neighbouring gold cells under any rigid motion.
+  const float c = clamp_cell_to_budget(lo, hi, ctx->grid.c, kMaxCells);
+  const GridP g = make_grid(lo, hi, ctx->origin, c);
+  if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, nullptr))) return rc;
+  HIPCHK(ctx->src.ensure((size_t)n * sizeof(float4)));
+  HIPCHK(ctx->src_perm.ensure((size_t)n * 4));
+  HIPCHK(hipMemcpyAsync(ctx->src_perm.p, ctx->vals_b.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->raw.as<float>(), d_w,
+                     ctx->src_perm.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1], ctx->origin[2], 0,
+                     ctx->src.as<float4>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n = n;
+  ctx->src_sorted = true;
+  ctx->have_src = true;
+  return MA_OK;
+}
+
+int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height,
+                             const float K[4], const double T[16], float depth_scale, uint64_t* n_valid) {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "set the gold map before the source cloud");
+  if (!depth || !K || !T) return ctx->fail(MA_ERR_INVALID, "NULL argument");
+  if (dtype != 0 && dtype != 1) return ctx->fail(MA_ERR_INVALID, "dtype must be 0 (float32) or 1 (uint16)");
+  if (width <= 0 || height <= 0 || (uint64_t)width * height >= 0xFFFFFFFEull) return ctx->fail(MA_ERR_INVALID, "bad image size");
+  if (!(K[0] != 0.f) || !(K[1] != 0.f) || !(depth_scale > 0.f) || !std::isfinite(depth_scale)) return ctx->fail(MA_ERR_INVALID, "bad intrinsics / depth_scale");
+  for (int i = 0; i < 16; ++i) if (!std::isfinite(T[i])) return ctx->fail(MA_ERR_INVALID, "non-finite camera pose");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->have_src = false;
+  const uint32_t npx = (uint32_t)((uint64_t)width * height);
+  const size_t esz = dtype == 0 ? 4 : 2;
+  HIPCHK(ctx->depth_in.ensure((size_t)npx * esz));
+  HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, (size_t)npx * esz, hipMemcpyHostToDevice, ctx->stream));
+  Pinhole cam{};
+  cam.fx_inv = 1.0 / (double)K[0];
+  cam.fy_inv = 1.0 / (double)K[1];
+  cam.cx = K[2];
+  cam.cy = K[3];
+  cam.inv_scale = 1.0 / (double)depth_scale;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) cam.T[4 * r + c] = T[4 * r + c];
+    cam.T[4 * r + 3] = T[4 * r + 3] - ctx->origin[r];
+  }
+  const uint32_t nb = div_up(npx, kPxPerBlock);
+  HIPCHK(ctx->keys_a.ensure((size_t)(nb + 1) * 4));
+  HIPCHK(ctx->keys_b.ensure((size_t)(nb + 1) * 4));
+  HIPCHK(hipMemsetAsync(ctx->keys_a.p, 0, (size_t)(nb + 1) * 4, ctx->stream));
+  HIPCHK(ctx->src.ensure((size_t)npx * sizeof(float4)));
+  if (dtype == 0) {
+    hipLaunchKernelGGL((k_unproject<float, 0>), dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
+                       width, npx, cam, ctx->keys_a.as<uint32_t>(), (const uint32_t*)nullptr, (float4*)nullptr);
+  } else {
+    hipLaunchKernelGGL((k_unproject<uint16_t, 0>), dim3(nb), dim3(kBlock), 0, ctx->stream,
+                       ctx->depth_in.as<uint16_t>(), width, npx, cam, ctx->keys_a.as<uint32_t>(),
+                       (const uint32_t*)nullptr, (float4*)nullptr);
+  }
+  HIPCHK(hipGetLastError());
+  size_t tmp_bytes = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(),
+                                          ctx->keys_b.as<uint32_t>(), (int)(nb + 1), ctx->stream));
+  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(),
+                                          ctx->keys_b.as<uint32_t>(), (int)(nb + 1), ctx->stream));
+  if (dtype == 0) {
+    hipLaunchKernelGGL((k_unproject<float, 1>), dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
+                       width, npx, cam, (uint32_t*)nullptr, ctx->keys_b.as<uint32_t>(), ctx->src.as<float4>());
+  } else {
+    hipLaunchKernelGGL((k_unproject<uint16_t, 1>), dim3(nb), dim3(kBlock), 0, ctx->stream,
+                       ctx->depth_in.as<uint16_t>(), width, npx, cam, (uint32_t*)nullptr,
+                       ctx->keys_b.as<uint32_t>(), ctx->src.as<float4>());
+  }
+  HIPCHK(hipGetLastError());
+  uint32_t total = 0;
+  HIPCHK(hipMemcpyAsync(&total, ctx->keys_b.as<uint32_t>() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n_valid) *n_valid = total;
+  if (total == 0) return ctx->fail(MA_ERR_EMPTY, "depth image has no valid pixel");
+  ctx->n = total;
+  ctx->src_sorted = false;
+  ctx->have_src = true;
+  return MA_OK;
+}
+
+int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n) {
+  if (!ctx || !n) return MA_ERR_INVALID;
+  if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set");
+  if (!xyz_out) { *n = ctx->n; return MA_OK; }
+  if (*n < ctx->n) { *n = ctx->n; return ctx->fail(MA_ERR_INVALID, "output capacity too small"); }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(ctx->raw.ensure((size_t)ctx->n * 12));
+  hipLaunchKernelGGL(k_uncentre, dim3(div_up(ctx->n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->src.as<float4>(),
+                     ctx->n, ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->raw.as<float>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(xyz_out, ctx->raw.p, (size_t)ctx->n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *n = ctx->n;
+  return MA_OK;
+}
+
+int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16], ma_stats* stats) {
+  if (!ctx) return MA_ERR_INVALID;
+  int rc;
+  if ((rc = check_params(ctx, params))) return rc;
+  if ((rc = need_ready(ctx))) return rc;
+  if (!T_out) return ctx->fail(MA_ERR_INVALID, "T_out is NULL");
+  if (init) for (int i = 0; i < 16; ++i) if (!std::isfinite(init[i])) return ctx->fail(MA_ERR_INVALID, "non-finite init");
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ensure_loop_buffers(ctx, params->max_iter))) return rc;
+  if ((rc = upload_state(ctx, init))) return rc;
+  const float best2 = open_gate2(params->max_corr_dist);
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int k = 0; k < params->max_iter; ++k) {
+    if ((rc = launch_nn<0>(ctx, params->count_work != 0, best2, nullptr, nullptr))) return rc;
+    if ((rc = launch_reduce_solve(ctx, nullptr, nullptr, params->tol, 1, 1))) return rc;
+  }
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  DevState s;
+  if ((rc = fetch_state(ctx, &s))) return rc;
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  centred_to_world(s, ctx->origin, T_out);
+  fill_stats(s, ms, stats);
+  if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "fewer than 3 correspondences inside max_corr_dist, or rank-deficient covariance");
+  return MA_OK;
+}
+
+int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {
+  if (!ctx || !out || max_rows < 0) return MA_ERR_INVALID;
+  if (!ctx->state.p || !ctx->trace.p) return ctx->fail(MA_ERR_STATE, "no iteration has run");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevState s;
+  int rc = fetch_state(ctx, &s);
+  if (rc) return rc;
+  const int rows = std::min({s.iter, max_rows, ctx->trace_cap});
+  if (rows == 0) return 0;
+  std::vector<double> h((size_t)rows * MA_TRACE_STRIDE);
+  HIPCHK(hipMemcpy(h.data(), ctx->trace.p, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int r = 0; r < rows; ++r) {
+    const double* in = &h[(size_t)r * MA_TRACE_STRIDE];
+    double* o = out + (size_t)r * MA_TRACE_STRIDE;
+    acc_to_world(in, ctx->origin, o);
+    o[17] = in[17]; o[18] = in[18]; o[19] = in[19];
+  }
+  return rows;
+}
+
+int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16], double acc_out[MA_ACC_LEN],
+                double T_out[16]) {
+  if (!ctx) return MA_ERR_INVALID;
+  int rc;
+  if ((rc = check_params(ctx, params))) return rc;
+  if ((rc = need_ready(ctx))) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = upload_state(ctx, T_in))) return rc;
+  if ((rc = launch_nn<0>(ctx, params->count_work != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
+  if ((rc = launch_reduce_solve(ctx, nullptr, ctx->acc19.as<double>(), params->tol, 1, 1))) return rc;
+  double a[kNAcc];
+  HIPCHK(hipMemcpyAsync(a, ctx->acc19.p, sizeof(a), hipMemcpyDeviceToHost, ctx->stream));
+  DevState s;
+  if ((rc = fetch_state(ctx, &s))) return rc;
+  if (acc_out) acc_to_world(a, ctx->origin, acc_out);
+  if (T_out) centred_to_world(s, ctx->origin, T_out);
+  if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "fewer than 3 correspondences inside max_corr_dist, or rank-deficient covariance");
+  return MA_OK;
+}
+
+int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_out, float* d2_out) {
+  if (!ctx) return MA_ERR_INVALID;
+  int rc;
+  if ((rc = need_ready(ctx))) return rc;
+  if (!(max_corr_dist > 0.0)) return ctx->fail(MA_ERR_INVALID, "max_corr_dist must be > 0 (or +inf)");
+  if (!idx_out && !d2_out) return ctx->fail(MA_ERR_INVALID, "no output requested");
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = upload_state(ctx, T))) return rc;
+  const size_t n = ctx->n;
+  HIPCHK(ctx->nn_idx.ensure(n * 4));
+  HIPCHK(ctx->nn_d2.ensure(n * 4));
+  HIPCHK(ctx->nn_tmp.ensure(n * 4));
+  if ((rc = launch_nn<1>(ctx, false, open_gate2(max_corr_dist), ctx->nn_idx.as<uint32_t>(), ctx->nn_d2.as<float>()))) return rc;
+  const uint32_t* perm = ctx->src_sorted ? ctx->src_perm.as<uint32_t>() : nullptr;
+  if (idx_out) {
+    hipLaunchKernelGGL(k_unpermute<uint32_t>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       ctx->nn_idx.as<uint32_t>(), perm, (uint32_t)n, ctx->nn_tmp.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(idx_out, ctx->nn_tmp.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  if (d2_out) {
+    hipLaunchKernelGGL(k_unpermute<float>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       ctx->nn_d2.as<float>(), perm, (uint32_t)n, ctx->nn_tmp.as<float>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(d2_out, ctx->nn_tmp.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return MA_OK;
+}
+
+int ma_state_set(ma_ctx* ctx, const double T[16]) {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "gold map not set");
+  if (T) for (int i = 0; i < 16; ++i) if (!std::isfinite(T[i])) return ctx->fail(MA_ERR_INVALID, "non-finite transform");
+  HIPCHK(hipSetDevice(ctx->device));
+  return upload_state(ctx, T);
+}
+
+int ma_state_get(ma_ctx* ctx, double T_out[16], ma_stats* stats) {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!ctx->state.p) return ctx->fail(MA_ERR_STATE, "no state (ma_state_set / ma_icp first)");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevState s;
+  int rc = fetch_state(ctx, &s);
+  if (rc) return rc;
+  if (T_out) centred_to_world(s, ctx->origin, T_out);
+  fill_stats(s, 0.0, stats);
+  return MA_OK;
+}
+
+int ma_step_accumulate(ma_ctx* ctx, const ma_params* params, void* acc_dev) {
+  if (!ctx) return MA_ERR_INVALID;
+  int rc;
+  if ((rc = check_params(ctx, params))) return rc;
+  if ((rc = need_ready(ctx))) return rc;
+  if (!ctx->state.p) return ctx->fail(MA_ERR_STATE, "ma_state_set first");
+  if (!acc_dev) return ctx->fail(MA_ERR_INVALID, "acc_dev is NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = launch_nn<0>(ctx, params->count_work != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
+  if ((rc = launch_reduce_solve(ctx, nullptr, ctx->acc19.as<double>(), params->tol, 1, 0))) return rc;
+  HIPCHK(hipMemcpyAsync(acc_dev, ctx->acc19.p, MA_ACC_LEN * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return MA_OK;
+}
+
+int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev) {
+  if (!ctx) return MA_ERR_INVALID;
+  int rc;
+  if ((rc = check_params(ctx, params))) return rc;
+  if (!ctx->state.p) return ctx->fail(MA_ERR_STATE, "ma_state_set first");
+  if (!acc_dev) return ctx->fail(MA_ERR_INVALID, "acc_dev is NULL");
+  HIPCHK(hipSetDevice(ctx->device));
+  // rows 17,18 (work counters) keep the local values of the accumulate step
+  HIPCHK(hipMemcpyAsync(ctx->acc19.p, acc_dev, MA_ACC_LEN * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return launch_reduce_solve(ctx, ctx->acc19.as<double>(), nullptr, params->tol, 0, 1);
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+"""Host-side handle on one libmapalign context (= one MI355X + one HIP stream).
+
+Thin by design: argument checking, NumPy <-> pointer plumbing and error translation.
+All arithmetic of rows a4-a8 happens in the HIP kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import MA_ACC_LEN, MA_TRACE_STRIDE, MapAlignError, ma_grid_info, ma_params, ma_stats
+
+
+def _as_T(init):
+    """None | 4x4 | (R, t) -> contiguous 4x4 float64 (or None)."""
+    if init is None:
+        return None
+    if isinstance(init, tuple):
+        R, t = init
+        T = np.eye(4)
+        T[:3, :3] = np.asarray(R, dtype=np.float64)
+        T[:3, 3] = np.asarray(t, dtype=np.float64).reshape(3)
+        return np.ascontiguousarray(T)
+    T = np.ascontiguousarray(init, dtype=np.float64)
+    if T.shape != (4, 4):
+        raise ValueError("transform must be None, a 4x4 matrix or an (R, t) tuple")
+    return T
+
+
+def _f64p(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _cloud(a, name):
+    a = np.asarray(a)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError(f"{name} must have shape [N,3], got {a.shape}")
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+@dataclass
+class AlignResult:
+    T: np.ndarray                  # 4x4, comparison -> gold
+    iterations: int
+    rmse: float
+    inliers: float
+    converged: bool
+    gpu_ms: float
+    trace: np.ndarray = field(default=None, repr=False)   # [iterations, 20] or None
+
+    @property
+    def R(self):
+        return self.T[:3, :3].copy()
+
+    @property
+    def t(self):
+        return self.T[:3, 3].copy()
+
+
+class MapAligner:
+    """One alignment context.  Not thread-safe; use one per host thread / GPU."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        st = self._lib.ma_create(int(device), C.byref(self._ctx))
+        if st < 0:
+            msg = (self._lib.ma_last_error(None) or b"").decode("utf-8", "replace")
+            self._ctx = None
+            raise MapAlignError(st, msg)
+        self.device = int(device)
+        self.n_gold = 0
+        self.n_source = 0
+
+    # -- lifetime -------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.ma_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, status):
+        return _lib.check(self._lib, self._ctx, status)
+
+    @staticmethod
+    def _params(max_iter, tol, max_corr_dist, count_work=False):
+        return ma_params(int(max_iter), int(bool(count_work)), float(tol), float(max_corr_dist))
+
+    def set_stream(self, hip_stream):
+        """Run on a caller-owned hipStream_t (int handle, e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._chk(self._lib.ma_set_stream(self._ctx, C.c_void_p(hip_stream or None)))
+
+    def sync(self):
+        self._chk(self._lib.ma_sync(self._ctx))
+
+    # -- clouds ---------------------------------------------------------------------
+    def set_gold(self, gold_cloud, cell=0.0):
+        g = _cloud(gold_cloud, "gold_cloud")
+        self._chk(self._lib.ma_set_gold(self._ctx, g.ctypes.data_as(C.POINTER(C.c_float)), g.shape[0], float(cell)))
+        self.n_gold = g.shape[0]
+        self.n_source = 0
+        return self.grid_info()
+
+    def grid_info(self):
+        gi = ma_grid_info()
+        self._chk(self._lib.ma_grid_info_get(self._ctx, C.byref(gi)))
+        return {"cell": float(gi.cell), "dims": (gi.nx, gi.ny, gi.nz), "n_cells": int(gi.n_cells),
+                "n_occupied": int(gi.n_occupied), "origin": np.array(list(gi.origin)),
+                "build_ms": float(gi.build_ms)}
+
+    def set_source(self, comparison_cloud, weights=None):
+        s = _cloud(comparison_cloud, "comparison_cloud")
+        w = None
+        if weights is not None:
+            w = np.ascontiguousarray(weights, dtype=np.float32).reshape(-1)
+            if w.shape[0] != s.shape[0]:
+                raise ValueError("weights must have one entry per comparison point")
+        self._chk(self._lib.ma_set_source(self._ctx, s.ctypes.data_as(C.POINTER(C.c_float)),
+                                          None if w is None else w.ctypes.data_as(C.POINTER(C.c_float)),
+                                          s.shape[0]))
+        self.n_source = s.shape[0]
+
+    def set_source_from_depth(self, depth, K, T_cam_to_world, depth_scale=1000.0):
+        """Fused depth -> world unprojection into the source buffer (row a8).  Returns #valid pixels."""
+        d = np.asarray(depth)
+        if d.ndim != 2:
+            raise ValueError("depth must be a 2-D image")
+        if d.dtype == np.uint16:
+            dtype = 1
+        else:
+            d = d.astype(np.float32, copy=False)
+            dtype = 0
+        d = np.ascontiguousarray(d)
+        Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
+        T = np.ascontiguousarray(T_cam_to_world, dtype=np.float64).reshape(4, 4)
+        nv = C.c_uint64(0)
+        self._chk(self._lib.ma_set_source_from_depth(
+            self._ctx, d.ctypes.data_as(C.c_void_p), dtype, d.shape[1], d.shape[0],
+            Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T), float(depth_scale), C.byref(nv)))
+        self.n_source = int(nv.value)
+        return self.n_source
+
+    def get_source(self):
+        n = C.c_uint64(0)
+        self._chk(self._lib.ma_get_source(self._ctx, None, C.byref(n)))
+        out = np.empty((int(n.value), 3), dtype=np.float32)
+        self._chk(self._lib.ma_get_source(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
+        return out
+
+    # -- the loop -------------------------------------------------------------------
+    def icp(self, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None, count_work=False, with_trace=False):
+        p = self._params(max_iter, tol, max_corr_dist, count_work)
+        Tin = _as_T(init)
+        Tout = np.empty((4, 4), dtype=np.float64)
+        st = ma_stats()
+        self._chk(self._lib.ma_icp(self._ctx, C.byref(p), _f64p(Tin), _f64p(Tout), C.byref(st)))
+        tr = self.trace(st.iterations) if with_trace else None
+        return AlignResult(Tout, int(st.iterations), float(st.rmse), float(st.inliers), bool(st.converged),
+                           float(st.gpu_ms), tr)
+
+    def trace(self, max_rows=4096):
+        buf = np.zeros((max(int(max_rows), 1), MA_TRACE_STRIDE), dtype=np.float64)
+        rows = self._chk(self._lib.ma_get_trace(self._ctx, _f64p(buf), buf.shape[0]))
+        return buf[:rows].copy()
+
+    def icp_step(self, T_in=None, max_corr_dist=0.10, count_work=False):
+        """One iteration at T_in: (acc17 world-frame, T_next)."""
+        p = self._params(1, 0.0, max_corr_dist, count_work)
+        Tin = _as_T(T_in)
+        acc = np.empty(MA_ACC_LEN, dtype=np.float64)
+        Tout = np.empty((4, 4), dtype=np.float64)
+        self._chk(self._lib.ma_icp_step(self._ctx, C.byref(p), _f64p(Tin), _f64p(acc), _f64p(Tout)))
+        return acc, Tout
+
+    def nn(self, T=None, max_corr_dist=np.inf):
+        """Nearest gold index (original order; 0xFFFFFFFF = none within the gate) and d^2 per source point."""
+        Tin = _as_T(T)
+        idx = np.empty(self.n_source, dtype=np.uint32)
+        d2 = np.empty(self.n_source, dtype=np.float32)
+        self._chk(self._lib.ma_nn(self._ctx, _f64p(Tin), float(max_corr_dist),
+                                  idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                  d2.ctypes.data_as(C.POINTER(C.c_float))))
+        return idx, d2
+
+    # -- split stepping (sharded-source multi-GPU mode) -------------------------------
+    def state_set(self, T=None):
+        self._chk(self._lib.ma_state_set(self._ctx, _f64p(_as_T(T))))
+
+    def state_get(self):
+        Tout = np.empty((4, 4), dtype=np.float64)
+        st = ma_stats()
+        self._chk(self._lib.ma_state_get(self._ctx, _f64p(Tout), C.byref(st)))
+        return Tout, {"iterations": int(st.iterations), "converged": bool(st.converged),
+                      "degenerate": bool(st.degenerate), "rmse": float(st.rmse), "inliers": float(st.inliers)}
+
+    def step_accumulate(self, acc_dev_ptr, max_corr_dist=0.10, count_work=False):
+        p = self._params(1, 0.0, max_corr_dist, count_work)
+        self._chk(self._lib.ma_step_accumulate(self._ctx, C.byref(p), C.c_void_p(int(acc_dev_ptr))))
+
+    def step_solve(self, acc_dev_ptr, tol=0.0, max_corr_dist=0.10):
+        p = self._params(1, tol, max_corr_dist)
+        self._chk(self._lib.ma_step_solve(self._ctx, C.byref(p), C.c_void_p(int(acc_dev_ptr))))

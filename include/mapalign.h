@@ -1,0 +1,153 @@
+/*
+ * mapalign.h — C ABI of libmapalign.so, the MI355X (gfx950) map-alignment engine.
+ *
+ * Drop-in boundary for the map-alignment path of ben-sanati/3d-localisation-and-mapping.
+ * The reference has no FFI: its boundary is the Python call
+ *     Alignment(base_pose_df, comparison_pose_df, base_bboxes, comparison_bboxes,
+ *               visualise).compare(data_folder)                 (task_def.py:175-187)
+ * whose body (src/map_alignment/align.py) is absent from the snapshot.  The entry points
+ * below are what a ctypes binding for that body's hot loop binds; each cites the row of
+ * SURVEY.md §8a / the reference line whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - return 0 (MA_OK) on success, a negative ma_status otherwise; ma_last_error(ctx)
+ *     gives the message; no C++ exception crosses this boundary.
+ *   - the caller owns every host buffer (row-major, contiguous, borrowed only for the
+ *     duration of the call); the library owns every device buffer inside the opaque ctx.
+ *   - one ctx = one HIP device + one stream.  A ctx is not thread-safe; different ctxs
+ *     may be driven from different host threads.  No global state but the HIP runtime.
+ *   - rigid transforms are 4x4 row-major doubles mapping comparison -> gold coordinates,
+ *     p' = T @ [p,1], the matrix form consumed by src/map_alignment/visualise.py:94-96,128-130.
+ *   - there is NO CPU fallback: without a usable HIP device ma_create fails with
+ *     MA_ERR_NO_DEVICE.
+ */
+#ifndef MAPALIGN_H
+#define MAPALIGN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MA_VERSION 100 /* 0.1.0 */
+#define MA_ACC_LEN 17  /* W, s_p[3], s_q[3], S[9] row-major (S_ab = sum w p'_a q_b), E */
+#define MA_TRACE_STRIDE 20 /* per-iteration trace row: acc[17], rmse, rows_visited, candidates */
+#define MA_NO_MATCH 0xFFFFFFFFu
+
+typedef struct ma_ctx ma_ctx;
+
+typedef enum ma_status {
+  MA_OK = 0,
+  MA_ERR_INVALID = -1,   /* bad argument (null pointer, non-finite parameter, ...) */
+  MA_ERR_NO_DEVICE = -2, /* no HIP device / device index out of range */
+  MA_ERR_HIP = -3,       /* a HIP runtime call failed; see ma_last_error */
+  MA_ERR_EMPTY = -4,     /* empty cloud / no valid depth pixel */
+  MA_ERR_STATE = -5,     /* call order: gold map or source cloud not set */
+  MA_ERR_DEGENERATE = -6,/* < 3 correspondences or rank-deficient covariance */
+  MA_ERR_TOO_LARGE = -7  /* more than 2^32-2 points */
+} ma_status;
+
+/* Loop parameters (rows a4-a7).  The reference exposes no alignment hyper-parameters
+ * (SURVEY.md §5 "Config / flags"), so these are the build's, mirrored by the oracle. */
+typedef struct ma_params {
+  int32_t max_iter;     /* iteration cap (benchmark: 50) */
+  int32_t count_work;   /* !=0: also count grid rows visited / candidates examined (slower) */
+  double tol;           /* stop after iteration k>=1 when |rmse_k - rmse_{k-1}| < tol; 0 = never */
+  double max_corr_dist; /* correspondence gate in metres (w_i = 1[d_i <= gate]); +inf = ungated */
+} ma_params;
+
+typedef struct ma_stats {
+  int32_t iterations;   /* iterations actually run */
+  int32_t converged;    /* 1 if the tol test fired */
+  int32_t degenerate;   /* 1 if an iteration had < 3 correspondences / rank < 2 (loop stopped) */
+  int32_t reserved;
+  double rmse;          /* sqrt(E/W) of the last iteration run (before its update) */
+  double inliers;       /* W of the last iteration run */
+  double gpu_ms;        /* device time of the whole loop (hipEvent, on the ctx stream) */
+} ma_stats;
+
+typedef struct ma_grid_info {
+  float cell;           /* cell edge actually used (m) */
+  int32_t nx, ny, nz;   /* grid dimensions */
+  uint64_t n_cells;
+  uint64_t n_occupied;  /* non-empty cells */
+  double origin[3];     /* centring origin subtracted before fp32 storage (world frame) */
+  double build_ms;      /* device time of the last grid build */
+} ma_grid_info;
+
+int ma_version(void);
+const char* ma_status_string(int status);
+/* Message of the last failure on ctx (or of the last failed ma_create when ctx == NULL). */
+const char* ma_last_error(const ma_ctx* ctx);
+
+/* Lifetime.  `device` is a HIP device ordinal. */
+int ma_create(int device, ma_ctx** out);
+int ma_destroy(ma_ctx* ctx);
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the
+ * ctx's own; pass NULL to return to the own stream. */
+int ma_set_stream(ma_ctx* ctx, void* hip_stream);
+int ma_sync(ma_ctx* ctx);
+
+/* Gold ("base") map: upload M x 3 fp32 points and build the uniform grid used by the
+ * nearest-neighbour search (row a4; replaces loading the gold .ply and whatever index
+ * align.py built — mapping.py:63-68 is the ingest precedent).  cell <= 0 picks the cell
+ * edge from the point density.  Invalidates a previously set source cloud. */
+int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell);
+int ma_grid_info_get(const ma_ctx* ctx, ma_grid_info* out);
+
+/* Comparison ("maintenance") cloud: N x 3 fp32 points, optional per-point weights
+ * (NULL = 1).  Needs the gold map first (points are stored relative to its origin). */
+int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t n);
+
+/* Row a8: fused depth -> 3-D unprojection written straight into the source-cloud device
+ * buffer.  Pinhole model of pose_processor.py:133-137,184-196,242-260:
+ *   Z = depth[y][x] / depth_scale;  X = (x-cx) Z / fx;  Y = (y-cy) Z / fy;
+ *   g = (T_cam_to_world @ [X,Y,Z,1])[:3]
+ * K = {fx, fy, cx, cy} already rescaled to the depth resolution.  dtype: 0 = float32
+ * (the reference's format, dataset.py:68-81: float32 millimetres, depth_scale = 1000),
+ * 1 = uint16.  Pixels with depth <= 0 / NaN / inf are dropped; survivors keep row-major
+ * pixel order.  *n_valid receives the number of points written. */
+int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height,
+                             const float K[4], const double T_cam_to_world[16],
+                             float depth_scale, uint64_t* n_valid);
+/* Copy the current source cloud back (world frame, storage order); *n in = capacity in
+ * points, out = points written.  For parity tests of the unprojection kernel. */
+int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n);
+
+/* Rows a4-a7: the whole ICP loop on the device.  init = NULL means identity.
+ * T_out receives the composed comparison->gold transform. */
+int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16],
+           ma_stats* stats);
+/* Per-iteration trace of the last ma_icp / stepping sequence: row k =
+ * {acc[17] in WORLD coordinates, rmse_k, rows_visited_k, candidates_k}; the last two are
+ * zero unless params->count_work.  Returns the number of rows written (<= max_rows) or a
+ * negative status. */
+int ma_get_trace(ma_ctx* ctx, double* out, int max_rows);
+
+/* One iteration at transform T_in (NULL = identity): accumulators (world frame) and the
+ * updated transform.  For parity tests (rows a4-a6). */
+int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16],
+                double acc_out[MA_ACC_LEN], double T_out[16]);
+
+/* Row a4 alone: nearest gold point of every source point under T (NULL = identity), in
+ * the ORIGINAL order of both clouds; unmatched (d > gate) -> MA_NO_MATCH / +inf. */
+int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_out,
+          float* d2_out);
+
+/* Split stepping for the sharded-source multi-GPU mode: every rank holds
+ * the whole gold map and a shard of the source cloud; per iteration
+ *   ma_step_accumulate -> all-reduce(sum) of MA_ACC_LEN doubles (RCCL) -> ma_step_solve.
+ * acc_dev is a DEVICE pointer to MA_ACC_LEN doubles owned by the caller (e.g. a torch
+ * tensor's data_ptr); accumulators are in the ctx's centred frame, which is identical
+ * on all ranks because it derives from the gold map alone.  Nothing here synchronises
+ * with the host. */
+int ma_state_set(ma_ctx* ctx, const double T[16]);
+int ma_state_get(ma_ctx* ctx, double T_out[16], ma_stats* stats);
+int ma_step_accumulate(ma_ctx* ctx, const ma_params* params, void* acc_dev);
+int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPALIGN_H */
