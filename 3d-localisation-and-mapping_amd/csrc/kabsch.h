@@ -27,40 +27,56 @@ namespace ma {
 constexpr int kAccLen = 17;
 constexpr double kMinCorrespondences = 3.0;
 
-// G (3x3 row-major) is overwritten by U*Sig (columns), V accumulates the right rotations.
-MA_HD inline void jacobi_svd3(double G[9], double V[9], double sig[3]) {
-  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+struct Col3 { double x, y, z; };
+
+MA_HD inline double dot3(const Col3& a, const Col3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MA_HD inline Col3 cross3(const Col3& a, const Col3& b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+MA_HD inline void swap_col(Col3& a, Col3& b) { const Col3 t = a; a = b; b = t; }
+
+// One Hestenes rotation: makes columns gp, gq of G orthogonal, applies the same rotation
+// to the columns vp, vq of V.  Returns the relative size of the off-diagonal it removed.
+MA_HD inline double jacobi_rotate(Col3& gp, Col3& gq, Col3& vp, Col3& vq) {
+  const double alpha = dot3(gp, gp), beta = dot3(gq, gq), gamma = dot3(gp, gq);
+  const double scale = sqrt(alpha * beta);
+  if (fabs(gamma) <= 1e-300 + 1e-16 * scale) return 0.0;  // already orthogonal
+  const double zeta = (beta - alpha) / (2.0 * gamma);
+  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double c = 1.0 / sqrt(1.0 + t * t);
+  const double s = c * t;
+  const Col3 g0 = gp, g1 = gq, w0 = vp, w1 = vq;
+  gp = {c * g0.x - s * g1.x, c * g0.y - s * g1.y, c * g0.z - s * g1.z};
+  gq = {s * g0.x + c * g1.x, s * g0.y + c * g1.y, s * g0.z + c * g1.z};
+  vp = {c * w0.x - s * w1.x, c * w0.y - s * w1.y, c * w0.z - s * w1.z};
+  vq = {s * w0.x + c * w1.x, s * w0.y + c * w1.y, s * w0.z + c * w1.z};
+  return fabs(gamma) / scale;
+}
+
+// A = U Sig V^T for a 3x3 given by its COLUMNS g0,g1,g2 (overwritten by the columns of
+// U Sig); v0,v1,v2 receive the columns of V.  No run-time array indexing: everything stays
+// in registers on the device.
+MA_HD inline void jacobi_svd3_cols(Col3& g0, Col3& g1, Col3& g2, Col3& v0, Col3& v1, Col3& v2) {
+  v0 = {1.0, 0.0, 0.0};
+  v1 = {0.0, 1.0, 0.0};
+  v2 = {0.0, 0.0, 1.0};
   for (int sweep = 0; sweep < 30; ++sweep) {
-    double off = 0.0;
-    for (int p = 0; p < 2; ++p) {
-      for (int q = p + 1; q < 3; ++q) {
-        double alpha = 0.0, beta = 0.0, gamma = 0.0;
-        for (int r = 0; r < 3; ++r) {
-          alpha += G[3 * r + p] * G[3 * r + p];
-          beta += G[3 * r + q] * G[3 * r + q];
-          gamma += G[3 * r + p] * G[3 * r + q];
-        }
-        const double scale = sqrt(alpha * beta);
-        if (fabs(gamma) <= 1e-300 + 1e-16 * scale) continue;  // already orthogonal
-        off = fmax(off, fabs(gamma) / scale);
-        const double zeta = (beta - alpha) / (2.0 * gamma);
-        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double c = 1.0 / sqrt(1.0 + t * t);
-        const double s = c * t;
-        for (int r = 0; r < 3; ++r) {
-          const double gp = G[3 * r + p], gq = G[3 * r + q];
-          G[3 * r + p] = c * gp - s * gq;
-          G[3 * r + q] = s * gp + c * gq;
-          const double vp = V[3 * r + p], vq = V[3 * r + q];
-          V[3 * r + p] = c * vp - s * vq;
-          V[3 * r + q] = s * vp + c * vq;
-        }
-      }
-    }
+    double off = jacobi_rotate(g0, g1, v0, v1);
+    off = fmax(off, jacobi_rotate(g0, g2, v0, v2));
+    off = fmax(off, jacobi_rotate(g1, g2, v1, v2));
     if (off < 1e-15) break;
   }
-  for (int j = 0; j < 3; ++j)
-    sig[j] = sqrt(G[j] * G[j] + G[3 + j] * G[3 + j] + G[6 + j] * G[6 + j]);
+}
+
+// Row-major array front end (used by the host-side unit test): G is overwritten by U*Sig.
+MA_HD inline void jacobi_svd3(double G[9], double V[9], double sig[3]) {
+  Col3 g0{G[0], G[3], G[6]}, g1{G[1], G[4], G[7]}, g2{G[2], G[5], G[8]}, v0, v1, v2;
+  jacobi_svd3_cols(g0, g1, g2, v0, v1, v2);
+  G[0] = g0.x; G[3] = g0.y; G[6] = g0.z; G[1] = g1.x; G[4] = g1.y; G[7] = g1.z;
+  G[2] = g2.x; G[5] = g2.y; G[8] = g2.z;
+  V[0] = v0.x; V[3] = v0.y; V[6] = v0.z; V[1] = v1.x; V[4] = v1.y; V[7] = v1.z;
+  V[2] = v2.x; V[5] = v2.y; V[8] = v2.z;
+  sig[0] = sqrt(dot3(g0, g0)); sig[1] = sqrt(dot3(g1, g1)); sig[2] = sqrt(dot3(g2, g2));
 }
 
 MA_HD inline double det3(const double M[9]) {
@@ -71,49 +87,46 @@ MA_HD inline double det3(const double M[9]) {
 // acc = {W, s_p[3], s_q[3], S[9] (S_ab = sum w p_a q_b), E}.  Writes dR (row-major) and dt.
 // Returns 0 on success, 1 if degenerate (W < 3, non-finite input, or rank(H) < 2), in
 // which case dR = I, dt = 0.
-MA_HD inline int kabsch_from_acc(const double acc[kAccLen], double dR[9], double dt[3]) {
-  for (int i = 0; i < 9; ++i) dR[i] = (i % 4 == 0) ? 1.0 : 0.0;
+MA_HD inline int kabsch_from_acc(const double* acc, double dR[9], double dt[3]) {
+  dR[0] = 1.0; dR[1] = 0.0; dR[2] = 0.0; dR[3] = 0.0; dR[4] = 1.0; dR[5] = 0.0;
+  dR[6] = 0.0; dR[7] = 0.0; dR[8] = 1.0;
   dt[0] = dt[1] = dt[2] = 0.0;
   bool finite = true;
   for (int i = 0; i < kAccLen; ++i) finite = finite && isfinite(acc[i]);
   const double W = acc[0];
   if (!finite || !(W >= kMinCorrespondences)) return 1;
-  double mp[3], mq[3];
-  for (int a = 0; a < 3; ++a) {
-    mp[a] = acc[1 + a] / W;
-    mq[a] = acc[4 + a] / W;
-  }
-  double G[9], V[9], sig[3];
-  for (int a = 0; a < 3; ++a)
-    for (int b = 0; b < 3; ++b) G[3 * a + b] = acc[7 + 3 * a + b] - W * mp[a] * mq[b];
-  jacobi_svd3(G, V, sig);
-  // order the singular directions: i0 largest, i2 smallest
-  int i0 = 0, i1 = 1, i2 = 2;
-  if (sig[i0] < sig[i1]) { int s = i0; i0 = i1; i1 = s; }
-  if (sig[i1] < sig[i2]) { int s = i1; i1 = i2; i2 = s; }
-  if (sig[i0] < sig[i1]) { int s = i0; i0 = i1; i1 = s; }
-  if (!(sig[i1] > 1e-12 * sig[i0]) || !(sig[i0] > 0.0)) return 1;
-  // U columns for the two leading directions; the third is their cross product, which
-  // also covers a vanishing third singular value (planar correspondences).
-  double u0[3], u1[3], u2[3], v0[3], v1[3], v2[3];
-  for (int r = 0; r < 3; ++r) {
-    u0[r] = G[3 * r + i0] / sig[i0];
-    u1[r] = G[3 * r + i1] / sig[i1];
-    v0[r] = V[3 * r + i0];
-    v1[r] = V[3 * r + i1];
-  }
-  u2[0] = u0[1] * u1[2] - u0[2] * u1[1];
-  u2[1] = u0[2] * u1[0] - u0[0] * u1[2];
-  u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
-  v2[0] = v0[1] * v1[2] - v0[2] * v1[1];
-  v2[1] = v0[2] * v1[0] - v0[0] * v1[2];
-  v2[2] = v0[0] * v1[1] - v0[1] * v1[0];
-  // With u2 = u0 x u1 and v2 = v0 x v1 both frames are right-handed, so
-  // dR = v0 u0^T + v1 u1^T + v2 u2^T has det +1: this IS V diag(1,1,det(VU^T)) U^T.
-  for (int a = 0; a < 3; ++a)
-    for (int b = 0; b < 3; ++b) dR[3 * a + b] = v0[a] * u0[b] + v1[a] * u1[b] + v2[a] * u2[b];
-  for (int a = 0; a < 3; ++a)
-    dt[a] = mq[a] - (dR[3 * a] * mp[0] + dR[3 * a + 1] * mp[1] + dR[3 * a + 2] * mp[2]);
+  const Col3 mp{acc[1] / W, acc[2] / W, acc[3] / W}, mq{acc[4] / W, acc[5] / W, acc[6] / W};
+  // H_ab = S_ab - W mp_a mq_b ; columns of H (index b)
+  Col3 g0{acc[7] - W * mp.x * mq.x, acc[10] - W * mp.y * mq.x, acc[13] - W * mp.z * mq.x};
+  Col3 g1{acc[8] - W * mp.x * mq.y, acc[11] - W * mp.y * mq.y, acc[14] - W * mp.z * mq.y};
+  Col3 g2{acc[9] - W * mp.x * mq.z, acc[12] - W * mp.y * mq.z, acc[15] - W * mp.z * mq.z};
+  Col3 v0, v1, v2;
+  jacobi_svd3_cols(g0, g1, g2, v0, v1, v2);
+  double s0 = sqrt(dot3(g0, g0)), s1 = sqrt(dot3(g1, g1)), s2 = sqrt(dot3(g2, g2));
+  // order the singular directions (largest first) with conditional swaps
+  if (s0 < s1) { swap_col(g0, g1); swap_col(v0, v1); const double t = s0; s0 = s1; s1 = t; }
+  if (s1 < s2) { swap_col(g1, g2); swap_col(v1, v2); const double t = s1; s1 = s2; s2 = t; }
+  if (s0 < s1) { swap_col(g0, g1); swap_col(v0, v1); const double t = s0; s0 = s1; s1 = t; }
+  if (!(s1 > 1e-12 * s0) || !(s0 > 0.0)) return 1;
+  // U columns of the two leading directions; the third of BOTH frames is the cross product
+  // of the first two.  That covers a vanishing third singular value (planar
+  // correspondences) and makes both frames right-handed, so
+  //   dR = v0 u0^T + v1 u1^T + (v0 x v1)(u0 x u1)^T
+  // has det +1: it IS V diag(1,1,det(V U^T)) U^T with the flip on the smallest direction.
+  const Col3 u0{g0.x / s0, g0.y / s0, g0.z / s0}, u1{g1.x / s1, g1.y / s1, g1.z / s1};
+  const Col3 u2 = cross3(u0, u1), w2 = cross3(v0, v1);
+  dR[0] = v0.x * u0.x + v1.x * u1.x + w2.x * u2.x;
+  dR[1] = v0.x * u0.y + v1.x * u1.y + w2.x * u2.y;
+  dR[2] = v0.x * u0.z + v1.x * u1.z + w2.x * u2.z;
+  dR[3] = v0.y * u0.x + v1.y * u1.x + w2.y * u2.x;
+  dR[4] = v0.y * u0.y + v1.y * u1.y + w2.y * u2.y;
+  dR[5] = v0.y * u0.z + v1.y * u1.z + w2.y * u2.z;
+  dR[6] = v0.z * u0.x + v1.z * u1.x + w2.z * u2.x;
+  dR[7] = v0.z * u0.y + v1.z * u1.y + w2.z * u2.y;
+  dR[8] = v0.z * u0.z + v1.z * u1.z + w2.z * u2.z;
+  dt[0] = mq.x - (dR[0] * mp.x + dR[1] * mp.y + dR[2] * mp.z);
+  dt[1] = mq.y - (dR[3] * mp.x + dR[4] * mp.y + dR[5] * mp.z);
+  dt[2] = mq.z - (dR[6] * mp.x + dR[7] * mp.y + dR[8] * mp.z);
   return 0;
 }
 

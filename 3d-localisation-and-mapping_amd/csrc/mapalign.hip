@@ -188,10 +188,10 @@ template <bool COUNT>
 __device__ __forceinline__ void nn_search(const float px, const float py, const float pz,
                                           const float4* __restrict__ gold,
                                           const uint32_t* __restrict__ cstart, const GridP& g,
-                                          const float best2_init, float& best2, uint32_t& bestj,
+                                          float& best2, uint32_t& bestj, float4& bestq,
                                           uint32_t& nrows, uint32_t& ncand) {
-  best2 = best2_init;
-  bestj = kNoMatch;
+  // best2 / bestj / bestq come in initialised by the caller: (gate, none) or the previous
+  // iteration's match, which is a valid candidate and usually already the answer.
   if (!(isfinite(px) && isfinite(py) && isfinite(pz))) return;
   // centre row, clamped to one cell outside the grid: for a query outside the grid the
   // ring bound (r-1)*c then under-estimates the true distance, which keeps it valid.
@@ -233,7 +233,7 @@ __device__ __forceinline__ void nn_search(const float px, const float py, const 
           const float4 q = gold[j];
           const float dx = px - q.x, dyy = py - q.y, dzz = pz - q.z;
           const float d2 = dx * dx + dyy * dyy + dzz * dzz;
-          if (d2 < best2) { best2 = d2; bestj = j; }
+          if (d2 < best2) { best2 = d2; bestj = j; bestq = q; }
         }
       }
     }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
     const float4* __restrict__ src, const uint32_t n, const uint32_t chunk,
     const float4* __restrict__ gold, const uint32_t* __restrict__ cstart, const GridP g,
     const DevState* __restrict__ st, const float best2_init, double* __restrict__ partials,
-    uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2) {
+    uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2) {
   if (MODE == 0 && st->done) return;
   const uint32_t G = gridDim.x;
   const uint32_t cb = xcd_chunk(blockIdx.x, G);
@@ -274,12 +274,24 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
     const double Px = R[0] * s.x + R[1] * s.y + R[2] * s.z + t[0];
     const double Py = R[3] * s.x + R[4] * s.y + R[5] * s.z + t[1];
     const double Pz = R[6] * s.x + R[7] * s.y + R[8] * s.z + t[2];
-    float best2;
-    uint32_t bestj;
-    nn_search<COUNT>((float)Px, (float)Py, (float)Pz, gold, cstart, g, best2_init, best2, bestj,
-                     nrows, ncand);
+    const float px = (float)Px, py = (float)Py, pz = (float)Pz;
+    float best2 = best2_init;
+    uint32_t bestj = kNoMatch;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (prev) {
+      // temporal coherence: last iteration's match bounds the search radius from the start
+      const uint32_t pj = prev[i];
+      if (pj != kNoMatch) {
+        const float4 c = gold[pj];
+        const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (COUNT) ncand += 1u;
+        if (d2 < best2) { best2 = d2; bestj = pj; q = c; }
+      }
+    }
+    nn_search<COUNT>(px, py, pz, gold, cstart, g, best2, bestj, q, nrows, ncand);
+    if (prev) prev[i] = bestj;
     if (bestj != kNoMatch) {
-      const float4 q = gold[bestj];
       if (MODE == 1) { nn_idx[i] = __float_as_uint(q.w); nn_d2[i] = best2; }
       const double w = (double)s.w;
       const double qx = q.x, qy = q.y, qz = q.z;
@@ -314,29 +326,46 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
   }
 }
 
-// a5 (final sum) + a6 + a7.  One workgroup.
+// a5 (final sum) + a6 + a7.  One workgroup of 1024 threads (16 wavefronts).
 //   do_reduce: acc = fixed-order sum of partials[k][0..G); optionally stored to acc_out
 //   else     : acc = acc_in[0..19)
 //   do_solve : Kabsch step, composition, convergence test, trace row
-__global__ __launch_bounds__(kBlock) void k_reduce_solve(
+// All 2 x 19 partial loads of a thread are issued before the first use, so the kernel pays
+// one memory round trip, not 19; the serial tail is one lane of fp64 Jacobi sweeps.
+constexpr int kSolveBlock = 1024;
+constexpr int kSolveWaves = kSolveBlock / kWave;
+static_assert(kMaxGrid <= 2 * kSolveBlock, "k_reduce_solve reads at most two partials per thread");
+
+__global__ __launch_bounds__(kSolveBlock) void k_reduce_solve(
     const double* __restrict__ partials, const int G, const double* __restrict__ acc_in,
     double* __restrict__ acc_out, DevState* __restrict__ st, double* __restrict__ trace,
     const int trace_cap, const double tol, const int do_reduce, const int do_solve) {
   if (st->done) return;
-  __shared__ double red[kBlock / kWave][kNAcc];
+  __shared__ double red[kSolveWaves][kNAcc];
   __shared__ double acc[kNAcc];
+  // thread 0 fetches the state while the partials are in flight
+  DevState s0;
+  if (threadIdx.x == 0 && do_solve) s0 = *st;
   if (do_reduce) {
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int b0 = threadIdx.x, b1 = threadIdx.x + kSolveBlock;
+    double v0[kNAcc], v1[kNAcc];
+#pragma unroll
     for (int k = 0; k < kNAcc; ++k) {
-      double v = 0.0;
-      for (int b = threadIdx.x; b < G; b += kBlock) v += partials[(size_t)k * G + b];
-      v = wave_sum(v);
+      v0[k] = b0 < G ? partials[(size_t)k * G + b0] : 0.0;
+      v1[k] = b1 < G ? partials[(size_t)k * G + b1] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kNAcc; ++k) {
+      const double v = wave_sum(v0[k] + v1[k]);
       if (lane == 0) red[wv][k] = v;
     }
     __syncthreads();
     if (threadIdx.x < kNAcc) {
       const int k = threadIdx.x;
-      const double v = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+      double v = red[0][k];
+#pragma unroll
+      for (int w = 1; w < kSolveWaves; ++w) v += red[w][k];
       acc[k] = v;
       if (acc_out) acc_out[k] = v;
     }
@@ -346,38 +375,46 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(
   __syncthreads();
   if (!do_solve || threadIdx.x != 0) return;
 
-  double a[ma::kAccLen];
-  for (int k = 0; k < ma::kAccLen; ++k) a[k] = acc[k];
-  const int it = st->iter;
+  double a[kNAcc];
+#pragma unroll
+  for (int k = 0; k < kNAcc; ++k) a[k] = acc[k];
+  const int it = s0.iter;
   const double W = a[0];
   const double rmse = W > 0.0 ? sqrt(a[16] / W) : NAN;
   if (it < trace_cap) {
     double* row = trace + (size_t)it * MA_TRACE_STRIDE;
+#pragma unroll
     for (int k = 0; k < ma::kAccLen; ++k) row[k] = a[k];
-    row[17] = rmse; row[18] = acc[17]; row[19] = acc[18];
+    row[17] = rmse; row[18] = a[17]; row[19] = a[18];
   }
-  st->iter = it + 1;
-  st->last_rmse = rmse;
-  st->last_W = W;
+  s0.iter = it + 1;
+  s0.last_rmse = rmse;
+  s0.last_W = W;
   double dR[9], dt[3];
   if (ma::kabsch_from_acc(a, dR, dt)) {
-    st->degenerate = 1;
-    st->done = 1;
+    s0.degenerate = 1;
+    s0.done = 1;
+    *st = s0;
     return;
   }
   double Rn[9], tn[3];
+#pragma unroll
   for (int r = 0; r < 3; ++r) {
+#pragma unroll
     for (int c = 0; c < 3; ++c)
-      Rn[3 * r + c] = dR[3 * r] * st->R[c] + dR[3 * r + 1] * st->R[3 + c] + dR[3 * r + 2] * st->R[6 + c];
-    tn[r] = dR[3 * r] * st->t[0] + dR[3 * r + 1] * st->t[1] + dR[3 * r + 2] * st->t[2] + dt[r];
+      Rn[3 * r + c] = dR[3 * r] * s0.R[c] + dR[3 * r + 1] * s0.R[3 + c] + dR[3 * r + 2] * s0.R[6 + c];
+    tn[r] = dR[3 * r] * s0.t[0] + dR[3 * r + 1] * s0.t[1] + dR[3 * r + 2] * s0.t[2] + dt[r];
   }
-  for (int i = 0; i < 9; ++i) st->R[i] = Rn[i];
-  for (int i = 0; i < 3; ++i) st->t[i] = tn[i];
-  if (it >= 1 && fabs(rmse - st->prev_rmse) < tol) {
-    st->converged = 1;
-    st->done = 1;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s0.R[i] = Rn[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) s0.t[i] = tn[i];
+  if (it >= 1 && fabs(rmse - s0.prev_rmse) < tol) {
+    s0.converged = 1;
+    s0.done = 1;
   }
-  st->prev_rmse = rmse;
+  s0.prev_rmse = rmse;
+  *st = s0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -526,9 +563,11 @@ struct ma_ctx {
   DevBuf raw, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
 
   // loop state
-  DevBuf state, partials, trace, acc19, nn_idx, nn_d2, nn_tmp;
+  DevBuf state, partials, trace, acc19, nn_idx, nn_d2, nn_tmp, prev;
   int trace_cap = 0;
   int last_G = 0;
+  std::vector<hipEvent_t> kev;   // MA_FLAG_TIME_KERNELS
+  double ktimes[4] = {0, 0, 0, 0};
 
   int fail(int code, const std::string& msg) {
     err = msg;
@@ -723,6 +762,10 @@ int upload_state(ma_ctx* ctx, const double* T) {
   s.iter = 0; s.done = 0; s.converged = 0; s.degenerate = 0;
   // pageable source: hipMemcpyAsync stages it before returning, so `s` may go out of scope
   HIPCHK(hipMemcpyAsync(ctx->state.p, &s, sizeof(s), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->have_src) {  // a new run starts without remembered matches
+    HIPCHK(ctx->prev.ensure((size_t)ctx->n * 4));
+    HIPCHK(hipMemsetAsync(ctx->prev.p, 0xFF, (size_t)ctx->n * 4, ctx->stream));
+  }
   return MA_OK;
 }
 
@@ -743,7 +786,8 @@ int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float
   auto args = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(lg.G), dim3(kBlock), 0, ctx->stream, ctx->src.as<float4>(), ctx->n, lg.chunk,
                        ctx->gold.as<float4>(), ctx->cstart.as<uint32_t>(), ctx->grid,
-                       ctx->state.as<DevState>(), best2_init, ctx->partials.as<double>(), nn_idx, nn_d2);
+                       ctx->state.as<DevState>(), best2_init, ctx->partials.as<double>(),
+                       MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, nn_idx, nn_d2);
   };
   if (count) args(k_nn_accum<true, MODE>);
   else args(k_nn_accum<false, MODE>);
@@ -753,7 +797,7 @@ int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float
 
 int launch_reduce_solve(ma_ctx* ctx, const double* acc_in, double* acc_out, double tol, int do_reduce,
                         int do_solve) {
-  hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
+  hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(kSolveBlock), 0, ctx->stream, ctx->partials.as<double>(),
                      ctx->last_G, acc_in, acc_out, ctx->state.as<DevState>(), ctx->trace.as<double>(),
                      ctx->trace_cap, tol, do_reduce, do_solve);
   HIPCHK(hipGetLastError());
@@ -840,8 +884,9 @@ int ma_destroy(ma_ctx* ctx) {
   for (DevBuf* b : {&ctx->gold, &ctx->cstart, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
                     &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc, &ctx->depth_in,
                     &ctx->state, &ctx->partials, &ctx->trace, &ctx->acc19, &ctx->nn_idx, &ctx->nn_d2,
-                    &ctx->nn_tmp})
+                    &ctx->nn_tmp, &ctx->prev})
     b->release();
+  for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -849,11 +894,11 @@ int ma_destroy(ma_ctx* ctx) {
   return MA_OK;
 }
 
-int ma_set_stream(ma_ctx* ctx, void* hip_stream) {
+int ma_set_stream(ma_ctx* ctx, void* hip_stream, int external) {
   if (!ctx) return MA_ERR_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  ctx->stream = external ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
   return MA_OK;
 }
 
@@ -1097,16 +1142,37 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   if ((rc = ensure_loop_buffers(ctx, params->max_iter))) return rc;
   if ((rc = upload_state(ctx, init))) return rc;
   const float best2 = open_gate2(params->max_corr_dist);
+  const bool timek = (params->flags & MA_FLAG_TIME_KERNELS) != 0;
+  if (timek) {
+    while ((int)ctx->kev.size() < 2 * params->max_iter + 1) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreate(&e));
+      ctx->kev.push_back(e);
+    }
+  }
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  if (timek) HIPCHK(hipEventRecord(ctx->kev[0], ctx->stream));
   for (int k = 0; k < params->max_iter; ++k) {
-    if ((rc = launch_nn<0>(ctx, params->count_work != 0, best2, nullptr, nullptr))) return rc;
+    if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr))) return rc;
+    if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
     if ((rc = launch_reduce_solve(ctx, nullptr, nullptr, params->tol, 1, 1))) return rc;
+    if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 2], ctx->stream));
   }
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   DevState s;
   if ((rc = fetch_state(ctx, &s))) return rc;
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (timek) {
+    ctx->ktimes[0] = ctx->ktimes[1] = ctx->ktimes[2] = ctx->ktimes[3] = 0;
+    for (int k = 0; k < s.iter && k < params->max_iter; ++k) {   // launches after `done` are no-ops: skip them
+      float a = 0, b = 0;
+      HIPCHK(hipEventElapsedTime(&a, ctx->kev[2 * k], ctx->kev[2 * k + 1]));
+      HIPCHK(hipEventElapsedTime(&b, ctx->kev[2 * k + 1], ctx->kev[2 * k + 2]));
+      ctx->ktimes[0] += a; ctx->ktimes[1] += 1;
+      ctx->ktimes[2] += b; ctx->ktimes[3] += 1;
+    }
+  }
   centred_to_world(s, ctx->origin, T_out);
   fill_stats(s, ms, stats);
   if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "fewer than 3 correspondences inside max_corr_dist, or rank-deficient covariance");
@@ -1133,6 +1199,12 @@ int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {
   return rows;
 }
 
+int ma_get_kernel_times(ma_ctx* ctx, double out[4]) {
+  if (!ctx || !out) return MA_ERR_INVALID;
+  for (int i = 0; i < 4; ++i) out[i] = ctx->ktimes[i];
+  return MA_OK;
+}
+
 int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16], double acc_out[MA_ACC_LEN],
                 double T_out[16]) {
   if (!ctx) return MA_ERR_INVALID;
@@ -1141,7 +1213,7 @@ int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16], dou
   if ((rc = need_ready(ctx))) return rc;
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = upload_state(ctx, T_in))) return rc;
-  if ((rc = launch_nn<0>(ctx, params->count_work != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
+  if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
   if ((rc = launch_reduce_solve(ctx, nullptr, ctx->acc19.as<double>(), params->tol, 1, 1))) return rc;
   double a[kNAcc];
   HIPCHK(hipMemcpyAsync(a, ctx->acc19.p, sizeof(a), hipMemcpyDeviceToHost, ctx->stream));
@@ -1212,7 +1284,7 @@ int ma_step_accumulate(ma_ctx* ctx, const ma_params* params, void* acc_dev) {
   if (!ctx->state.p) return ctx->fail(MA_ERR_STATE, "ma_state_set first");
   if (!acc_dev) return ctx->fail(MA_ERR_INVALID, "acc_dev is NULL");
   HIPCHK(hipSetDevice(ctx->device));
-  if ((rc = launch_nn<0>(ctx, params->count_work != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
+  if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
   if ((rc = launch_reduce_solve(ctx, nullptr, ctx->acc19.as<double>(), params->tol, 1, 0))) return rc;
   HIPCHK(hipMemcpyAsync(acc_dev, ctx->acc19.p, MA_ACC_LEN * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return MA_OK;

@@ -17,6 +17,8 @@ LIB_PATH = PKG_ROOT / "lib" / "libmapalign.so"
 MA_ACC_LEN = 17
 MA_TRACE_STRIDE = 20
 MA_NO_MATCH = 0xFFFFFFFF
+MA_FLAG_COUNT_WORK = 1
+MA_FLAG_TIME_KERNELS = 2
 
 MA_OK = 0
 MA_ERR_INVALID = -1
@@ -41,7 +43,7 @@ class MapAlignLibraryError(ImportError):
 
 
 class ma_params(C.Structure):
-    _fields_ = [("max_iter", C.c_int32), ("count_work", C.c_int32), ("tol", C.c_double),
+    _fields_ = [("max_iter", C.c_int32), ("flags", C.c_int32), ("tol", C.c_double),
                 ("max_corr_dist", C.c_double)]
 
 
@@ -70,7 +72,7 @@ ABI = {
     "ma_last_error": (C.c_char_p, [_ctx_p]),
     "ma_create": (C.c_int, [C.c_int, C.POINTER(_ctx_p)]),
     "ma_destroy": (C.c_int, [_ctx_p]),
-    "ma_set_stream": (C.c_int, [_ctx_p, C.c_void_p]),
+    "ma_set_stream": (C.c_int, [_ctx_p, C.c_void_p, C.c_int]),
     "ma_sync": (C.c_int, [_ctx_p]),
     "ma_set_gold": (C.c_int, [_ctx_p, _f32p, C.c_uint64, C.c_float]),
     "ma_grid_info_get": (C.c_int, [_ctx_p, C.POINTER(ma_grid_info)]),
@@ -80,6 +82,7 @@ ABI = {
     "ma_get_source": (C.c_int, [_ctx_p, _f32p, _u64p]),
     "ma_icp": (C.c_int, [_ctx_p, C.POINTER(ma_params), _f64p, _f64p, C.POINTER(ma_stats)]),
     "ma_get_trace": (C.c_int, [_ctx_p, _f64p, C.c_int]),
+    "ma_get_kernel_times": (C.c_int, [_ctx_p, _f64p]),
     "ma_icp_step": (C.c_int, [_ctx_p, C.POINTER(ma_params), _f64p, _f64p, _f64p]),
     "ma_nn": (C.c_int, [_ctx_p, _f64p, C.c_double, _u32p, _f32p]),
     "ma_state_set": (C.c_int, [_ctx_p, _f64p]),

@@ -97,12 +97,20 @@ class MapAligner:
         return _lib.check(self._lib, self._ctx, status)
 
     @staticmethod
-    def _params(max_iter, tol, max_corr_dist, count_work=False):
-        return ma_params(int(max_iter), int(bool(count_work)), float(tol), float(max_corr_dist))
+    def _params(max_iter, tol, max_corr_dist, count_work=False, time_kernels=False):
+        flags = (_lib.MA_FLAG_COUNT_WORK if count_work else 0) | (_lib.MA_FLAG_TIME_KERNELS if time_kernels else 0)
+        return ma_params(int(max_iter), flags, float(tol), float(max_corr_dist))
 
-    def set_stream(self, hip_stream):
-        """Run on a caller-owned hipStream_t (int handle, e.g. torch.cuda.current_stream().cuda_stream)."""
-        self._chk(self._lib.ma_set_stream(self._ctx, C.c_void_p(hip_stream or None)))
+    def set_stream(self, hip_stream, external=True):
+        """Run on a caller-owned hipStream_t given as an int handle, e.g.
+        ``torch.cuda.current_stream().cuda_stream`` (0 = the legacy default stream, which is
+        what torch returns for its default stream).  ``external=False`` returns to the
+        context's own stream."""
+        self._chk(self._lib.ma_set_stream(self._ctx, C.c_void_p(int(hip_stream) if hip_stream else None),
+                                          1 if external else 0))
+
+    def use_own_stream(self):
+        self.set_stream(None, external=False)
 
     def sync(self):
         self._chk(self._lib.ma_sync(self._ctx))
@@ -162,8 +170,9 @@ class MapAligner:
         return out
 
     # -- the loop -------------------------------------------------------------------
-    def icp(self, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None, count_work=False, with_trace=False):
-        p = self._params(max_iter, tol, max_corr_dist, count_work)
+    def icp(self, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None, count_work=False, with_trace=False,
+            time_kernels=False):
+        p = self._params(max_iter, tol, max_corr_dist, count_work, time_kernels)
         Tin = _as_T(init)
         Tout = np.empty((4, 4), dtype=np.float64)
         st = ma_stats()
@@ -171,6 +180,12 @@ class MapAligner:
         tr = self.trace(st.iterations) if with_trace else None
         return AlignResult(Tout, int(st.iterations), float(st.rmse), float(st.inliers), bool(st.converged),
                            float(st.gpu_ms), tr)
+
+    def kernel_times(self):
+        """{nn_ms, nn_launches, solve_ms, solve_launches} of the last icp(time_kernels=True)."""
+        out = np.zeros(4, dtype=np.float64)
+        self._chk(self._lib.ma_get_kernel_times(self._ctx, _f64p(out)))
+        return {"nn_ms": out[0], "nn_launches": int(out[1]), "solve_ms": out[2], "solve_launches": int(out[3])}
 
     def trace(self, max_rows=4096):
         buf = np.zeros((max(int(max_rows), 1), MA_TRACE_STRIDE), dtype=np.float64)

@@ -34,6 +34,8 @@ extern "C" {
 #define MA_ACC_LEN 17  /* W, s_p[3], s_q[3], S[9] row-major (S_ab = sum w p'_a q_b), E */
 #define MA_TRACE_STRIDE 20 /* per-iteration trace row: acc[17], rmse, rows_visited, candidates */
 #define MA_NO_MATCH 0xFFFFFFFFu
+#define MA_FLAG_COUNT_WORK 1   /* also count grid rows visited / candidates examined (slower kernel) */
+#define MA_FLAG_TIME_KERNELS 2 /* bracket every kernel launch of ma_icp with hipEvents (perturbs the loop) */
 
 typedef struct ma_ctx ma_ctx;
 
@@ -52,7 +54,7 @@ typedef enum ma_status {
  * (SURVEY.md §5 "Config / flags"), so these are the build's, mirrored by the oracle. */
 typedef struct ma_params {
   int32_t max_iter;     /* iteration cap (benchmark: 50) */
-  int32_t count_work;   /* !=0: also count grid rows visited / candidates examined (slower) */
+  int32_t flags;        /* MA_FLAG_* bits */
   double tol;           /* stop after iteration k>=1 when |rmse_k - rmse_{k-1}| < tol; 0 = never */
   double max_corr_dist; /* correspondence gate in metres (w_i = 1[d_i <= gate]); +inf = ungated */
 } ma_params;
@@ -84,9 +86,10 @@ const char* ma_last_error(const ma_ctx* ctx);
 /* Lifetime.  `device` is a HIP device ordinal. */
 int ma_create(int device, ma_ctx** out);
 int ma_destroy(ma_ctx* ctx);
-/* Run on a caller-provided hipStream_t (e.g. torch's current stream) instead of the
- * ctx's own; pass NULL to return to the own stream. */
-int ma_set_stream(ma_ctx* ctx, void* hip_stream);
+/* external != 0: run on the caller's hipStream_t `hip_stream` (e.g. torch's current
+ * stream; NULL is then the legacy default stream, which is what torch hands out for its
+ * default stream).  external == 0: return to the ctx's own stream (hip_stream ignored). */
+int ma_set_stream(ma_ctx* ctx, void* hip_stream, int external);
 int ma_sync(ma_ctx* ctx);
 
 /* Gold ("base") map: upload M x 3 fp32 points and build the uniform grid used by the
@@ -121,9 +124,13 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
            ma_stats* stats);
 /* Per-iteration trace of the last ma_icp / stepping sequence: row k =
  * {acc[17] in WORLD coordinates, rmse_k, rows_visited_k, candidates_k}; the last two are
- * zero unless params->count_work.  Returns the number of rows written (<= max_rows) or a
+ * zero unless MA_FLAG_COUNT_WORK.  Returns the number of rows written (<= max_rows) or a
  * negative status. */
 int ma_get_trace(ma_ctx* ctx, double* out, int max_rows);
+
+/* Per-kernel device time of the last ma_icp run with MA_FLAG_TIME_KERNELS:
+ * out = {nn_accum total ms, nn_accum launches, reduce_solve total ms, reduce_solve launches}. */
+int ma_get_kernel_times(ma_ctx* ctx, double out[4]);
 
 /* One iteration at transform T_in (NULL = identity): accumulators (world frame) and the
  * updated transform.  For parity tests (rows a4-a6). */

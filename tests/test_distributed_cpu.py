@@ -1,0 +1,118 @@
+"""world_size-2 `gloo` tests of the multi-GPU scheduling code (mapalign/dist.py) on CPU.
+
+The product engine needs a GPU, so these drive the SAME scheduling functions with a
+stand-in engine built on the oracle (tests may use the oracle; the product may not).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+
+class OracleShardEngine:
+    """CPU stand-in with the HipShardEngine interface."""
+
+    def __init__(self, gold, comp_shard, gate):
+        from oracle import icp_oracle as orc
+        self.orc = orc
+        self.index = orc.GoldIndex(gold, n_jobs=1)
+        self.comp = np.asarray(comp_shard, dtype=np.float64)
+        self.gate = gate
+        self.iters = 0
+
+    def state_set(self, T=None):
+        self.R, self.t = self.orc.as_matrix(T)
+        self.iters = 0
+
+    def accumulate_into(self, acc):
+        p_t = self.comp @ self.R.T + self.t
+        idx, d2 = self.index.query(p_t)
+        w = (d2 <= self.gate ** 2).astype(np.float64)
+        acc.copy_(torch.from_numpy(self.orc.accumulate(p_t, self.index.gold[idx], w, d2)))
+
+    def solve_from(self, acc):
+        dR, dt, ok = self.orc.kabsch_from_acc(acc.numpy())
+        assert ok
+        self.R, self.t = dR @ self.R, dR @ self.t + dt
+        self.iters += 1
+
+    def state_get(self):
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = self.R, self.t
+        return T, {"iterations": self.iters}
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (PKG, ROOT):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapalign import dist as mdist
+    from mapalign import synthetic as syn
+
+    # --- sharded source: all-reduce of the 17-double accumulator only
+    gold, comp, _, _ = syn.make_pair(21, 3000, 2501, resample=False if False else True)
+    lo, hi = mdist.shard_bounds(len(comp), world, rank)
+    eng = OracleShardEngine(gold, comp[lo:hi], 0.4)
+    acc = torch.zeros(mdist.ACC_LEN, dtype=torch.float64)
+    T, info = mdist.sharded_icp(eng, acc, max_iter=6)
+    # --- pair-per-GPU: no collective in the loop, one gather at the end
+    calls = []
+
+    def fake_align(g, c):
+        calls.append(1)
+        T = np.eye(4)
+        T[0, 3] = float(len(g) + len(c))
+        return T
+
+    pairs = [(np.zeros((10 + i, 3)), np.zeros((5, 3))) for i in range(5)]
+    res = mdist.align_pairs(pairs, align_fn=fake_align)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), T=T, iters=info["iterations"], pair_T=np.stack(res),
+             n_calls=len(calls))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_bounds_cover_everything():
+    from mapalign import dist as mdist
+    for n in (1, 7, 100, 1_000_003):
+        for w in (1, 2, 3, 8):
+            spans = [mdist.shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert mdist.pairs_for_rank(8, 8, 3) == [3] and mdist.pairs_for_rank(5, 2, 1) == [1, 3]
+
+
+def test_world2_sharded_and_pair_modes(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    # every rank ends with the identical transform ...
+    assert np.array_equal(r0["T"], r1["T"]) and int(r0["iters"]) == 6
+    # ... equal to the single-process oracle on the whole cloud (sum order differs: 1e-10)
+    from mapalign import synthetic as syn
+    from oracle import icp_oracle as orc
+    gold, comp, _, _ = syn.make_pair(21, 3000, 2501)
+    ref = orc.icp_oracle(gold, comp, max_iter=6, max_corr_dist=0.4, n_jobs=1)
+    assert np.allclose(r0["T"][:3, :3], ref["R"], atol=1e-10) and np.allclose(r0["T"][:3, 3], ref["t"], atol=1e-10)
+    # pair mode: work split 3 + 2, results complete and ordered on both ranks
+    assert int(r0["n_calls"]) == 3 and int(r1["n_calls"]) == 2
+    assert np.array_equal(r0["pair_T"], r1["pair_T"])
+    assert [int(T[0, 3]) for T in r0["pair_T"]] == [15, 16, 17, 18, 19]

@@ -1,0 +1,443 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(ctypes, mapalign.MapAligner), against the CPU oracle on identical seeded inputs, against
+the committed golden fixtures, and — at BASELINE.json's full 1M-point size — through
+size-independent properties (align(A, T.A) = T, cell-size invariance, determinism).
+
+Tolerances (BASELINE.json:north_star): ||R - R_cpu||_F <= 1e-4, ||t - t_cpu||_2 <= 1 mm.
+Index work (nearest-neighbour ids) must be exact, up to exact distance ties.
+"""
+import numpy as np
+import pytest
+
+import mapalign
+from mapalign import synthetic as syn
+from oracle import icp_oracle as orc
+
+from conftest import R_TOL_FRO, T_TOL_M
+
+pytestmark = pytest.mark.gpu
+
+NO_MATCH = 0xFFFFFFFF
+# inputs are re-centred and stored as fp32 on the device (<= 0.5 ulp(10 m) = 0.5 um per
+# coordinate); fp64 sums over >= 1e3 points therefore agree to ~1e-8 relative
+ACC_RTOL = 2e-7
+
+
+# coordinates are stored re-centred in fp32 on the device: each one is within 0.5 ulp(10 m)
+# ~ 0.5 um of the oracle's, so distances agree to a few um (NOT to a relative tolerance:
+# d^2 of a 1 mm match moves by 2 d delta ~ 1e-9 m^2)
+DIST_ATOL_M = 5e-6
+
+
+def assert_nn_matches(idx, d2, oidx, od2, gate=np.inf):
+    """Exact index parity; a differing index is accepted only as a tie at storage precision."""
+    matched = od2 <= gate ** 2
+    borderline = np.abs(np.sqrt(od2) - gate) < 2 * DIST_ATOL_M
+    ok_unmatched = (idx == NO_MATCH) == (~matched)
+    assert (ok_unmatched | borderline).all()
+    m = matched & (idx != NO_MATCH)
+    differ = m & (idx.astype(np.int64) != oidx)
+    if m.any():
+        assert np.abs(np.sqrt(d2[m].astype(np.float64)) - np.sqrt(od2[m])).max() <= DIST_ATOL_M
+        assert differ.mean() < 1e-3      # ties only (already distance-checked above)
+
+
+def acc_close(a, b):
+    scale = np.abs(b).max()
+    return np.abs(np.asarray(a) - np.asarray(b)).max() <= ACC_RTOL * scale
+
+
+# ----------------------------------------------------------------------------- row a4
+@pytest.mark.parametrize("n_gold,n_comp", [(10_000, 10_000), (4097, 1023), (1, 300), (257, 1), (5000, 7777)])
+def test_nn_exact_vs_bruteforce(engine, n_gold, n_comp):
+    gold, comp, _, _ = syn.make_pair(30, max(n_gold, 2), max(n_comp, 2))
+    gold, comp = gold[:n_gold], comp[:n_comp]
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    oidx, od2 = orc.nn_bruteforce(gold, comp)
+    idx, d2 = engine.nn(None, np.inf)               # ungated: ring expansion to the whole grid
+    assert_nn_matches(idx, d2, oidx, od2)
+    idx, d2 = engine.nn(None, 0.10)                 # gated
+    assert_nn_matches(idx, d2, oidx, od2, gate=0.10)
+
+
+@pytest.mark.parametrize("cell", [0.0, 0.01, 0.1, 1.0, 50.0])
+def test_nn_independent_of_cell_size(engine, cell):
+    gold, comp, R0, t0 = syn.make_pair(31, 20_000, 15_000)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R0, t0 + [0.3, -0.2, 0.1]
+    engine.set_gold(gold, cell)
+    engine.set_source(comp)
+    p_t = comp.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    oidx, od2 = orc.GoldIndex(gold, n_jobs=4).query(p_t)
+    idx, d2 = engine.nn(T, 0.25)
+    assert_nn_matches(idx, d2, oidx, od2, gate=0.25)
+    idx, d2 = engine.nn(T, np.inf)
+    assert_nn_matches(idx, d2, oidx, od2)
+
+
+def test_nn_far_outside_the_grid_and_duplicates(engine):
+    rng = np.random.default_rng(32)
+    gold = rng.uniform(-1, 1, size=(3000, 3)).astype(np.float32)
+    gold[100:200] = gold[100]                          # 100 exact duplicates
+    comp = np.concatenate([rng.uniform(-1, 1, size=(500, 3)), rng.uniform(-1, 1, size=(500, 3)) * 40.0,
+                           gold[100:101].repeat(5, 0)]).astype(np.float32)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    oidx, od2 = orc.nn_bruteforce(gold, comp)
+    idx, d2 = engine.nn(None, np.inf)
+    m = np.ones(len(comp), bool)
+    # duplicates: any of the duplicate ids is a correct answer
+    dup = (oidx >= 100) & (oidx < 200)
+    assert np.abs(np.sqrt(d2.astype(np.float64)) - np.sqrt(od2)).max() <= 2e-5   # coordinates up to 40 m
+    assert (idx[~dup & m].astype(np.int64) != oidx[~dup & m]).mean() < 1e-3
+    assert ((idx[dup] >= 100) & (idx[dup] < 200)).all()
+    idx, d2 = engine.nn(None, 0.05)
+    assert ((idx == NO_MATCH) == (od2 > 0.05 ** 2)).all()
+
+
+# ----------------------------------------------------------------------------- rows a4-a6
+@pytest.mark.parametrize("gate", [0.10, 0.35, np.inf])
+def test_one_iteration_accumulators_and_solve(engine, gate):
+    gold, comp, _, _ = syn.make_pair(33, 12_000, 9_000)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    index = orc.GoldIndex(gold, n_jobs=4)
+    T0 = np.eye(4)
+    T0[:3, :3] = syn.rotation_about_axis([0, 0, 1], 0.004)
+    T0[:3, 3] = [0.01, 0.02, -0.01]
+    oacc, _, _, Rn, tn, ok = orc.icp_step(index, comp, T0[:3, :3], T0[:3, 3], gate)
+    acc, Tn = engine.icp_step(T0, gate)
+    assert ok and acc_close(acc, oacc)
+    assert acc[0] == oacc[0]                                  # inlier count is integer work: exact
+    eR, et = orc.rt_error(Tn[:3, :3], Tn[:3, 3], Rn, tn)
+    assert eR <= 1e-7 and et <= 1e-6
+
+
+def test_weights(engine, golden):
+    g = golden("pair_weighted.npz")
+    engine.set_gold(g["gold"])
+    engine.set_source(g["comp"], g["weights"])
+    res = engine.icp(int(g["iters"]), 0.0, float(g["gate"]), with_trace=True)
+    eR, et = orc.rt_error(res.R, res.t, g["R"], g["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    for k in range(int(g["iters"])):
+        assert acc_close(res.trace[k, :17], g["acc"][k]), k
+
+
+# ----------------------------------------------------------------------------- rows a4-a7
+def test_config1_10k_pair_vs_oracle_and_truth(engine):
+    gold, comp, R0, t0 = syn.make_pair(0, 10_000, resample=False)       # BASELINE configs[0]
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    res = engine.icp(50, 0.0, 0.10, with_trace=True)
+    ref = orc.icp_oracle(gold, comp, max_iter=50, max_corr_dist=0.10, n_jobs=4)
+    eR, et = orc.rt_error(res.R, res.t, ref["R"], ref["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    eR, et = orc.rt_error(res.R, res.t, R0, t0)
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    assert res.iterations == 50 and res.inliers == ref["inliers"]
+    for k in (0, 1, 5, 20):
+        assert acc_close(res.trace[k, :17], ref["trace"][k]["acc"]), k
+
+
+def test_resampled_pair_vs_oracle(engine):
+    gold, comp, _, _ = syn.make_pair(1, 60_000, 50_000)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    res = engine.icp(30, 0.0, 0.10, with_trace=True)
+    ref = orc.icp_oracle(gold, comp, max_iter=30, max_corr_dist=0.10, n_jobs=8)
+    eR, et = orc.rt_error(res.R, res.t, ref["R"], ref["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    assert abs(res.inliers - ref["inliers"]) <= 2          # fp32 vs fp64 gate on the boundary
+    assert abs(res.rmse - ref["rmse"]) <= 1e-6
+
+
+def test_golden_pair(engine, golden):
+    g = golden("pair_a.npz")
+    engine.set_gold(g["gold"])
+    engine.set_source(g["comp"])
+    idx, d2 = engine.nn(None, np.inf)
+    assert_nn_matches(idx, d2, g["nn0"], g["d20"])
+    res = engine.icp(int(g["iters"]), 0.0, float(g["gate"]), with_trace=True)
+    eR, et = orc.rt_error(res.R, res.t, g["R"], g["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    assert res.trace.shape[0] == int(g["iters"])
+    for k in range(int(g["iters"])):
+        assert acc_close(res.trace[k, :17], g["acc"][k]), k
+    assert np.allclose(res.trace[:, 17], g["rmse"], atol=1e-7)
+
+
+def test_align_function_surface():
+    gold, comp, R0, t0 = syn.make_pair(2, 8000, resample=False)
+    R, t = mapalign.align(gold, comp)
+    assert R.shape == (3, 3) and t.shape == (3,) and R.dtype == np.float64
+    eR, et = orc.rt_error(R, t, R0, t0)
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    R2, t2, info = mapalign.align(gold.astype(np.float64), comp.tolist(), return_info=True, max_iter=5)
+    assert info["iterations"] == 5 and info["trace"].shape == (5, 20)
+
+
+def test_init_transform_and_tuple_form(engine):
+    gold, comp, R0, t0 = syn.make_pair(3, 9000, resample=False)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    # start from the true transform: must stay there
+    res = engine.icp(3, 0.0, 0.10, init=(R0, t0))
+    eR, et = orc.rt_error(res.R, res.t, R0, t0)
+    assert eR <= 1e-6 and et <= 1e-5
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R0, t0
+    res2 = engine.icp(3, 0.0, 0.10, init=T)
+    assert np.array_equal(res.T, res2.T)
+
+
+def test_tol_early_stop_matches_oracle(engine):
+    gold, comp, _, _ = syn.make_pair(4, 6000, resample=False)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    ref = orc.icp_oracle(gold, comp, max_iter=50, tol=1e-7, max_corr_dist=0.3, n_jobs=4)
+    res = engine.icp(50, 1e-7, 0.3)
+    assert res.converged and ref["converged"]
+    assert abs(res.iterations - ref["iterations"]) <= 1 and res.iterations < 50
+    eR, et = orc.rt_error(res.R, res.t, ref["R"], ref["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+
+
+def test_ungated_far_start(engine):
+    gold, comp, R0, t0 = syn.make_pair(5, 5000, resample=False, angle_deg=4.0, t0=np.array([0.5, -0.3, 0.2]))
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    res = engine.icp(40, 0.0, np.inf)
+    ref = orc.icp_oracle(gold, comp, max_iter=40, max_corr_dist=np.inf, n_jobs=4)
+    eR, et = orc.rt_error(res.R, res.t, ref["R"], ref["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+
+
+def test_bitwise_deterministic(engine):
+    gold, comp, _, _ = syn.make_pair(6, 50_000, 40_000)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    a = engine.icp(10, 0.0, 0.10, with_trace=True)
+    b = engine.icp(10, 0.0, 0.10, with_trace=True)
+    assert np.array_equal(a.T, b.T) and np.array_equal(a.trace, b.trace)
+    with mapalign.MapAligner(0) as other:                   # fresh context, fresh grid build
+        other.set_gold(gold)
+        other.set_source(comp)
+        c = other.icp(10, 0.0, 0.10, with_trace=True)
+    assert np.array_equal(a.T, c.T) and np.array_equal(a.trace, c.trace)
+
+
+def test_work_counters_do_not_change_results(engine):
+    gold, comp, _, _ = syn.make_pair(7, 20_000, 20_000)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    a = engine.icp(5, 0.0, 0.10, with_trace=True)
+    b = engine.icp(5, 0.0, 0.10, with_trace=True, count_work=True)
+    assert np.array_equal(a.T, b.T) and np.array_equal(a.trace[:, :18], b.trace[:, :18])
+    assert (a.trace[:, 18:] == 0).all() and (b.trace[:, 18] >= 20_000 * 0.5).all() and (b.trace[:, 19] > 0).all()
+
+
+# ----------------------------------------------------------------------------- edge cases
+def test_error_paths(engine):
+    gold, comp, _, _ = syn.make_pair(8, 2000, resample=False)
+    E = mapalign.MapAlignError
+    with pytest.raises(E) as e:
+        engine.set_source(comp)                              # source before gold
+    assert e.value.status == -5
+    with pytest.raises(E) as e:
+        engine.set_gold(np.zeros((0, 3), np.float32))
+    assert e.value.status == -4
+    bad = gold.copy()
+    bad[5, 1] = np.nan
+    with pytest.raises(E) as e:
+        engine.set_gold(bad)
+    assert e.value.status == -1
+    engine.set_gold(gold)
+    with pytest.raises(E) as e:
+        engine.icp()                                         # gold but no source
+    assert e.value.status == -5
+    with pytest.raises(E) as e:
+        engine.set_source(np.zeros((0, 3), np.float32))
+    assert e.value.status == -4
+    bad = comp.copy()
+    bad[0, 0] = np.inf
+    with pytest.raises(E):
+        engine.set_source(bad)
+    with pytest.raises(ValueError):
+        engine.set_source(np.zeros((5, 2), np.float32))
+    engine.set_source(comp)
+    for kw in ({"max_iter": 0}, {"tol": -1.0}, {"max_corr_dist": 0.0}, {"max_corr_dist": np.nan}):
+        with pytest.raises(E) as e:
+            engine.icp(**kw)
+        assert e.value.status == -1
+    engine.set_source(comp + 100.0)                          # no correspondence inside the gate
+    with pytest.raises(E) as e:
+        engine.icp(5, 0.0, 0.10)
+    assert e.value.status == -6
+    engine.set_source(comp[:2])                              # fewer than 3 points
+    with pytest.raises(E) as e:
+        engine.icp(5, 0.0, np.inf)
+    assert e.value.status == -6
+    engine.set_gold(gold[:1])                                # rank-deficient: everything maps to one point
+    engine.set_source(comp)
+    with pytest.raises(E) as e:
+        engine.icp(5, 0.0, np.inf)
+    assert e.value.status == -6
+    with pytest.raises(E):
+        mapalign.MapAligner(99)                              # no such device
+
+
+def test_context_reuse_across_clouds(engine):
+    for seed, n in ((9, 3000), (10, 12_000), (11, 500)):
+        gold, comp, R0, t0 = syn.make_pair(seed, n, resample=False)
+        engine.set_gold(gold)
+        engine.set_source(comp)
+        res = engine.icp(50, 0.0, 0.25 if n < 1000 else 0.10)
+        eR, et = orc.rt_error(res.R, res.t, R0, t0)
+        assert eR <= R_TOL_FRO and et <= T_TOL_M, (seed, eR, et)
+
+
+# ----------------------------------------------------------------------------- row a8
+def test_golden_depth_unprojection(engine, golden):
+    g = golden("depth_a.npz")
+    gold, _, _, _ = syn.make_pair(13, 4000)
+    engine.set_gold(gold)
+    n = engine.set_source_from_depth(g["depth"], g["K"], g["T"], float(g["scale"]))
+    assert n == int(g["mask"].sum())
+    pts = engine.get_source()
+    # world coordinates up to 20 m stored as centred fp32: 1 ulp(10 m) ~ 1e-6 m
+    assert np.abs(pts.astype(np.float64) - g["points"]).max() <= 4e-6
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint16])
+def test_depth_unprojection_vs_oracle_and_pipeline(engine, dtype):
+    # BASELINE configs[2] at reduced size: depth frame -> cloud -> align against the gold map
+    depth, K, T = syn.make_depth_frame(0, width=320, height=240, fx=250.0, fy=250.0, cx=159.5, cy=119.5)
+    if dtype == np.uint16:
+        depth = np.clip(np.round(depth), 0, 65535).astype(np.uint16)
+    gold, _, _, _ = syn.make_pair(0, 200_000)
+    engine.set_gold(gold)
+    n = engine.set_source_from_depth(depth, K, T, 1000.0)
+    opts, mask = orc.unproject_oracle(depth, K, T, 1000.0)
+    assert n == int(mask.sum()) and n > 0.9 * depth.size
+    pts = engine.get_source()
+    assert np.abs(pts.astype(np.float64) - opts).max() <= 4e-6
+    # perturb the camera pose by a small rigid motion and recover it through the fused path
+    dT = np.eye(4)
+    dT[:3, :3] = syn.rotation_about_axis([0.2, 1.0, 0.1], np.deg2rad(0.5))
+    dT[:3, 3] = [0.03, -0.02, 0.02]
+    n2 = engine.set_source_from_depth(depth, K, dT @ T, 1000.0)
+    assert n2 == n
+    res = engine.icp(40, 0.0, 0.10)
+    ref = orc.icp_oracle(gold, engine.get_source(), max_iter=40, max_corr_dist=0.10, n_jobs=8)
+    eR, et = orc.rt_error(res.R, res.t, ref["R"], ref["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    idx, d2 = engine.nn(None, 0.10)                          # unsorted (pixel-order) source path
+    oidx, od2 = orc.GoldIndex(gold, n_jobs=8).query(engine.get_source())
+    assert_nn_matches(idx, d2, oidx, od2, gate=0.10)
+
+
+def test_depth_error_paths(engine):
+    gold, _, _, _ = syn.make_pair(14, 1000)
+    engine.set_gold(gold)
+    K, T = (50.0, 50.0, 16.0, 12.0), np.eye(4)
+    with pytest.raises(mapalign.MapAlignError) as e:
+        engine.set_source_from_depth(np.zeros((24, 32), np.float32), K, T)
+    assert e.value.status == -4                              # no valid pixel
+    with pytest.raises(mapalign.MapAlignError):
+        engine.set_source_from_depth(np.ones((24, 32), np.float32), (0.0, 50.0, 1.0, 1.0), T)
+    with pytest.raises(ValueError):
+        engine.set_source_from_depth(np.ones((24,), np.float32), K, T)
+
+
+# ----------------------------------------------------------------------------- sharded stepping
+def test_split_stepping_two_shards_equals_one_context(lib_built):
+    """Sharded-source mode on ONE GPU: two contexts each hold half the source cloud; the
+    17-double accumulators are summed (what RCCL's all-reduce does across GPUs) and both
+    solve.  Must equal the single-context loop."""
+    import torch
+    from mapalign import dist as mdist
+
+    gold, comp, _, _ = syn.make_pair(15, 40_000, 30_001)
+    with mapalign.MapAligner(0) as full:
+        full.set_gold(gold)
+        full.set_source(comp)
+        ref = full.icp(12, 0.0, 0.10)
+    engs, accs = [], []
+    for r in range(2):
+        lo, hi = mdist.shard_bounds(len(comp), 2, r)
+        a = mapalign.MapAligner(0)
+        a.set_gold(gold)
+        a.set_source(comp[lo:hi])
+        he = mdist.HipShardEngine(a, 0.10, 0.0)
+        he.bind_current_stream()
+        he.state_set(None)
+        engs.append(he)
+        accs.append(he.new_acc())
+    for _ in range(12):
+        for he, acc in zip(engs, accs):
+            he.accumulate_into(acc)
+        total = accs[0] + accs[1]
+        for he, acc in zip(engs, accs):
+            acc.copy_(total)
+            he.solve_from(acc)
+    T0, i0 = engs[0].state_get()
+    T1, i1 = engs[1].state_get()
+    for he in engs:
+        he.aligner.use_own_stream()
+        he.aligner.close()
+    assert np.array_equal(T0, T1) and i0["iterations"] == 12
+    assert np.allclose(T0, ref.T, atol=1e-11)
+    assert i0["inliers"] == ref.inliers
+
+
+def test_sharded_icp_driver_single_rank(lib_built):
+    from mapalign import dist as mdist
+    gold, comp, R0, t0 = syn.make_pair(16, 8000, resample=False)
+    R, t, info = mdist.sharded_align(gold, comp, max_iter=50, device=0)
+    eR, et = orc.rt_error(R, t, R0, t0)
+    assert eR <= R_TOL_FRO and et <= T_TOL_M and info["iterations"] == 50
+
+
+# ----------------------------------------------------------------------------- full size (1M)
+def test_full_size_1m_known_transform_and_invariances(engine):
+    """BASELINE configs[1] size.  The oracle needs minutes here, so parity is shown through
+    properties: align(A, T.A) recovers T; the result does not depend on the grid cell;
+    two runs are bitwise equal."""
+    gold, comp, R0, t0 = syn.make_pair(0, 1_000_000, resample=False)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    res = engine.icp(50, 0.0, 0.10, with_trace=True)
+    eR, et = orc.rt_error(res.R, res.t, R0, t0)
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    assert res.inliers == 1_000_000 and res.rmse < 1e-5
+    again = engine.icp(50, 0.0, 0.10)
+    assert np.array_equal(res.T, again.T)
+    engine.set_gold(gold, 0.10)
+    engine.set_source(comp)
+    coarse = engine.icp(50, 0.0, 0.10)
+    assert np.allclose(coarse.T, res.T, atol=1e-9)
+    # linearity of the accumulators: W, s_p, s_q of iteration 0 equal direct sums over matched points
+    idx, d2 = engine.nn(None, 0.10)
+    m = idx != NO_MATCH
+    assert res.trace[0, 0] == m.sum()
+    assert np.allclose(res.trace[0, 1:4], comp[m].astype(np.float64).sum(0), rtol=1e-9)
+    assert np.allclose(res.trace[0, 4:7], gold[idx[m]].astype(np.float64).sum(0), rtol=1e-9)
+
+
+def test_full_size_1m_resampled_pair_one_step_vs_oracle(engine):
+    """One full-size iteration against the KD-tree oracle (a single 1M query is affordable)."""
+    gold, comp, R0, t0 = syn.make_pair(0, 1_000_000)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    T0 = np.eye(4)
+    T0[:3, :3], T0[:3, 3] = R0, t0                        # near the optimum: everything inside the gate
+    index = orc.GoldIndex(gold, n_jobs=-1)
+    oacc, oidx, od2, Rn, tn, ok = orc.icp_step(index, comp, R0, t0, 0.10)
+    acc, Tn = engine.icp_step(T0, 0.10)
+    assert acc[0] == oacc[0] and acc_close(acc, oacc)
+    eR, et = orc.rt_error(Tn[:3, :3], Tn[:3, 3], Rn, tn)
+    assert eR <= 1e-7 and et <= 1e-6
+    idx, d2 = engine.nn(T0, 0.10)
+    assert_nn_matches(idx, d2, oidx, od2, gate=0.10)

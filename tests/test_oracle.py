@@ -1,0 +1,137 @@
+"""CPU tests of the oracle: closed-form known answers + the committed golden vectors.
+
+The reference has no tests or goldens for this path, so the oracle is
+pinned by analytic answers: align(A, T.A) = T, align(A, A) = I, permutation invariance,
+Kabsch on exact correspondences.
+"""
+import numpy as np
+import pytest
+
+from mapalign import synthetic as syn
+from oracle import icp_oracle as orc
+
+from conftest import R_TOL_FRO, T_TOL_M
+
+
+def test_known_transform_recovered_config1():
+    # BASELINE.json configs[0]: two synthetic 10k-point clouds with a known rigid transform
+    gold, comp, R0, t0 = syn.make_pair(0, 10_000, resample=False)
+    res = orc.icp_oracle(gold, comp, max_iter=50, max_corr_dist=0.10, n_jobs=1)
+    eR, et = orc.rt_error(res["R"], res["t"], R0, t0)
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    assert res["inliers"] == 10_000 and res["rmse"] < 1e-5
+
+
+def test_identity_on_identical_clouds():
+    gold, _, _, _ = syn.make_pair(1, 3000, resample=False)
+    res = orc.icp_oracle(gold, gold, max_iter=5, n_jobs=1)
+    assert np.allclose(res["R"], np.eye(3), atol=1e-12) and np.allclose(res["t"], 0, atol=1e-12)
+    assert res["rmse"] < 1e-9
+
+
+def test_permutation_invariance():
+    gold, comp, _, _ = syn.make_pair(2, 4000, resample=False)
+    a = orc.icp_oracle(gold, comp, max_iter=10, max_corr_dist=0.3, n_jobs=1)
+    perm = np.random.default_rng(0).permutation(len(comp))
+    b = orc.icp_oracle(gold, comp[perm], max_iter=10, max_corr_dist=0.3, n_jobs=1)
+    assert np.allclose(a["R"], b["R"], atol=1e-10) and np.allclose(a["t"], b["t"], atol=1e-10)
+
+
+def test_kabsch_exact_correspondences_and_reflection_guard():
+    rng = np.random.default_rng(3)
+    p = rng.normal(size=(500, 3))
+    R0 = syn.rotation_about_axis([1, 2, 3], 0.7)
+    t0 = np.array([0.3, -2.0, 1.1])
+    q = p @ R0.T + t0
+    acc = orc.accumulate(p, q, np.ones(len(p)), np.zeros(len(p)))
+    dR, dt, ok = orc.kabsch_from_acc(acc)
+    assert ok and np.allclose(dR, R0, atol=1e-12) and np.allclose(dt, t0, atol=1e-12)
+    # planar correspondences: the naive SVD solution may be a reflection; the guard must give det +1
+    p[:, 2] = 0.0
+    q = p @ R0.T + t0
+    dR, dt, ok = orc.kabsch_from_acc(orc.accumulate(p, q, np.ones(len(p)), np.zeros(len(p))))
+    assert ok and np.isclose(np.linalg.det(dR), 1.0) and np.allclose(dR, R0, atol=1e-10)
+
+
+def test_kabsch_degenerate_inputs():
+    acc = np.zeros(17)
+    assert orc.kabsch_from_acc(acc)[2] is False          # W = 0
+    p = np.array([[0.0, 0, 0], [1.0, 0, 0], [2.0, 0, 0], [3.0, 0, 0]])   # collinear -> rank 1
+    assert orc.kabsch_from_acc(orc.accumulate(p, p, np.ones(4), np.zeros(4)))[2] is False
+
+
+def test_kdtree_matches_bruteforce():
+    gold, comp, _, _ = syn.make_pair(4, 2000, 1500)
+    idx, d2 = orc.GoldIndex(gold, n_jobs=1).query(comp)
+    bi, bd2 = orc.nn_bruteforce(gold, comp)
+    assert np.array_equal(idx, bi) and np.allclose(d2, bd2, rtol=1e-12, atol=1e-15)
+
+
+def test_gate_excludes_far_points_and_weights_scale():
+    gold, comp, _, _ = syn.make_pair(5, 2000, resample=False)
+    index = orc.GoldIndex(gold, n_jobs=1)
+    acc, idx, d2, *_ = orc.icp_step(index, comp, np.eye(3), np.zeros(3), max_corr_dist=0.05)
+    assert acc[0] == float((d2 <= 0.05 ** 2).sum())
+    acc2, *_ = orc.icp_step(index, comp, np.eye(3), np.zeros(3), max_corr_dist=0.05, weights=np.full(len(comp), 2.0))
+    assert np.allclose(acc2, 2.0 * acc)
+
+
+def test_tol_stops_early_and_empty_inputs_raise():
+    gold, comp, _, _ = syn.make_pair(6, 3000, resample=False)
+    res = orc.icp_oracle(gold, comp, max_iter=50, tol=1e-9, max_corr_dist=0.3, n_jobs=1)
+    assert res["converged"] and res["iterations"] < 50
+    with pytest.raises(ValueError):
+        orc.icp_oracle(gold, np.zeros((0, 3)))
+    with pytest.raises(ValueError):
+        orc.icp_oracle(np.zeros((0, 3)), comp)
+
+
+def test_far_apart_clouds_are_degenerate_not_wrong():
+    gold, comp, _, _ = syn.make_pair(7, 1000, resample=False)
+    res = orc.icp_oracle(gold, comp + 100.0, max_iter=5, max_corr_dist=0.1, n_jobs=1)
+    assert not res["ok"] and np.allclose(res["R"], np.eye(3))
+
+
+def test_unproject_round_trip():
+    # project known camera-frame points to pixels, unproject with the pinhole model of
+    # pose_processor.py:184-196 / SURVEY §8a-8 and compare
+    K = (80.0, 82.0, 31.5, 23.5)
+    T = syn.pose_to_matrix([1.0, -2.0, 0.5, 0.1, -0.2, 0.3, 0.9])
+    h, w = 48, 64
+    rng = np.random.default_rng(8)
+    depth = rng.uniform(500.0, 8000.0, size=(h, w)).astype(np.float32)
+    depth[0, 0] = 0.0
+    depth[1, 1] = np.nan
+    pts, mask = orc.unproject_oracle(depth, K, T, 1000.0)
+    assert mask.sum() == h * w - 2 and len(pts) == mask.sum()
+    cam = (pts - T[:3, 3]) @ T[:3, :3]        # world -> camera
+    u = cam[:, 0] / cam[:, 2] * K[0] + K[2]
+    v = cam[:, 1] / cam[:, 2] * K[1] + K[3]
+    ys, xs = np.nonzero(mask)
+    assert np.allclose(u, xs, atol=1e-8) and np.allclose(v, ys, atol=1e-8)
+    assert np.allclose(cam[:, 2] * 1000.0, depth[mask], rtol=1e-12)
+
+
+def test_quaternion_pose_convention():
+    # Hamilton (qx,qy,qz,qw), pose row tx ty tz qx qy qz qw (mapper/database_query.py:22)
+    s = np.sin(np.pi / 4)
+    R = syn.quat_to_rot([0, 0, s, s])            # +90 deg about z
+    assert np.allclose(R @ [1, 0, 0], [0, 1, 0], atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["pair_a.npz", "pair_weighted.npz"])
+def test_oracle_reproduces_golden_pairs(golden, name):
+    g = golden(name)
+    w = g.get("weights")
+    res = orc.icp_oracle(g["gold"], g["comp"], max_iter=int(g["iters"]), tol=0.0, max_corr_dist=float(g["gate"]),
+                         weights=w, keep_nn=True, n_jobs=1)
+    assert np.allclose(res["R"], g["R"], atol=1e-12) and np.allclose(res["t"], g["t"], atol=1e-12)
+    acc = np.stack([r["acc"] for r in res["trace"]])
+    assert np.allclose(acc, g["acc"], rtol=1e-12, atol=1e-9)
+    assert np.array_equal(res["trace"][0]["idx"], g["nn0"])
+
+
+def test_oracle_reproduces_golden_depth(golden):
+    g = golden("depth_a.npz")
+    pts, mask = orc.unproject_oracle(g["depth"], g["K"], g["T"], float(g["scale"]))
+    assert np.array_equal(mask, g["mask"]) and np.allclose(pts, g["points"], atol=1e-12)
