@@ -44,7 +44,6 @@ namespace {
 constexpr int kBlock = 256;           // 4 wavefronts
 constexpr int kWave = 64;
 constexpr int kNAcc = 19;             // 17 accumulators + rows visited + candidates
-constexpr int kMaxGrid = 2048;        // 256 CUs x 8 resident workgroups
 constexpr uint64_t kMaxCells = 1ull << 27;
 constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
 
@@ -159,11 +158,14 @@ __global__ __launch_bounds__(kBlock) void k_count_occupied(const uint32_t* __res
   if ((threadIdx.x & (kWave - 1)) == 0 && v > 0) atomicAdd(out, (unsigned long long)v);
 }
 
-// sorted[pos] = centred(xyz[perm[pos]]), .w = original index (gold) or weight (source).
+// sorted[pos] = centred(xyz[perm[pos]]).  w_mode 0: .w = weight (source cloud);
+// 1: .w = pos (level 0 of the gold map: its own position); 2: .w = lut[orig] (coarser
+// levels: the point's position in level 0).
 __global__ __launch_bounds__(kBlock) void k_gather(const float* __restrict__ xyz,
                                                    const float* __restrict__ weights,
                                                    const uint32_t* __restrict__ perm, uint32_t n,
-                                                   double o0, double o1, double o2, int w_is_index,
+                                                   double o0, double o1, double o2, int w_mode,
+                                                   const uint32_t* __restrict__ lut,
                                                    float4* __restrict__ out) {
   const uint32_t pos = blockIdx.x * kBlock + threadIdx.x;
   if (pos >= n) return;
@@ -172,71 +174,234 @@ __global__ __launch_bounds__(kBlock) void k_gather(const float* __restrict__ xyz
   v.x = (float)((double)xyz[3 * (size_t)i] - o0);
   v.y = (float)((double)xyz[3 * (size_t)i + 1] - o1);
   v.z = (float)((double)xyz[3 * (size_t)i + 2] - o2);
-  v.w = w_is_index ? __uint_as_float(i) : (weights ? weights[i] : 1.0f);
+  if (w_mode == 0) v.w = weights ? weights[i] : 1.0f;
+  else if (w_mode == 1) v.w = __uint_as_float(pos);
+  else v.w = __uint_as_float(lut[i]);
   out[pos] = v;
 }
 
+// inv[perm[pos]] = pos
+__global__ __launch_bounds__(kBlock) void k_invert_perm(const uint32_t* __restrict__ perm, uint32_t n,
+                                                        uint32_t* __restrict__ inv) {
+  const uint32_t pos = blockIdx.x * kBlock + threadIdx.x;
+  if (pos < n) inv[perm[pos]] = pos;
+}
+
 // ---------------------------------------------------------------------------------------
-// a4: exact nearest neighbour through the grid
+// a4: exact nearest neighbour through a multi-resolution grid
 // ---------------------------------------------------------------------------------------
-// Rows (y,z) of the grid are visited in square rings of growing Chebyshev radius r around
-// the query's row.  Every point of ring r is at least (r-1)*c away, so the walk stops as
-// soon as that bound reaches the best distance found (or the gate).  Inside a row only the
-// x-run of cells that the current best sphere can reach is scanned; with the x-fastest
-// cell sort that run is ONE contiguous slice of the gold array (two cstart reads).
+// kLevels uniform grids over the same box, cell edges c0, 2 c0, 4 c0, 8 c0, each with its own
+// cell-sorted (x fastest) copy of the gold map.  A query with search radius r is answered at
+// the finest level whose cell edge is >= r: there the sphere cannot leave the 3 x 3 rows
+// around the query's row, nor the 3 cells around its cell inside a row, so the whole search
+// is nine independent row tests, at most nine 16-byte table reads (issued together) and a
+// few short contiguous runs of candidates — a fixed, shallow dependency chain instead of a
+// data-dependent ring walk.  r comes from the previous iteration's match (temporal
+// coherence) or, without one, from a probe of the finest level; if a pass ends with a best
+// distance larger than its level's cell edge, the query moves up to the level that covers
+// it.  Beyond the coarsest level (ungated far-apart clouds) an exact ring walk finishes.
+constexpr int kLevels = 4;
+
+struct LevelSet {
+  const float4* gold[kLevels];     // .w = position of the point in level 0's array
+  const uint32_t* cs[kLevels];     // exclusive prefix of points per cell (+4 words padding)
+  float c[kLevels], inv_c[kLevels];
+  int nx[kLevels], ny[kLevels], nz[kLevels];
+  float ox, oy, oz;                // common min corner (centred frame)
+  float delta;                     // boundary slack (a few ulp of the largest coordinate)
+};
+
+struct LevelView {
+  const float4* gold;
+  const uint32_t* cs;
+  float c, inv_c;
+  int nx, ny, nz;
+};
+
+template <typename T>
+__device__ __forceinline__ T sel4(int l, T a0, T a1, T a2, T a3) {
+  return l == 0 ? a0 : (l == 1 ? a1 : (l == 2 ? a2 : a3));
+}
+
+// per-lane level selection as select chains over kernel arguments (no memory access)
+__device__ __forceinline__ LevelView pick_level(const LevelSet& S, int l) {
+  LevelView V;
+  V.gold = sel4(l, S.gold[0], S.gold[1], S.gold[2], S.gold[3]);
+  V.cs = sel4(l, S.cs[0], S.cs[1], S.cs[2], S.cs[3]);
+  V.c = sel4(l, S.c[0], S.c[1], S.c[2], S.c[3]);
+  V.inv_c = sel4(l, S.inv_c[0], S.inv_c[1], S.inv_c[2], S.inv_c[3]);
+  V.nx = sel4(l, S.nx[0], S.nx[1], S.nx[2], S.nx[3]);
+  V.ny = sel4(l, S.ny[0], S.ny[1], S.ny[2], S.ny[3]);
+  V.nz = sel4(l, S.nz[0], S.nz[1], S.nz[2], S.nz[3]);
+  return V;
+}
+
+struct u4_unaligned { uint32_t x, y, z, w; } __attribute__((packed, aligned(4)));
+
+// Two candidates per trip: the run is contiguous, so both loads are in flight together.
+__device__ __forceinline__ void scan_run(const float px, const float py, const float pz,
+                                         const float4* __restrict__ gold, const uint32_t a,
+                                         const uint32_t b, float& best2, uint32_t& bestj,
+                                         float4& bestq) {
+  for (uint32_t j = a; j < b; j += 2u) {
+    const float4 q0 = gold[j];
+    const float4 q1 = gold[min(j + 1u, b - 1u)];
+    const float dx0 = px - q0.x, dy0 = py - q0.y, dz0 = pz - q0.z;
+    const float dx1 = px - q1.x, dy1 = py - q1.y, dz1 = pz - q1.z;
+    const float d0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
+    const float d1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+    if (d0 < best2) { best2 = d0; bestj = __float_as_uint(q0.w); bestq = q0; }
+    if (d1 < best2) { best2 = d1; bestj = __float_as_uint(q1.w); bestq = q1; }
+  }
+}
+
+// One pass at one level: 3 x 3 rows x (<= 3 cells), pruned by the current best.
+// Exact for every gold point within (c - delta) of the query.
 template <bool COUNT>
-__device__ __forceinline__ void nn_search(const float px, const float py, const float pz,
-                                          const float4* __restrict__ gold,
-                                          const uint32_t* __restrict__ cstart, const GridP& g,
+__device__ __forceinline__ void level_pass(const float px, const float py, const float pz,
+                                           const LevelView& V, const LevelSet& S, float& best2,
+                                           uint32_t& bestj, float4& bestq, uint32_t& nrows,
+                                           uint32_t& ncand) {
+  const float ux = fminf(fmaxf((px - S.ox) * V.inv_c, -1.f), (float)V.nx);
+  const float uy = fminf(fmaxf((py - S.oy) * V.inv_c, -1.f), (float)V.ny);
+  const float uz = fminf(fmaxf((pz - S.oz) * V.inv_c, -1.f), (float)V.nz);
+  const int cx = (int)floorf(ux), cy = (int)floorf(uy), cz = (int)floorf(uz);
+  const int xlo = max(cx - 1, 0), xhi = min(cx + 1, V.nx - 1);
+  // three z-slabs (centre first so that the bound shrinks early); a slab the best sphere
+  // cannot reach costs no memory access at all
+  for (int sl = 0; sl < 3; ++sl) {
+    const int z = cz + (sl == 0 ? 0 : (sl == 1 ? -1 : 1));
+    if ((unsigned)z >= (unsigned)V.nz) continue;
+    const float zlo = S.oz + (float)z * V.c;
+    const float dzq = fmaxf(0.f, fmaxf(zlo - S.delta - pz, pz - (zlo + V.c + S.delta)));
+    if (dzq * dzq >= best2) continue;
+    uint32_t a[3], b[3];
+    // phase 1: the slab's three row tests + table reads, independent => one round trip
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int y = cy + (k == 0 ? 0 : (k == 1 ? -1 : 1));
+      a[k] = 0u;
+      b[k] = 0u;
+      if ((unsigned)y < (unsigned)V.ny) {
+        const float ylo = S.oy + (float)y * V.c;
+        const float dyq = fmaxf(0.f, fmaxf(ylo - S.delta - py, py - (ylo + V.c + S.delta)));
+        const float d2yz = dyq * dyq + dzq * dzq;
+        if (d2yz < best2) {
+          const float rx = sqrtf(best2 - d2yz) + S.delta;  // +inf while ungated and unmatched
+          const float fx0 = fminf(fmaxf(floorf((px - rx - S.ox) * V.inv_c), -1.f), (float)V.nx);
+          const float fx1 = fminf(fmaxf(floorf((px + rx - S.ox) * V.inv_c), -1.f), (float)V.nx);
+          const int x0 = max(xlo, (int)fx0), x1 = min(xhi, (int)fx1);
+          if (x0 <= x1) {
+            const u4_unaligned v =
+                *reinterpret_cast<const u4_unaligned*>(V.cs + ((size_t)(z * V.ny + y) * V.nx + x0));
+            const int span = x1 - x0;  // 0..2 cells beyond the first
+            a[k] = v.x;
+            b[k] = span == 0 ? v.y : (span == 1 ? v.z : v.w);
+            if (COUNT) { nrows += 1u; ncand += b[k] - a[k]; }
+          }
+        }
+      }
+    }
+    // phase 2: candidates
+#pragma unroll
+    for (int k = 0; k < 3; ++k) scan_run(px, py, pz, V.gold, a[k], b[k], best2, bestj, bestq);
+  }
+}
+
+// Exact ring walk on one level, from ring r_start outwards.  Rows (y,z) are visited in
+// square rings of growing Chebyshev radius r around the query's row; every point of ring r
+// is at least (r-1)*c away, so the walk stops as soon as that bound reaches the best
+// distance found.  Inside a row only the x-run the best sphere can reach is scanned — one
+// contiguous slice of the level's array.  Rows are handled four at a time: their tests
+// and table reads are independent, so a batch costs one memory round trip, not four.
+template <bool COUNT>
+__device__ __forceinline__ void ring_walk(const float px, const float py, const float pz,
+                                          const LevelView& V, const LevelSet& S, const int r_start,
                                           float& best2, uint32_t& bestj, float4& bestq,
                                           uint32_t& nrows, uint32_t& ncand) {
-  // best2 / bestj / bestq come in initialised by the caller: (gate, none) or the previous
-  // iteration's match, which is a valid candidate and usually already the answer.
-  if (!(isfinite(px) && isfinite(py) && isfinite(pz))) return;
   // centre row, clamped to one cell outside the grid: for a query outside the grid the
   // ring bound (r-1)*c then under-estimates the true distance, which keeps it valid.
-  const float uy = fminf(fmaxf((py - g.oy) * g.inv_c, -1.f), (float)g.ny);
-  const float uz = fminf(fmaxf((pz - g.oz) * g.inv_c, -1.f), (float)g.nz);
+  const float uy = fminf(fmaxf((py - S.oy) * V.inv_c, -1.f), (float)V.ny);
+  const float uz = fminf(fmaxf((pz - S.oz) * V.inv_c, -1.f), (float)V.nz);
   const int cy = (int)floorf(uy), cz = (int)floorf(uz);
-  const int r0 = max(0, max(max(-cy, cy - (g.ny - 1)), max(-cz, cz - (g.nz - 1))));
-  const int rmax = max(max(cy, g.ny - 1 - cy), max(cz, g.nz - 1 - cz));
+  const int r0 = max(r_start, max(max(-cy, cy - (V.ny - 1)), max(-cz, cz - (V.nz - 1))));
+  const int rmax = max(max(cy, V.ny - 1 - cy), max(cz, V.nz - 1 - cz));
   for (int r = r0; r <= rmax; ++r) {
     if (r >= 2) {
-      const float lb = (float)(r - 1) * g.c - g.delta;
+      const float lb = (float)(r - 1) * V.c - S.delta;
       if (lb * lb >= best2) break;
     }
     const int nside = r ? 4 : 1, len = r ? 2 * r : 1;
     for (int s = 0; s < nside; ++s) {
-      for (int o = 0; o < len; ++o) {
-        int dy, dz;
-        if (s == 0)      { dy = o - r; dz = -r; }
-        else if (s == 1) { dy = r;     dz = o - r; }
-        else if (s == 2) { dy = r - o; dz = r; }
-        else             { dy = -r;    dz = r - o; }
-        const int y = cy + dy, z = cz + dz;
-        if ((unsigned)y >= (unsigned)g.ny || (unsigned)z >= (unsigned)g.nz) continue;
-        const float ylo = g.oy + (float)y * g.c, zlo = g.oz + (float)z * g.c;
-        const float dyq = fmaxf(0.f, fmaxf(ylo - g.delta - py, py - (ylo + g.c + g.delta)));
-        const float dzq = fmaxf(0.f, fmaxf(zlo - g.delta - pz, pz - (zlo + g.c + g.delta)));
-        const float d2yz = dyq * dyq + dzq * dzq;
-        if (d2yz >= best2) continue;
-        const float rx = sqrtf(best2 - d2yz) + g.delta;  // +inf while ungated and unmatched
-        const float fx0 = floorf((px - rx - g.ox) * g.inv_c);
-        const float fx1 = floorf((px + rx - g.ox) * g.inv_c);
-        const int x0 = (int)fmaxf(fx0, 0.f);
-        const int x1 = (int)fminf(fx1, (float)(g.nx - 1));
-        if (x0 > x1) continue;
-        const uint32_t row = (uint32_t)((z * g.ny + y) * g.nx);
-        const uint32_t a = cstart[row + x0], b = cstart[row + x1 + 1];
-        if (COUNT) { nrows += 1u; ncand += b - a; }
-        for (uint32_t j = a; j < b; ++j) {
-          const float4 q = gold[j];
-          const float dx = px - q.x, dyy = py - q.y, dzz = pz - q.z;
-          const float d2 = dx * dx + dyy * dyy + dzz * dzz;
-          if (d2 < best2) { best2 = d2; bestj = j; bestq = q; }
+      for (int o4 = 0; o4 < len; o4 += 4) {
+        uint32_t a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] = 0u;
+          b[u] = 0u;
+          const int o = o4 + u;
+          if (o < len) {
+            int dy, dz;
+            if (s == 0)      { dy = o - r; dz = -r; }
+            else if (s == 1) { dy = r;     dz = o - r; }
+            else if (s == 2) { dy = r - o; dz = r; }
+            else             { dy = -r;    dz = r - o; }
+            const int y = cy + dy, z = cz + dz;
+            if ((unsigned)y < (unsigned)V.ny && (unsigned)z < (unsigned)V.nz) {
+              const float ylo = S.oy + (float)y * V.c, zlo = S.oz + (float)z * V.c;
+              const float dyq = fmaxf(0.f, fmaxf(ylo - S.delta - py, py - (ylo + V.c + S.delta)));
+              const float dzq = fmaxf(0.f, fmaxf(zlo - S.delta - pz, pz - (zlo + V.c + S.delta)));
+              const float d2yz = dyq * dyq + dzq * dzq;
+              if (d2yz < best2) {
+                const float rx = sqrtf(best2 - d2yz) + S.delta;
+                const int x0 = (int)fmaxf(floorf((px - rx - S.ox) * V.inv_c), 0.f);
+                const int x1 = (int)fminf(floorf((px + rx - S.ox) * V.inv_c), (float)(V.nx - 1));
+                if (x0 <= x1) {
+                  const size_t row = (size_t)(z * V.ny + y) * V.nx;
+                  a[u] = V.cs[row + x0];
+                  b[u] = V.cs[row + x1 + 1];
+                  if (COUNT) { nrows += 1u; ncand += b[u] - a[u]; }
+                }
+              }
+            }
+          }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) scan_run(px, py, pz, V.gold, a[u], b[u], best2, bestj, bestq);
       }
     }
+  }
+}
+
+// Driver: best2 / bestj / bestq come in initialised by the caller — (gate, none) or the
+// previous iteration's match, which is a valid candidate and usually already the answer.
+template <bool COUNT>
+__device__ __forceinline__ void nn_find(const float px, const float py, const float pz,
+                                        const LevelSet& S, float& best2, uint32_t& bestj,
+                                        float4& bestq, uint32_t& nrows, uint32_t& ncand) {
+  if (!(isfinite(px) && isfinite(py) && isfinite(pz))) return;
+  // 1. Probe the 3 x 3 rows of the finest level: the true neighbour of a point on a
+  //    scanned surface is almost always there, and the pass is then already exact.
+  // 2. If the best sphere is still larger than the cell but only a few cells wide (the
+  //    usual case for a gated search), walk the outer rings of the SAME level: fine cells
+  //    keep the number of candidates at what the sphere really contains.
+  // 3. Only a sphere many cells wide (ungated, far-apart clouds) climbs to a coarser level,
+  //    where the same two steps cover eight times the volume per table read.
+  constexpr float kWalkCells = 6.f;
+  int l = 0;
+  for (;;) {
+    const LevelView V = pick_level(S, l);
+    level_pass<COUNT>(px, py, pz, V, S, best2, bestj, bestq, nrows, ncand);
+    const float lim = V.c - S.delta;
+    if (best2 <= lim * lim) return;  // the pass covered the whole best sphere: exact
+    const float wide = kWalkCells * V.c;
+    if (l == kLevels - 1 || best2 <= wide * wide) {
+      // from ring 0 again: the pass looked at no more than 3 cells of each of its rows,
+      // the walk scans whatever x-run the (now much smaller) best sphere still reaches
+      ring_walk<COUNT>(px, py, pz, V, S, 0, best2, bestj, bestq, nrows, ncand);
+      return;
+    }
+    l = l + 1;
   }
 }
 
@@ -248,68 +413,63 @@ __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t G) {
 }
 
 // a4 + a5 fused.  MODE 0: accumulate only; MODE 1: also write per-point (idx, d2).
+// One source point per thread: the 17 fp64 accumulator terms are formed only after the
+// search, so they do not occupy registers while the search needs them for latency hiding.
 template <bool COUNT, int MODE>
 __global__ __launch_bounds__(kBlock) void k_nn_accum(
-    const float4* __restrict__ src, const uint32_t n, const uint32_t chunk,
-    const float4* __restrict__ gold, const uint32_t* __restrict__ cstart, const GridP g,
-    const DevState* __restrict__ st, const float best2_init, double* __restrict__ partials,
-    uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx, float* __restrict__ nn_d2) {
+    const float4* __restrict__ src, const uint32_t n, const LevelSet S,
+    const uint32_t* __restrict__ perm0, const DevState* __restrict__ st, const float best2_init,
+    double* __restrict__ partials, uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx,
+    float* __restrict__ nn_d2) {
   if (MODE == 0 && st->done) return;
   const uint32_t G = gridDim.x;
-  const uint32_t cb = xcd_chunk(blockIdx.x, G);
-  const uint32_t begin = min(cb * chunk, n), end = min(begin + chunk, n);
-  double R[9], t[3];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) R[i] = st->R[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) t[i] = st->t[i];
+  const uint32_t i = xcd_chunk(blockIdx.x, G) * kBlock + threadIdx.x;
 
   double acc[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
-  uint32_t nrows = 0, ncand = 0;
 
-  for (uint32_t i = begin + threadIdx.x; i < end; i += kBlock) {
+  if (i < n) {
     const float4 s = src[i];
-    const double Px = R[0] * s.x + R[1] * s.y + R[2] * s.z + t[0];
-    const double Py = R[3] * s.x + R[4] * s.y + R[5] * s.z + t[1];
-    const double Pz = R[6] * s.x + R[7] * s.y + R[8] * s.z + t[2];
+    const double Px = st->R[0] * s.x + st->R[1] * s.y + st->R[2] * s.z + st->t[0];
+    const double Py = st->R[3] * s.x + st->R[4] * s.y + st->R[5] * s.z + st->t[1];
+    const double Pz = st->R[6] * s.x + st->R[7] * s.y + st->R[8] * s.z + st->t[2];
     const float px = (float)Px, py = (float)Py, pz = (float)Pz;
     float best2 = best2_init;
-    uint32_t bestj = kNoMatch;
+    uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (prev) {
       // temporal coherence: last iteration's match bounds the search radius from the start
       const uint32_t pj = prev[i];
       if (pj != kNoMatch) {
-        const float4 c = gold[pj];
+        const float4 c = S.gold[0][pj];
         const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         if (COUNT) ncand += 1u;
         if (d2 < best2) { best2 = d2; bestj = pj; q = c; }
       }
     }
-    nn_search<COUNT>(px, py, pz, gold, cstart, g, best2, bestj, q, nrows, ncand);
+    nn_find<COUNT>(px, py, pz, S, best2, bestj, q, nrows, ncand);
     if (prev) prev[i] = bestj;
+    if (MODE == 1) {
+      nn_idx[i] = bestj != kNoMatch ? perm0[bestj] : kNoMatch;
+      nn_d2[i] = bestj != kNoMatch ? best2 : INFINITY;
+    }
     if (bestj != kNoMatch) {
-      if (MODE == 1) { nn_idx[i] = __float_as_uint(q.w); nn_d2[i] = best2; }
       const double w = (double)s.w;
       const double qx = q.x, qy = q.y, qz = q.z;
       const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
       const double wPx = w * Px, wPy = w * Py, wPz = w * Pz;
-      acc[0] += w;
-      acc[1] += wPx; acc[2] += wPy; acc[3] += wPz;
-      acc[4] += w * qx; acc[5] += w * qy; acc[6] += w * qz;
-      acc[7] += wPx * qx;  acc[8] += wPx * qy;  acc[9] += wPx * qz;
-      acc[10] += wPy * qx; acc[11] += wPy * qy; acc[12] += wPy * qz;
-      acc[13] += wPz * qx; acc[14] += wPz * qy; acc[15] += wPz * qz;
-      acc[16] += w * (dx * dx + dy * dy + dz * dz);
-    } else if (MODE == 1) {
-      nn_idx[i] = kNoMatch;
-      nn_d2[i] = INFINITY;
+      acc[0] = w;
+      acc[1] = wPx; acc[2] = wPy; acc[3] = wPz;
+      acc[4] = w * qx; acc[5] = w * qy; acc[6] = w * qz;
+      acc[7] = wPx * qx;  acc[8] = wPx * qy;  acc[9] = wPx * qz;
+      acc[10] = wPy * qx; acc[11] = wPy * qy; acc[12] = wPy * qz;
+      acc[13] = wPz * qx; acc[14] = wPz * qy; acc[15] = wPz * qz;
+      acc[16] = w * (dx * dx + dy * dy + dz * dz);
     }
+    if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
   }
-  if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
 
   // wavefront shuffle reduction, then a fixed-order sum over the 4 wavefronts
   __shared__ double red[kBlock / kWave][kNAcc];
@@ -334,7 +494,6 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
 // one memory round trip, not 19; the serial tail is one lane of fp64 Jacobi sweeps.
 constexpr int kSolveBlock = 1024;
 constexpr int kSolveWaves = kSolveBlock / kWave;
-static_assert(kMaxGrid <= 2 * kSolveBlock, "k_reduce_solve reads at most two partials per thread");
 
 __global__ __launch_bounds__(kSolveBlock) void k_reduce_solve(
     const double* __restrict__ partials, const int G, const double* __restrict__ acc_in,
@@ -348,17 +507,19 @@ __global__ __launch_bounds__(kSolveBlock) void k_reduce_solve(
   if (threadIdx.x == 0 && do_solve) s0 = *st;
   if (do_reduce) {
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    const int b0 = threadIdx.x, b1 = threadIdx.x + kSolveBlock;
-    double v0[kNAcc], v1[kNAcc];
+    double v[kNAcc];
 #pragma unroll
-    for (int k = 0; k < kNAcc; ++k) {
-      v0[k] = b0 < G ? partials[(size_t)k * G + b0] : 0.0;
-      v1[k] = b1 < G ? partials[(size_t)k * G + b1] : 0.0;
+    for (int k = 0; k < kNAcc; ++k) v[k] = 0.0;
+    // fixed assignment partial -> thread and fixed order within a thread: deterministic.
+    // All 19 loads of one trip are independent (one memory round trip per trip).
+    for (int b = threadIdx.x; b < G; b += kSolveBlock) {
+#pragma unroll
+      for (int k = 0; k < kNAcc; ++k) v[k] += partials[(size_t)k * G + b];
     }
 #pragma unroll
     for (int k = 0; k < kNAcc; ++k) {
-      const double v = wave_sum(v0[k] + v1[k]);
-      if (lane == 0) red[wv][k] = v;
+      const double r = wave_sum(v[k]);
+      if (lane == 0) red[wv][k] = r;
     }
     __syncthreads();
     if (threadIdx.x < kNAcc) {
@@ -548,10 +709,11 @@ struct ma_ctx {
   bool have_gold = false;
   uint32_t m = 0;
   double origin[3] = {0, 0, 0};
-  GridP grid{};
+  GridP grid{};                 // level 0 (finest)
   uint64_t ncells = 0, noccupied = 0;
   double build_ms = 0;
-  DevBuf gold, cstart;
+  DevBuf gold[kLevels], cstart[kLevels], perm0, inv0;
+  LevelSet levels{};
 
   // source cloud
   bool have_src = false;
@@ -721,18 +883,18 @@ int sort_by_cell(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, co
 int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, const double o[3],
                    uint64_t* out) {
   const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
-  HIPCHK(ctx->cstart.ensure((ncells + 1) * 4));
-  HIPCHK(hipMemsetAsync(ctx->cstart.p, 0, (ncells + 1) * 4, ctx->stream));
+  HIPCHK(ctx->cstart[0].ensure((ncells + 8) * 4));
+  HIPCHK(hipMemsetAsync(ctx->cstart[0].p, 0, (ncells + 1) * 4, ctx->stream));
   HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
   HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
   hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0],
                      o[1], o[2], g, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
-                     ctx->cstart.as<uint32_t>());
+                     ctx->cstart[0].as<uint32_t>());
   HIPCHK(hipGetLastError());
   HIPCHK(ctx->misc.ensure(64));
   HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 8, ctx->stream));
   hipLaunchKernelGGL(k_count_occupied, dim3(std::min<uint32_t>(div_up(ncells, kBlock), 4096)), dim3(kBlock), 0,
-                     ctx->stream, ctx->cstart.as<uint32_t>(), (uint32_t)ncells,
+                     ctx->stream, ctx->cstart[0].as<uint32_t>(), (uint32_t)ncells,
                      ctx->misc.as<unsigned long long>());
   HIPCHK(hipGetLastError());
   unsigned long long h = 0;
@@ -742,9 +904,15 @@ int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, 
   return MA_OK;
 }
 
+// one source point per thread; G a multiple of 8 so that the XCD remap is a bijection
+uint32_t grid_for(uint32_t n) {
+  const uint32_t G = div_up(n, kBlock);
+  return std::max<uint32_t>(8, (G + 7u) / 8u * 8u);
+}
+
 int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
   HIPCHK(ctx->state.ensure(sizeof(DevState)));
-  HIPCHK(ctx->partials.ensure((size_t)kNAcc * kMaxGrid * sizeof(double)));
+  HIPCHK(ctx->partials.ensure((size_t)kNAcc * grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(double)));
   HIPCHK(ctx->acc19.ensure(kNAcc * sizeof(double)));
   if (trace_rows > ctx->trace_cap) {
     HIPCHK(ctx->trace.ensure((size_t)trace_rows * MA_TRACE_STRIDE * sizeof(double)));
@@ -769,24 +937,16 @@ int upload_state(ma_ctx* ctx, const double* T) {
   return MA_OK;
 }
 
-struct LaunchGeom { uint32_t G, chunk; };
 
-LaunchGeom geom_for(uint32_t n) {
-  uint32_t G = std::min<uint32_t>(div_up(n, kBlock), kMaxGrid);
-  G = std::max<uint32_t>(8, (G + 7u) / 8u * 8u);
-  uint32_t chunk = div_up(n, G);
-  chunk = (chunk + kBlock - 1) / kBlock * kBlock;
-  return {G, chunk};
-}
 
 template <int MODE>
 int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2) {
-  const LaunchGeom lg = geom_for(ctx->n);
-  ctx->last_G = (int)lg.G;
+  const uint32_t G = grid_for(ctx->n);
+  ctx->last_G = (int)G;
   auto args = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(lg.G), dim3(kBlock), 0, ctx->stream, ctx->src.as<float4>(), ctx->n, lg.chunk,
-                       ctx->gold.as<float4>(), ctx->cstart.as<uint32_t>(), ctx->grid,
-                       ctx->state.as<DevState>(), best2_init, ctx->partials.as<double>(),
+    hipLaunchKernelGGL(kern, dim3(G), dim3(kBlock), 0, ctx->stream, ctx->src.as<float4>(), ctx->n,
+                       ctx->levels, ctx->perm0.as<uint32_t>(), ctx->state.as<DevState>(), best2_init,
+                       ctx->partials.as<double>(),
                        MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, nn_idx, nn_d2);
   };
   if (count) args(k_nn_accum<true, MODE>);
@@ -881,7 +1041,8 @@ int ma_destroy(ma_ctx* ctx) {
   if (!ctx) return MA_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (DevBuf* b : {&ctx->gold, &ctx->cstart, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
+  for (int l = 0; l < kLevels; ++l) { ctx->gold[l].release(); ctx->cstart[l].release(); }
+  for (DevBuf* b : {&ctx->perm0, &ctx->inv0, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
                     &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc, &ctx->depth_in,
                     &ctx->state, &ctx->partials, &ctx->trace, &ctx->acc19, &ctx->nn_idx, &ctx->nn_d2,
                     &ctx->nn_tmp, &ctx->prev})
@@ -961,39 +1122,61 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
   c = clamp_cell_to_budget(lo, hi, c, kMaxCells);
   if (!(c > 0.f) || !std::isfinite(c)) return ctx->fail(MA_ERR_INVALID, "could not choose a cell edge");
 
-  const GridP g = make_grid(lo, hi, ctx->origin, c);
-  const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
-  HIPCHK(ctx->cstart.ensure((ncells + 1) * 4));
-  // histogram -> exclusive scan -> cstart
+  // one grid per level: cell edges c, 2c, 4c, 8c over the same box
   DevBuf& hist = ctx->misc;
-  HIPCHK(hist.ensure((ncells + 1) * 4 + 64));
-  uint32_t* d_hist = reinterpret_cast<uint32_t*>(static_cast<char*>(hist.p) + 64);
-  HIPCHK(hipMemsetAsync(hist.p, 0, (ncells + 1) * 4 + 64, ctx->stream));
-  if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, d_hist))) return rc;
-  size_t tmp_bytes = 0;
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_hist, ctx->cstart.as<uint32_t>(),
-                                          (int)(ncells + 1), ctx->stream));
-  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart.as<uint32_t>(),
-                                          (int)(ncells + 1), ctx->stream));
-  hipLaunchKernelGGL(k_count_occupied, dim3(std::min<uint32_t>(div_up(ncells, kBlock), 4096)), dim3(kBlock), 0,
-                     ctx->stream, d_hist, (uint32_t)ncells, static_cast<unsigned long long*>(hist.p));
-  HIPCHK(hipGetLastError());
-  HIPCHK(ctx->gold.ensure((size_t)n * sizeof(float4)));
-  hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->raw.as<float>(),
-                     (const float*)nullptr, ctx->vals_b.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1],
-                     ctx->origin[2], 1, ctx->gold.as<float4>());
-  HIPCHK(hipGetLastError());
-  unsigned long long occ = 0;
-  HIPCHK(hipMemcpyAsync(&occ, hist.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  LevelSet L{};
+  GridP g0{};
+  uint64_t ncells0 = 0;
+  for (int l = 0; l < kLevels; ++l) {
+    const float cl = c * (float)(1 << l);
+    const GridP g = make_grid(lo, hi, ctx->origin, cl);
+    const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
+    if (l == 0) { g0 = g; ncells0 = ncells; }
+    HIPCHK(ctx->cstart[l].ensure((ncells + 8) * 4));   // + padding for the 16-byte table reads
+    HIPCHK(hist.ensure((ncells + 8) * 4 + 64));
+    uint32_t* d_hist = reinterpret_cast<uint32_t*>(static_cast<char*>(hist.p) + 64);
+    HIPCHK(hipMemsetAsync(hist.p, 0, (ncells + 8) * 4 + 64, ctx->stream));
+    // histogram + stable radix sort by cell id -> vals_b = permutation (sorted pos -> original index)
+    if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, d_hist))) return rc;
+    size_t tmp_bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(),
+                                            (int)(ncells + 8), ctx->stream));
+    HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(),
+                                            (int)(ncells + 8), ctx->stream));
+    HIPCHK(ctx->gold[l].ensure((size_t)n * sizeof(float4)));
+    if (l == 0) {
+      hipLaunchKernelGGL(k_count_occupied, dim3(std::min<uint32_t>(div_up(ncells, kBlock), 4096)), dim3(kBlock),
+                         0, ctx->stream, d_hist, (uint32_t)ncells, static_cast<unsigned long long*>(hist.p));
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(&ctx->noccupied, hist.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx->perm0.ensure((size_t)n * 4));
+      HIPCHK(ctx->inv0.ensure((size_t)n * 4));
+      HIPCHK(hipMemcpyAsync(ctx->perm0.p, ctx->vals_b.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_invert_perm, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream,
+                         ctx->perm0.as<uint32_t>(), n, ctx->inv0.as<uint32_t>());
+      HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->raw.as<float>(),
+                       (const float*)nullptr, ctx->vals_b.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1],
+                       ctx->origin[2], l == 0 ? 1 : 2, ctx->inv0.as<uint32_t>(), ctx->gold[l].as<float4>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // hist / sort scratch is reused by the next level
+    L.gold[l] = ctx->gold[l].as<float4>();
+    L.cs[l] = ctx->cstart[l].as<uint32_t>();
+    L.c[l] = g.c; L.inv_c[l] = g.inv_c;
+    L.nx[l] = g.nx; L.ny[l] = g.ny; L.nz[l] = g.nz;
+    L.ox = g.ox; L.oy = g.oy; L.oz = g.oz;
+    if (l == 0) L.delta = g.delta;
+  }
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->build_ms = ms;
-  ctx->grid = g;
-  ctx->ncells = ncells;
-  ctx->noccupied = occ;
+  ctx->grid = g0;
+  ctx->levels = L;
+  ctx->ncells = ncells0;
   ctx->m = n;
   ctx->have_gold = true;
   return MA_OK;
@@ -1041,7 +1224,7 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
   HIPCHK(hipMemcpyAsync(ctx->src_perm.p, ctx->vals_b.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
   hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->raw.as<float>(), d_w,
                      ctx->src_perm.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1], ctx->origin[2], 0,
-                     ctx->src.as<float4>());
+                     (const uint32_t*)nullptr, ctx->src.as<float4>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->n = n;

@@ -38,6 +38,9 @@ def big(n=1_000_000, cell=0.0):
         res = eng.icp(50, 0.0, 0.1)
         print("icp 50 it: gpu_ms %.3f -> %.1f it/s ; rmse %.5f inl %d err-vs-truth %s" % (
             res.gpu_ms, 50 / res.gpu_ms * 1e3, res.rmse, res.inliers, orc.rt_error(res.R, res.t, R0, t0)))
+    res = eng.icp(50, 0.0, 0.1, time_kernels=True)
+    kt = eng.kernel_times()
+    print("kernel times: nn avg us %.1f solve avg us %.1f" % (kt["nn_ms"] / kt["nn_launches"] * 1e3, kt["solve_ms"] / kt["solve_launches"] * 1e3))
     res = eng.icp(50, 0.0, 0.1, count_work=True, with_trace=True)
     print("counted run gpu_ms", res.gpu_ms, "rows/cands per point it0,it10,it49:",
           res.trace[[0, 10, 49], 18:20] / n)
