@@ -35,22 +35,36 @@ MA_HD inline Col3 cross3(const Col3& a, const Col3& b) {
 }
 MA_HD inline void swap_col(Col3& a, Col3& b) { const Col3 t = a; a = b; b = t; }
 
+// 1/sqrt(x): the device has a hardware seed + refinement (a handful of instructions);
+// an IEEE divide and square root cost ~40 fp64 instructions on one lane, and the solve
+// kernel is exactly one lane of dependent fp64 work.
+MA_HD inline double rsqrt_f64(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return rsqrt(x);
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 // One Hestenes rotation: makes columns gp, gq of G orthogonal, applies the same rotation
-// to the columns vp, vq of V.  Returns the relative size of the off-diagonal it removed.
+// to the columns vp, vq of V.  Returns the squared relative size of the off-diagonal it
+// removed.  tan(theta) = 2 gamma sgn(d) / (|d| + sqrt(d^2 + 4 gamma^2)) with d = beta -
+// alpha is the smaller root (|theta| <= pi/4); c = rsqrt(1 + t^2), s = c t keeps
+// c^2 + s^2 = 1 to rounding whatever the accuracy of t, so V stays orthogonal.
 MA_HD inline double jacobi_rotate(Col3& gp, Col3& gq, Col3& vp, Col3& vq) {
   const double alpha = dot3(gp, gp), beta = dot3(gq, gq), gamma = dot3(gp, gq);
-  const double scale = sqrt(alpha * beta);
-  if (fabs(gamma) <= 1e-300 + 1e-16 * scale) return 0.0;  // already orthogonal
-  const double zeta = (beta - alpha) / (2.0 * gamma);
-  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-  const double c = 1.0 / sqrt(1.0 + t * t);
+  const double ab = alpha * beta, g2 = gamma * gamma;
+  if (g2 <= 1e-300 + 1e-32 * ab) return 0.0;  // already orthogonal
+  const double d = beta - alpha;
+  const double t = (d >= 0.0 ? 2.0 : -2.0) * gamma / (fabs(d) + sqrt(d * d + 4.0 * g2));
+  const double c = rsqrt_f64(1.0 + t * t);
   const double s = c * t;
   const Col3 g0 = gp, g1 = gq, w0 = vp, w1 = vq;
   gp = {c * g0.x - s * g1.x, c * g0.y - s * g1.y, c * g0.z - s * g1.z};
   gq = {s * g0.x + c * g1.x, s * g0.y + c * g1.y, s * g0.z + c * g1.z};
   vp = {c * w0.x - s * w1.x, c * w0.y - s * w1.y, c * w0.z - s * w1.z};
   vq = {s * w0.x + c * w1.x, s * w0.y + c * w1.y, s * w0.z + c * w1.z};
-  return fabs(gamma) / scale;
+  return g2 / ab;
 }
 
 // A = U Sig V^T for a 3x3 given by its COLUMNS g0,g1,g2 (overwritten by the columns of
@@ -64,7 +78,7 @@ MA_HD inline void jacobi_svd3_cols(Col3& g0, Col3& g1, Col3& g2, Col3& v0, Col3&
     double off = jacobi_rotate(g0, g1, v0, v1);
     off = fmax(off, jacobi_rotate(g0, g2, v0, v2));
     off = fmax(off, jacobi_rotate(g1, g2, v1, v2));
-    if (off < 1e-15) break;
+    if (off < 1e-30) break;  // squared relative off-diagonal
   }
 }
 

@@ -57,12 +57,13 @@ def parse():
 def algorithmic_bytes(trace, n_src, n_blocks):
     """bytes one k_nn_accum launch must move, from the exact work counters.
 
-    16 B per source point (float4) + 8 B per grid row visited (two cstart words) + 16 B per
-    candidate gold point examined (float4) + 16 B per matched point (re-read of the winner)
-    + 19 fp64 partials per workgroup.  Averaged over the launches of one step."""
-    rows, cands, matched = trace[:, 18], trace[:, 19], trace[:, 0]
-    per_launch = 16.0 * n_src + 8.0 * rows + 16.0 * cands + 16.0 * matched + 19 * 8.0 * n_blocks
-    return float(per_launch.mean()), float(rows.mean() / n_src), float(cands.mean() / n_src)
+    16 B per source point (float4) + 8 B per point for the remembered match (4 B read +
+    4 B write) + 4 B per grid-table word read + 16 B per candidate gold point examined
+    (float4, the remembered match included) + 16 B per matched point (re-read of the
+    winner) + 19 fp64 partials per workgroup.  Averaged over the launches of one step."""
+    words, cands, matched = trace[:, 18], trace[:, 19], trace[:, 0]
+    per_launch = 24.0 * n_src + 4.0 * words + 16.0 * cands + 16.0 * matched + 19 * 8.0 * n_blocks
+    return float(per_launch.mean()), float(words.mean() / n_src), float(cands.mean() / n_src)
 
 
 def cpu_baseline(gold, comp, iters):
@@ -169,7 +170,7 @@ def main():
             res_t = eng.icp(ITERS, 0.0, GATE, time_kernels=True)
             kt = eng.kernel_times()
             res_c = eng.icp(ITERS, 0.0, GATE, count_work=True, with_trace=True)
-            n_blocks = min((len(comp) + 255) // 256, 2048)
+            n_blocks = (len(comp) + 255) // 256
             b_launch, rows_pp, cands_pp = algorithmic_bytes(res_c.trace, len(comp), n_blocks)
             t_launch_s = kt["nn_ms"] / max(kt["nn_launches"], 1) * 1e-3
             achieved = b_launch / t_launch_s / 1e9
@@ -183,9 +184,9 @@ def main():
             roof = {"bound": "hbm", "kernel": "k_nn_accum", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                     "bytes_per_launch": b_launch, "launch_us": t_launch_s * 1e6,
-                    "rows_per_point": rows_pp, "candidates_per_point": cands_pp,
-                    "compulsory_bytes_per_launch": 16.0 * len(comp) + 16.0 * len(gold),
-                    "compulsory_frac": (16.0 * len(comp) + 16.0 * len(gold)) / t_launch_s / 1e9 / HBM_PEAK_GBPS,
+                    "table_words_per_point": rows_pp, "candidates_per_point": cands_pp,
+                    "compulsory_bytes_per_launch": 24.0 * len(comp) + 16.0 * len(gold),
+                    "compulsory_frac": (24.0 * len(comp) + 16.0 * len(gold)) / t_launch_s / 1e9 / HBM_PEAK_GBPS,
                     "solve_kernel_us": kt["solve_ms"] / max(kt["solve_launches"], 1) * 1e3,
                     "timed_loop_it_per_s": ITERS / (res_t.gpu_ms * 1e-3)}
         cpu = None

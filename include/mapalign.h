@@ -32,9 +32,9 @@ extern "C" {
 
 #define MA_VERSION 100 /* 0.1.0 */
 #define MA_ACC_LEN 17  /* W, s_p[3], s_q[3], S[9] row-major (S_ab = sum w p'_a q_b), E */
-#define MA_TRACE_STRIDE 20 /* per-iteration trace row: acc[17], rmse, rows_visited, candidates */
+#define MA_TRACE_STRIDE 20 /* per-iteration trace row: acc[17], rmse, table_words_read, candidates */
 #define MA_NO_MATCH 0xFFFFFFFFu
-#define MA_FLAG_COUNT_WORK 1   /* also count grid rows visited / candidates examined (slower kernel) */
+#define MA_FLAG_COUNT_WORK 1   /* also count 4-byte grid-table words read / candidates examined (slower kernel) */
 #define MA_FLAG_TIME_KERNELS 2 /* bracket every kernel launch of ma_icp with hipEvents (perturbs the loop) */
 
 typedef struct ma_ctx ma_ctx;
@@ -123,7 +123,7 @@ int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n);
 int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16],
            ma_stats* stats);
 /* Per-iteration trace of the last ma_icp / stepping sequence: row k =
- * {acc[17] in WORLD coordinates, rmse_k, rows_visited_k, candidates_k}; the last two are
+ * {acc[17] in WORLD coordinates, rmse_k, table_words_read_k, candidates_k}; the last two are
  * zero unless MA_FLAG_COUNT_WORK.  Returns the number of rows written (<= max_rows) or a
  * negative status. */
 int ma_get_trace(ma_ctx* ctx, double* out, int max_rows);

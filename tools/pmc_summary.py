@@ -1,0 +1,33 @@
+"""Average per-dispatch PMC values per kernel from rocprofv3 --pmc CSV output (all passes under a dir)."""
+import csv, glob, os, sys, collections
+d = sys.argv[1]
+out = sys.argv[2] if len(sys.argv) > 2 else None
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+    rows = list(csv.DictReader(open(f)))
+    # keep dispatch order; k_nn_accum: only the LAST 50 dispatches (the measured icp run)
+    per_disp = collections.OrderedDict()
+    for r in rows:
+        key = (int(r["Dispatch_Id"]), r["Kernel_Name"])
+        per_disp.setdefault(key, {})[r["Counter_Name"]] = per_disp.get(key, {}).get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    by_kernel = collections.defaultdict(list)
+    for (did, k), vals in per_disp.items():
+        by_kernel[k].append(vals)
+    for k, lst in by_kernel.items():
+        short = "k_nn_accum" if "k_nn_accum" in k else ("k_reduce_solve" if "k_reduce_solve" in k else None)
+        if not short:
+            continue
+        lst = lst[-50:]
+        for vals in lst:
+            for c, v in vals.items():
+                agg[short][c].append(v)
+lines = []
+for k in agg:
+    lines.append(f"== {k} (avg per dispatch over the last {max(len(v) for v in agg[k].values())} dispatches)")
+    for c in sorted(agg[k]):
+        v = agg[k][c]
+        lines.append(f"  {c:45s} {sum(v)/len(v):18.1f}   (min {min(v):.0f} max {max(v):.0f})")
+txt = "\n".join(lines)
+print(txt)
+if out:
+    open(out, "w").write(txt + "\n")
