@@ -5,5 +5,6 @@
 from ._lib import MapAlignError, MapAlignLibraryError  # noqa: F401
 from .api import align  # noqa: F401
 from .engine import AlignResult, MapAligner  # noqa: F401
+from .alignment import Alignment  # noqa: F401
 
-__all__ = ["align", "MapAligner", "AlignResult", "MapAlignError", "MapAlignLibraryError"]
+__all__ = ["align", "Alignment", "MapAligner", "AlignResult", "MapAlignError", "MapAlignLibraryError"]

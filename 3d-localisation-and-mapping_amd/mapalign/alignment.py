@@ -1,0 +1,93 @@
+"""``Alignment(...).compare(data_folder)`` — the reference's call surface for the path.
+
+Mirrors the call site ``/root/reference/task_def.py:175-187``::
+
+    map_alignment = Alignment(base_pose_df=..., comparison_pose_df=..., base_bboxes=...,
+                              comparison_bboxes=..., visualise=cfg.alignment_vis)
+    aligned_maintenance_bboxes, _, goldstd_mesh, _ = map_alignment.compare(data_folder)
+
+and leaves behind what the reference's offline visualiser reads from the scan's pickle
+(``src/map_alignment/visualise.py:233-238``): ``transformations`` (list of ``(R, centre)``
+tuples and 4x4 matrices, applied in order), ``base_map_filepath``,
+``comparison_map_filepath``.  The body of the reference class is absent from the snapshot;
+this adaptor runs coarse pre-alignment + ICP on the MI355X engine.
+
+The second and fourth elements of the reference's 4-tuple are unused by its caller and
+unknown; here they carry the composed 4x4 and an info dict.  ``goldstd_mesh`` is the gold
+map's points (the reference returns an Open3D mesh for its viewer, which is out of scope).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import pickle
+
+import numpy as np
+
+from . import boxes, coarse, ply, transforms
+from .engine import MapAligner
+
+DATA_ROOT = os.path.join("src", "common", "data")     # visualise.py:241
+GOLD_FOLDER = "gold_std"                               # visualise.py:224-225
+
+
+def default_map_resolver(data_folder):
+    """(gold .ply, comparison .ply): first ``*.ply`` under src/common/data/<folder>/."""
+    def first(folder):
+        hits = sorted(glob.glob(os.path.join(DATA_ROOT, folder, "**", "*.ply"), recursive=True))
+        if not hits:
+            raise FileNotFoundError(f"no .ply under {os.path.join(DATA_ROOT, folder)}")
+        return hits[0]
+    return first(GOLD_FOLDER), first(data_folder)
+
+
+class Alignment:
+    def __init__(self, base_pose_df=None, comparison_pose_df=None, base_bboxes=None, comparison_bboxes=None,
+                 visualise=False, *, base_map_filepath=None, comparison_map_filepath=None,
+                 map_resolver=default_map_resolver, pickle_path=None, device=0, max_iter=50, tol=0.0,
+                 max_corr_dist=0.10, coarse_stage=True):
+        self.base_pose_df = base_pose_df
+        self.comparison_pose_df = comparison_pose_df
+        self.base_bboxes = base_bboxes or {}
+        self.comparison_bboxes = comparison_bboxes or {}
+        self.visualise = visualise      # rendering is out of scope; kept for signature parity
+        self.base_map_filepath = base_map_filepath
+        self.comparison_map_filepath = comparison_map_filepath
+        self.map_resolver = map_resolver
+        self.pickle_path = pickle_path
+        self.device = device
+        self.max_iter, self.tol, self.max_corr_dist = max_iter, tol, max_corr_dist
+        self.coarse_stage = coarse_stage
+        self.transformations = []
+
+    def align_clouds(self, gold_cloud, comparison_cloud):
+        """Staged alignment of two point arrays -> (transformations list, composed 4x4, info)."""
+        with MapAligner(self.device) as eng:
+            eng.set_gold(gold_cloud)
+            stages, T0, info = [], np.eye(4), {}
+            if self.coarse_stage:
+                stages, T0, info = coarse.coarse_align(eng, gold_cloud, comparison_cloud)
+            eng.set_source(comparison_cloud)
+            res = eng.icp(self.max_iter, self.tol, self.max_corr_dist, init=T0)
+        T_icp = res.T @ np.linalg.inv(T0)          # refinement applied AFTER the coarse stages
+        stages = list(stages) + [T_icp]
+        info.update(iterations=res.iterations, rmse=res.rmse, inliers=res.inliers, gpu_ms=res.gpu_ms)
+        return stages, res.T, info
+
+    def compare(self, data_folder):
+        if self.base_map_filepath is None or self.comparison_map_filepath is None:
+            self.base_map_filepath, self.comparison_map_filepath = self.map_resolver(data_folder)
+        gold = ply.read_ply(self.base_map_filepath)                 # NaN / inf removed, as mapping.py:63-68
+        comp = ply.read_ply(self.comparison_map_filepath)
+        self.transformations, T, info = self.align_clouds(gold, comp)
+        aligned = boxes.transform_bboxes(self.comparison_bboxes, T)
+        if self.pickle_path:
+            state = {}
+            if os.path.exists(self.pickle_path):
+                with open(self.pickle_path, "rb") as f:
+                    state = pickle.load(f)
+            state.update(transformations=self.transformations, base_map_filepath=self.base_map_filepath,
+                         comparison_map_filepath=self.comparison_map_filepath)
+            with open(self.pickle_path, "wb") as f:
+                pickle.dump(state, f)
+        return aligned, T, gold, info

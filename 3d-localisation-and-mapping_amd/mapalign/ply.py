@@ -1,0 +1,128 @@
+"""Point-cloud ingest without Open3D.
+
+The reference loads maps with ``o3d.io.read_point_cloud(path, remove_nan_points=True,
+remove_infinite_points=True)`` (``src/mapper/mapping.py:63-68``,
+``src/map_alignment/visualise.py:21-22``); RTAB-Map exports binary little-endian PLY.
+This reader handles ascii, binary_little_endian and binary_big_endian vertex elements with
+arbitrary scalar properties (list properties only in non-vertex elements, which are
+skipped), and applies the same two filters.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2",
+          "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4",
+          "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+class PlyError(ValueError):
+    pass
+
+
+def _parse_header(f):
+    if f.readline().strip() != b"ply":
+        raise PlyError("not a PLY file")
+    fmt = None
+    elements = []          # [name, count, [(prop, dtype)|('list', ...)]]
+    while True:
+        line = f.readline()
+        if not line:
+            raise PlyError("unterminated PLY header")
+        tok = line.decode("ascii", "replace").split()
+        if not tok or tok[0] in ("comment", "obj_info"):
+            continue
+        if tok[0] == "format":
+            fmt = tok[1]
+        elif tok[0] == "element":
+            elements.append([tok[1], int(tok[2]), []])
+        elif tok[0] == "property":
+            if not elements:
+                raise PlyError("property before element")
+            if tok[1] == "list":
+                elements[-1][2].append(("list", tok[2], tok[3], tok[4]))
+            else:
+                if tok[1] not in _TYPES:
+                    raise PlyError(f"unknown property type {tok[1]}")
+                elements[-1][2].append((tok[2], _TYPES[tok[1]]))
+        elif tok[0] == "end_header":
+            break
+    if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+        raise PlyError(f"unsupported PLY format {fmt}")
+    return fmt, elements
+
+
+def read_ply(path, remove_nan_points=True, remove_infinite_points=True, with_colors=False):
+    """-> points float64 [N,3] (and uint8 colors [N,3] or None when ``with_colors``)."""
+    with open(path, "rb") as f:
+        fmt, elements = _parse_header(f)
+        vertex = None
+        for name, count, props in elements:
+            if name == "vertex":
+                if any(p[0] == "list" for p in props):
+                    raise PlyError("list property in vertex element")
+                names = [p[0] for p in props]
+                if not all(a in names for a in ("x", "y", "z")):
+                    raise PlyError("vertex element lacks x/y/z")
+                if fmt == "ascii":
+                    rows = [f.readline().split() for _ in range(count)]
+                    arr = np.array(rows, dtype=np.float64).reshape(count, len(props)) if count else \
+                        np.zeros((0, len(props)))
+                    vertex = {n: arr[:, i] for i, n in enumerate(names)}
+                else:
+                    end = "<" if fmt == "binary_little_endian" else ">"
+                    dt = np.dtype([(n, end + t) for n, t in props])
+                    buf = f.read(dt.itemsize * count)
+                    if len(buf) != dt.itemsize * count:
+                        raise PlyError("truncated vertex data")
+                    rec = np.frombuffer(buf, dtype=dt, count=count)
+                    vertex = {n: rec[n] for n in names}
+                break
+            # skip elements in front of the vertex element
+            if fmt == "ascii":
+                for _ in range(count):
+                    f.readline()
+            else:
+                if any(p[0] == "list" for p in props):
+                    raise PlyError("cannot skip a binary list element placed before the vertices")
+                f.seek(sum(np.dtype(t).itemsize for _, t in props) * count, 1)
+        if vertex is None:
+            raise PlyError("no vertex element")
+    pts = np.stack([vertex["x"], vertex["y"], vertex["z"]], axis=1).astype(np.float64)
+    keep = np.ones(len(pts), dtype=bool)
+    if remove_nan_points:
+        keep &= ~np.isnan(pts).any(axis=1)
+    if remove_infinite_points:
+        keep &= ~np.isinf(pts).any(axis=1)
+    pts = pts[keep]
+    if not with_colors:
+        return pts
+    cols = None
+    if all(c in vertex for c in ("red", "green", "blue")):
+        cols = np.stack([vertex["red"], vertex["green"], vertex["blue"]], axis=1)[keep].astype(np.uint8)
+    return pts, cols
+
+
+def write_ply(path, points, colors=None, binary=True):
+    """Minimal writer (tests and examples): float32 xyz (+ uchar rgb)."""
+    pts = np.asarray(points, dtype=np.float32).reshape(-1, 3)
+    props = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")]
+    if colors is not None:
+        props += [("red", "u1"), ("green", "u1"), ("blue", "u1")]
+    rec = np.zeros(len(pts), dtype=np.dtype(props))
+    rec["x"], rec["y"], rec["z"] = pts[:, 0], pts[:, 1], pts[:, 2]
+    if colors is not None:
+        c = np.asarray(colors, dtype=np.uint8).reshape(-1, 3)
+        rec["red"], rec["green"], rec["blue"] = c[:, 0], c[:, 1], c[:, 2]
+    head = ["ply", "format binary_little_endian 1.0" if binary else "format ascii 1.0",
+            f"element vertex {len(pts)}", "property float x", "property float y", "property float z"]
+    if colors is not None:
+        head += ["property uchar red", "property uchar green", "property uchar blue"]
+    head.append("end_header")
+    with open(path, "wb") as f:
+        f.write(("\n".join(head) + "\n").encode("ascii"))
+        if binary:
+            f.write(rec.tobytes())
+        else:
+            for r in rec:
+                f.write((" ".join(repr(float(v)) if isinstance(v, np.floating) else str(int(v)) for v in r) + "\n").encode())

@@ -441,3 +441,47 @@ def test_full_size_1m_resampled_pair_one_step_vs_oracle(engine):
     assert eR <= 1e-7 and et <= 1e-6
     idx, d2 = engine.nn(T0, 0.10)
     assert_nn_matches(idx, d2, oidx, od2, gate=0.10)
+
+
+# ----------------------------------------------------------------------------- adaptor (a1-a3, N1-N3)
+def test_alignment_adaptor_far_start_with_ply_and_pickle(tmp_path):
+    """Reference call shape (task_def.py:175-187) end to end: .ply maps on disk, a maintenance
+    scan that starts 150 degrees / several metres away (the README GIF's situation), boxes
+    moved onto the gold map, the visualiser's three pickle keys written."""
+    import pickle
+
+    from mapalign import Alignment, boxes, ply, transforms
+
+    gold, comp, R0, t0 = syn.make_pair(17, 60_000, 50_000, angle_deg=150.0, t0=np.array([7.0, -4.0, 1.5]))
+    gold_path, comp_path = tmp_path / "gold.ply", tmp_path / "scan.ply"
+    ply.write_ply(gold_path, gold)
+    ply.write_ply(comp_path, comp)
+    T_true = transforms.rt_to_matrix(R0, t0)
+    sign = np.array([3.0, 0.0, 1.2])                         # a sign on the gold map ...
+    d = 0.15
+    gold_boxes = {0: [[sign + [-d, 0, -d], sign + [d, 0, -d], sign + [d, 0, d], sign + [-d, 0, d], 0, 0.9, "exit"]]}
+    inv = np.linalg.inv(T_true)                              # ... as the maintenance scan saw it
+    comp_boxes = {4: [[transforms.apply(inv, c[None])[0] for c in gold_boxes[0][0][:4]] + [1, 0.8, "exit"]]}
+    pkl = tmp_path / "scan.pkl"
+    with open(pkl, "wb") as f:
+        pickle.dump({"pose_df": None}, f)
+    al = Alignment(base_pose_df=None, comparison_pose_df=None, base_bboxes=gold_boxes, comparison_bboxes=comp_boxes,
+                   visualise=False, base_map_filepath=str(gold_path), comparison_map_filepath=str(comp_path),
+                   pickle_path=str(pkl))
+    aligned, T, gold_pts, info = al.compare("scan")
+    eR, et = orc.rt_error(T[:3, :3], T[:3, 3], R0, t0)
+    assert eR <= 2e-3 and et <= 2e-2                         # independent resample: sampling noise, not parity
+    ref = orc.icp_oracle(gold, comp, max_iter=50, max_corr_dist=0.10, init=transforms.compose(al.transformations[:2]),
+                         n_jobs=8)
+    eR, et = orc.rt_error(T[:3, :3], T[:3, 3], ref["R"], ref["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M                 # parity with the oracle from the same coarse start
+    # staged list: (R, centre) tuple, 4x4 translation, 4x4 refinement — composes to T
+    tr = al.transformations
+    assert isinstance(tr[0], tuple) and tr[1].shape == (4, 4) and tr[2].shape == (4, 4)
+    assert np.allclose(transforms.compose(tr), T, atol=1e-9) and transforms.is_rigid(T, 1e-8)
+    with open(pkl, "rb") as f:
+        state = pickle.load(f)
+    assert set(state) >= {"transformations", "base_map_filepath", "comparison_map_filepath", "pose_df"}
+    res = boxes.match_bboxes(gold_boxes, aligned, max_dist=0.1)
+    assert res["matches"] and res["matches"][0][2] < 0.03 and res["damaged"] == [0] and not res["missing"]
+    assert len(gold_pts) == len(gold)

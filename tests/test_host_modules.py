@@ -1,0 +1,114 @@
+"""CPU tests of the host-side modules around the path: transform containers
+(visualise.py:82-96 formats), PLY ingest (mapping.py:63-68 flags), box transform +
+matching (task_def.py:182-197), coarse-stage candidate generation."""
+import numpy as np
+import pytest
+
+from mapalign import boxes, coarse, ply, synthetic as syn, transforms
+
+
+def test_rotation_about_centre_matches_open3d_semantics():
+    R = syn.rotation_about_axis([0.1, 0.7, -0.3], 0.9)
+    c = np.array([1.0, -2.0, 0.5])
+    p = np.random.default_rng(0).normal(size=(50, 3))
+    assert np.allclose(transforms.apply((R, c), p), (p - c) @ R.T + c)      # p' = R (p - c) + c
+    T = transforms.rotation_about_centre(R, c)
+    assert transforms.is_rigid(T) and np.allclose(transforms.apply(T, c[None]), c[None])
+
+
+def test_compose_applies_in_list_order():
+    R = syn.rotation_about_axis([0, 0, 1], 0.5)
+    stages = [(R, np.array([1.0, 0, 0])), transforms.rt_to_matrix(np.eye(3), [0, 2.0, 0]),
+              transforms.rt_to_matrix(syn.rotation_about_axis([1, 0, 0], -0.2), [0.1, 0, 0])]
+    p = np.random.default_rng(1).normal(size=(20, 3))
+    q = p
+    for s in stages:
+        q = transforms.apply(s, q)
+    assert np.allclose(transforms.apply(transforms.compose(stages), p), q)
+    with pytest.raises(ValueError):
+        transforms.to_matrix(np.eye(3))
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_ply_round_trip_and_filters(tmp_path, binary):
+    rng = np.random.default_rng(2)
+    pts = rng.normal(size=(200, 3)).astype(np.float32)
+    pts[3, 1] = np.nan
+    pts[7, 0] = np.inf
+    cols = rng.integers(0, 255, size=(200, 3), dtype=np.uint8)
+    path = tmp_path / "cloud.ply"
+    ply.write_ply(path, pts, cols, binary=binary)
+    out, c = ply.read_ply(path, with_colors=True)
+    keep = np.isfinite(pts).all(axis=1)
+    assert out.shape == (198, 3) and out.dtype == np.float64
+    assert np.allclose(out, pts[keep].astype(np.float64), rtol=1e-6) and np.array_equal(c, cols[keep])
+    assert ply.read_ply(path, remove_nan_points=False, remove_infinite_points=False).shape == (200, 3)
+
+
+def test_ply_big_endian_double_and_extra_properties(tmp_path):
+    pts = np.arange(30, dtype=np.float64).reshape(10, 3) / 7.0
+    rec = np.zeros(10, dtype=np.dtype([("nx", ">f4"), ("x", ">f8"), ("y", ">f8"), ("z", ">f8"), ("label", ">u2")]))
+    rec["x"], rec["y"], rec["z"] = pts.T
+    head = ("ply\nformat binary_big_endian 1.0\ncomment made by test\nelement vertex 10\nproperty float nx\n"
+            "property double x\nproperty double y\nproperty double z\nproperty ushort label\n"
+            "element face 0\nproperty list uchar int vertex_indices\nend_header\n")
+    path = tmp_path / "be.ply"
+    path.write_bytes(head.encode() + rec.tobytes())
+    assert np.array_equal(ply.read_ply(path), pts)
+
+
+def test_ply_errors(tmp_path):
+    bad = tmp_path / "bad.ply"
+    bad.write_bytes(b"plx\n")
+    with pytest.raises(ply.PlyError):
+        ply.read_ply(bad)
+    trunc = tmp_path / "trunc.ply"
+    trunc.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 5\nproperty float x\nproperty float y\n"
+                      b"property float z\nend_header\n" + b"\0" * 10)
+    with pytest.raises(ply.PlyError):
+        ply.read_ply(trunc)
+    empty = tmp_path / "empty.ply"
+    ply.write_ply(empty, np.zeros((0, 3)))
+    assert ply.read_ply(empty).shape == (0, 3)
+
+
+def _box(centre, cls=0, conf=0.9, label="exit"):
+    c = np.asarray(centre, dtype=np.float64)
+    d = 0.1
+    return [c + [-d, -d, 0], c + [d, -d, 0], c + [d, d, 0], c + [-d, d, 0], cls, conf, label]
+
+
+def test_transform_and_match_bboxes(tmp_path):
+    gold = {0: [_box([0, 0, 0]), _box([1, 0, 0], label="fire")], 3: [_box([2, 1, 0])]}
+    R = syn.rotation_about_axis([0, 0, 1], 0.3)
+    T = transforms.rt_to_matrix(R, [0.5, -0.2, 0.1])
+    Tinv = np.linalg.inv(T)
+    # maintenance scan: same signs seen in its own frame, one missing, one damaged, one new
+    comp = {5: [_box(transforms.apply(Tinv, [[0, 0, 0]])[0], cls=2), _box(transforms.apply(Tinv, [[2, 1, 0]])[0])],
+            9: [_box(transforms.apply(Tinv, [[5, 5, 0]])[0])]}
+    aligned = boxes.transform_bboxes(comp, T)
+    assert aligned[5][0][4:] == [2, 0.9, "exit"]                      # metadata untouched (pose_processor.py:208)
+    centres, _ = boxes.flatten(aligned)
+    # a rotated square keeps its centre: centres land on the gold ones
+    assert np.allclose(centres[0], [0, 0, 0], atol=1e-9) and np.allclose(centres[1], [2, 1, 0], atol=1e-9)
+    out = tmp_path / "report.csv"
+    res = boxes.match_bboxes(gold, aligned, max_dist=0.3, csv_output_file=out)
+    assert sorted((g, a) for g, a, _ in res["matches"]) == [(0, 0), (2, 1)]
+    assert res["missing"] == [1] and res["unexpected"] == [2] and res["damaged"] == [0]
+    rows = out.read_text().strip().splitlines()
+    assert rows[0].startswith("gold_index") and len(rows) == 4 and ",missing," in rows[3]
+    assert boxes.match_bboxes({}, aligned)["matches"] == [] and boxes.match_bboxes(gold, {})["missing"] == [0, 1, 2]
+    # list-of-stages form is accepted too
+    staged = boxes.transform_bboxes(comp, [(R, np.zeros(3)), transforms.rt_to_matrix(np.eye(3), [0.5, -0.2, 0.1])])
+    assert np.allclose(staged[9][0][0], aligned[9][0][0])
+
+
+def test_coarse_candidates_contain_the_true_rotation():
+    gold, comp, _, _ = syn.make_pair(40, 5000, resample=False, angle_deg=140.0, t0=np.array([6.0, -3.0, 1.0]))
+    cg, ag, vg = coarse.principal_frame(gold)
+    cc, ac, vc = coarse.principal_frame(comp)
+    assert np.allclose(vg, vc, rtol=1e-3)                    # rigid motion preserves the spectrum
+    R_true = syn.rotation_about_axis(syn.GT_AXIS, np.deg2rad(140.0))
+    cands = coarse.candidate_rotations(ag, ac)
+    assert all(abs(np.linalg.det(R) - 1) < 1e-9 for R in cands)
+    assert min(np.linalg.norm(R - R_true) for R in cands) < 1e-3
