@@ -148,8 +148,11 @@ __global__ __launch_bounds__(kBlock) void k_minmax(const float* __restrict__ xyz
 
 // key = cell id, val = original index; also the per-cell histogram (integer atomics:
 // the counts are order-independent, hence deterministic).
+// brick != 0: the key is brick-major — 8 x 8 x 8-cell bricks in x-fastest order, cells
+// x-fastest inside a brick — so that 256 consecutive points of the sorted SOURCE cloud form
+// a compact patch (small LDS tile) instead of a 2 m long line of cells.
 __global__ __launch_bounds__(kBlock) void k_cell_keys(const float* __restrict__ xyz, uint32_t n,
-                                                      double o0, double o1, double o2, GridP g,
+                                                      double o0, double o1, double o2, GridP g, int brick,
                                                       uint32_t* __restrict__ keys,
                                                       uint32_t* __restrict__ vals,
                                                       uint32_t* __restrict__ counts) {
@@ -158,7 +161,12 @@ __global__ __launch_bounds__(kBlock) void k_cell_keys(const float* __restrict__ 
   const float x = (float)((double)xyz[3 * (size_t)i] - o0);
   const float y = (float)((double)xyz[3 * (size_t)i + 1] - o1);
   const float z = (float)((double)xyz[3 * (size_t)i + 2] - o2);
-  const uint32_t c = cell_of(x, y, z, g);
+  uint32_t c = cell_of(x, y, z, g);
+  if (brick) {
+    const uint32_t ix = c % (uint32_t)g.nx, iy = (c / (uint32_t)g.nx) % (uint32_t)g.ny, iz = c / ((uint32_t)g.nx * g.ny);
+    const uint32_t nbx = ((uint32_t)g.nx + 7u) >> 3, nby = ((uint32_t)g.ny + 7u) >> 3;
+    c = ((((iz >> 3) * nby + (iy >> 3)) * nbx + (ix >> 3)) << 9) | ((iz & 7u) << 6) | ((iy & 7u) << 3) | (ix & 7u);
+  }
   keys[i] = c;
   vals[i] = i;
   if (counts) atomicAdd(&counts[c], 1u);
@@ -421,6 +429,251 @@ __device__ __forceinline__ void nn_find(const float px, const float py, const fl
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// LDS-tiled search: the workgroup's 256 (cell-sorted, hence neighbouring) queries share one
+// block of the level-0 grid
+// ---------------------------------------------------------------------------------------
+// Every lane knows an upper bound r of its neighbour distance before the search starts (the
+// remembered match, or the gate).  The union of the lanes' spheres, in cells, is the tile:
+// its table rows and its points are copied ONCE per workgroup with fully coalesced reads
+// (a row segment of the table and the points of a row segment are both contiguous), after
+// which all per-lane random access — the part that saturates the texture addresser when it
+// goes to global memory — is served by LDS.  A tile that would not fit (a workgroup that
+// straddles two rows of the source sort, a first iteration with the full gate as radius on
+// a dense map) falls back to the global-memory search for that workgroup only.
+#ifndef MA_TILE
+#define MA_TILE 1
+#endif
+constexpr int kTileRows = 128;    // (y,z) rows per tile
+constexpr int kTileWords = 3072;  // 16-bit table entries (row-relative point offsets)
+constexpr int kTilePts = 1536;    // staged float4 points
+
+struct TileShared {
+  float4 pts[kTilePts];            // 24 KB: xyz + position in gold[0]
+  uint16_t tab[kTileWords];        // 6 KB : cstart[row + x] - cstart[row + xlo]
+  uint32_t rowbase[kTileRows];     // cstart[row + xlo]
+  uint32_t rowoff[kTileRows + 1];  // offset of the row's points in pts
+  int wave_box[kBlock / kWave][8];
+  int info[8];                     // xlo, ylo, zlo, tw, ty, feasible, nrows, -
+};
+enum { TI_XLO = 0, TI_YLO, TI_ZLO, TI_TW, TI_TY, TI_OK, TI_NROWS };
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_step(int v) {
+  return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false));
+}
+// minimum over the wavefront, valid in lane 63
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = dpp_min_step<0x111, 0xF>(v);
+  v = dpp_min_step<0x112, 0xF>(v);
+  v = dpp_min_step<0x114, 0xF>(v);
+  v = dpp_min_step<0x118, 0xF>(v);
+  v = dpp_min_step<0x142, 0xA>(v);
+  v = dpp_min_step<0x143, 0xC>(v);
+  return v;
+}
+
+// a-th element of the centre-out enumeration c, c-1, c+1, c-2, ... of the range [lo, hi]
+// (once one side is exhausted the other continues); a = 0 .. hi-lo
+__device__ __forceinline__ int centre_out(int a, int c, int lo, int hi) {
+  const int L = c - lo, R = hi - c, m = min(L, R);
+  if (a <= 2 * m) return c + ((a & 1) ? -((a + 1) >> 1) : (a >> 1));
+  return L < R ? c + (a - m) : c - (a - m);
+}
+
+// Returns true if the workgroup was served by the tile (all lanes done, exact); false if
+// the caller must run the global-memory search.  Must be called by all 256 threads.
+template <bool COUNT>
+__device__ __forceinline__ bool tile_search(TileShared& T, const bool has_query, const float px,
+                                            const float py, const float pz, const LevelSet& S,
+                                            float& best2, uint32_t& bestj, uint32_t& nrows,
+                                            uint32_t& ncand) {
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  const float c = S.c[0], inv_c = S.inv_c[0];
+  const int nx = S.nx[0], ny = S.ny[0], nz = S.nz[0];
+  const float4* __restrict__ gold0 = S.gold[0];
+  const uint32_t* __restrict__ cs0 = S.cs[0];
+
+  // ---- the lane's cell range (its sphere, clipped to the grid)
+  bool ranged = false, bad = false;
+  int ix0 = 0, ix1 = -1, iy0 = 0, iy1 = -1, iz0 = 0, iz1 = -1;
+  if (has_query && isfinite(px) && isfinite(py) && isfinite(pz)) {
+    if (!isfinite(best2)) {
+      bad = true;  // no radius known (ungated, nothing remembered): cannot bound a tile
+    } else {
+      const float r = sqrtf(best2) + S.delta;
+      ix0 = max((int)fmaxf(floorf((px - r - S.ox) * inv_c), -1.f), 0);
+      ix1 = min((int)fminf(floorf((px + r - S.ox) * inv_c), (float)nx), nx - 1);
+      iy0 = max((int)fmaxf(floorf((py - r - S.oy) * inv_c), -1.f), 0);
+      iy1 = min((int)fminf(floorf((py + r - S.oy) * inv_c), (float)ny), ny - 1);
+      iz0 = max((int)fmaxf(floorf((pz - r - S.oz) * inv_c), -1.f), 0);
+      iz1 = min((int)fminf(floorf((pz + r - S.oz) * inv_c), (float)nz), nz - 1);
+      ranged = ix0 <= ix1 && iy0 <= iy1 && iz0 <= iz1;  // else: the sphere misses the grid
+    }
+  }
+  const int big = 0x3FFFFFFF;
+  const int m0 = wave_min_i32(ranged ? ix0 : big), m1 = wave_min_i32(ranged ? iy0 : big);
+  const int m2 = wave_min_i32(ranged ? iz0 : big), m3 = wave_min_i32(ranged ? -ix1 : big);
+  const int m4 = wave_min_i32(ranged ? -iy1 : big), m5 = wave_min_i32(ranged ? -iz1 : big);
+  const int m6 = wave_min_i32(bad ? 0 : 1);
+  if (lane == kWave - 1) {
+    T.wave_box[wv][0] = m0; T.wave_box[wv][1] = m1; T.wave_box[wv][2] = m2; T.wave_box[wv][3] = m3;
+    T.wave_box[wv][4] = m4; T.wave_box[wv][5] = m5; T.wave_box[wv][6] = m6;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int b[7];
+    for (int k = 0; k < 7; ++k) {
+      int v = T.wave_box[0][k];
+      for (int w = 1; w < kBlock / kWave; ++w) v = min(v, T.wave_box[w][k]);
+      b[k] = v;
+    }
+    int ok = b[6] != 0;
+    int tw = 0, ty = 0, tz = 0;
+    if (b[0] == big) {
+      ok = ok ? 2 : 0;  // nobody needs anything: trivially served
+    } else {
+      tw = (-b[3]) - b[0] + 2;  // cells + 1 table entries per row
+      ty = (-b[4]) - b[1] + 1;
+      tz = (-b[5]) - b[2] + 1;
+      if (ty * tz > kTileRows || ty * tz * tw > kTileWords || tw > 2 * kWave) ok = 0;
+    }
+    T.info[TI_XLO] = b[0]; T.info[TI_YLO] = b[1]; T.info[TI_ZLO] = b[2];
+    T.info[TI_TW] = tw; T.info[TI_TY] = ty; T.info[TI_NROWS] = ty * tz; T.info[TI_OK] = ok;
+  }
+  __syncthreads();
+  int ok = T.info[TI_OK];
+  if (ok == 0) return false;
+  if (ok == 2) return true;
+  const int xlo = T.info[TI_XLO], ylo = T.info[TI_YLO], zlo = T.info[TI_ZLO];
+  const int tw = T.info[TI_TW], ty = T.info[TI_TY], nrow = T.info[TI_NROWS];
+
+  // ---- stage the table: wavefront w takes rows w, w+4, ...; lane k reads entry k of the row
+  // (coalesced).  Eight rows per trip, all eight loads issued before the first use, so a
+  // trip costs one memory round trip; no integer division anywhere (row -> (y,z) is kept
+  // incrementally).
+  {
+    constexpr int kNW = kBlock / kWave, kRowsPerTrip = 8;
+    int yi = wv % ty, zi = wv / ty;       // wave-uniform: scalar unit
+    for (int r0 = wv; r0 < nrow; r0 += kNW * kRowsPerTrip) {
+      uint32_t word[kRowsPerTrip][2];
+      int yy = yi, zz = zi;
+#pragma unroll
+      for (int u = 0; u < kRowsPerTrip; ++u) {
+        const int r = r0 + u * kNW;
+        word[u][0] = word[u][1] = 0u;
+        if (r < nrow) {
+          const uint32_t base = (uint32_t)(((zlo + zz) * ny + (ylo + yy)) * nx + xlo);
+          if (lane < tw) word[u][0] = ld_cell(cs0, base + (uint32_t)lane);
+          if (lane + kWave < tw) word[u][1] = ld_cell(cs0, base + (uint32_t)(lane + kWave));
+        }
+        yy += kNW;
+        while (yy >= ty) { yy -= ty; ++zz; }
+      }
+#pragma unroll
+      for (int u = 0; u < kRowsPerTrip; ++u) {
+        const int r = r0 + u * kNW;
+        if (r < nrow) {
+          const uint32_t first = __shfl(word[u][0], 0, kWave);
+          if (lane < tw) T.tab[r * tw + lane] = (uint16_t)(word[u][0] - first);
+          if (lane + kWave < tw) T.tab[r * tw + lane + kWave] = (uint16_t)(word[u][1] - first);
+          const int kl = tw - 1;   // last entry: cstart[row + xhi + 1]
+          const uint32_t last = __shfl(kl < kWave ? word[u][0] : word[u][1], kl & (kWave - 1), kWave);
+          if (lane == 0) {
+            T.rowoff[r] = last - first;   // the row's point count, scanned below
+            T.rowbase[r] = first;
+            if (last - first > 0xFFFFu) T.info[TI_OK] = 0;  // 16-bit offsets would overflow
+          }
+        }
+      }
+      yi = yy; zi = zz;
+    }
+  }
+  __syncthreads();
+  // ---- exclusive scan of the row counts (wavefront 0, two rows per lane)
+  if (wv == 0) {
+    const int r0 = 2 * lane, r1 = 2 * lane + 1;
+    const uint32_t c0 = r0 < nrow ? T.rowoff[r0] : 0u, c1 = r1 < nrow ? T.rowoff[r1] : 0u;
+    uint32_t incl = c0 + c1;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const uint32_t u = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += u;
+    }
+    const uint32_t excl = incl - (c0 + c1);
+    if (r0 < nrow) T.rowoff[r0] = excl;
+    if (r1 < nrow) T.rowoff[r1] = excl + c0;
+    if (lane == kWave - 1) {
+      T.rowoff[nrow] = incl;   // kTileRows <= 2 * kWave, so every row is covered
+      if (incl > (uint32_t)kTilePts) T.info[TI_OK] = 0;
+    }
+  }
+  __syncthreads();
+  if (T.info[TI_OK] == 0) return false;
+
+  // ---- stage the points: flat point index -> row by binary search in rowoff (LDS); the
+  // points of a row segment are contiguous in gold[0], so consecutive threads read
+  // consecutive addresses, and a thread's up to 6 loads are all in flight together
+  const uint32_t npts = T.rowoff[nrow];
+  constexpr int kPtsPerThread = (kTilePts + kBlock - 1) / kBlock;
+  {
+    float4 q[kPtsPerThread];
+#pragma unroll
+    for (int u = 0; u < kPtsPerThread; ++u) {
+      const uint32_t f = threadIdx.x + (uint32_t)u * kBlock;
+      if (f < npts) {
+        int lo = 0, hi = nrow;          // invariant: rowoff[lo] <= f < rowoff[hi]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (T.rowoff[mid] <= f) lo = mid; else hi = mid;
+        }
+        q[u] = ld_point(gold0, T.rowbase[lo] + (f - T.rowoff[lo]));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kPtsPerThread; ++u) {
+      const uint32_t f = threadIdx.x + (uint32_t)u * kBlock;
+      if (f < npts) T.pts[f] = q[u];
+    }
+  }
+  if (COUNT && threadIdx.x == 0) { nrows += (uint32_t)(nrow * tw); ncand += npts; }
+  __syncthreads();
+
+  // ---- per-lane exact search inside the tile (rows of the lane's own range, centre first)
+  if (ranged) {
+    const int ccy = min(max((int)floorf((py - S.oy) * inv_c), iy0), iy1);
+    const int ccz = min(max((int)floorf((pz - S.oz) * inv_c), iz0), iz1);
+    const int nyr = iy1 - iy0 + 1, nzr = iz1 - iz0 + 1;
+    for (int a = 0; a < nzr; ++a) {
+      const int z = centre_out(a, ccz, iz0, iz1);
+      const float zlo_f = S.oz + (float)z * c;
+      const float dzq = fmaxf(0.f, fmaxf(zlo_f - S.delta - pz, pz - (zlo_f + c + S.delta)));
+      if (dzq * dzq >= best2) continue;
+      for (int bq = 0; bq < nyr; ++bq) {
+        const int y = centre_out(bq, ccy, iy0, iy1);
+        const float ylo_f = S.oy + (float)y * c;
+        const float dyq = fmaxf(0.f, fmaxf(ylo_f - S.delta - py, py - (ylo_f + c + S.delta)));
+        const float d2yz = dyq * dyq + dzq * dzq;
+        if (d2yz >= best2) continue;
+        const float rx = sqrtf(best2 - d2yz) + S.delta;
+        const int x0 = max((int)fmaxf(floorf((px - rx - S.ox) * inv_c), -1.f), ix0);
+        const int x1 = min((int)fminf(floorf((px + rx - S.ox) * inv_c), (float)nx), ix1);
+        if (x0 > x1) continue;
+        const int r = (z - zlo) * ty + (y - ylo);
+        const uint32_t off = T.rowoff[r];
+        const uint32_t ja = off + T.tab[r * tw + (x0 - xlo)], jb = off + T.tab[r * tw + (x1 + 1 - xlo)];
+        for (uint32_t j = ja; j < jb; ++j) {
+          const float4 q = T.pts[j];
+          const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          if (d2 < best2) { best2 = d2; bestj = __float_as_uint(q.w); }
+        }
+      }
+    }
+  }
+  return true;
+}
+
 // XCD-aware chunk order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
 // and b+8 share an L2.  Chunk (b%8)*(G/8) + b/8 gives every XCD one contiguous eighth of
 // the (cell-sorted) source cloud, i.e. one slab of the gold grid in its private L2.
@@ -445,14 +698,17 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
 
-  if (i < n) {
-    const float4 s = src[i];
-    const double Px = st->R[0] * s.x + st->R[1] * s.y + st->R[2] * s.z + st->t[0];
-    const double Py = st->R[3] * s.x + st->R[4] * s.y + st->R[5] * s.z + st->t[1];
-    const double Pz = st->R[6] * s.x + st->R[7] * s.y + st->R[8] * s.z + st->t[2];
-    const float px = (float)Px, py = (float)Py, pz = (float)Pz;
-    float best2 = best2_init;
-    uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
+  const bool has_query = i < n;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  double Px = 0.0, Py = 0.0, Pz = 0.0;
+  float px = 0.f, py = 0.f, pz = 0.f, best2 = best2_init;
+  uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
+  if (has_query) {
+    s = src[i];
+    Px = st->R[0] * s.x + st->R[1] * s.y + st->R[2] * s.z + st->t[0];
+    Py = st->R[3] * s.x + st->R[4] * s.y + st->R[5] * s.z + st->t[1];
+    Pz = st->R[6] * s.x + st->R[7] * s.y + st->R[8] * s.z + st->t[2];
+    px = (float)Px; py = (float)Py; pz = (float)Pz;
     if (prev) {
       // temporal coherence: last iteration's match bounds the search radius from the start
       const uint32_t pj = prev[i];
@@ -464,7 +720,24 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
         if (d2 < best2) { best2 = d2; bestj = pj; }
       }
     }
-    nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
+  }
+#if MA_TILE
+  __shared__ TileShared tile;
+  const bool served = tile_search<COUNT>(tile, has_query, px, py, pz, S, best2, bestj, nrows, ncand);
+#else
+  const bool served = false;
+#endif
+#if defined(MA_EXP_TILESTAT)
+  if (COUNT && threadIdx.x == 0) { nrows = served ? 1u : 0u; ncand = served ? tile.rowoff[tile.info[TI_NROWS]] : 0u; }
+  else { nrows = 0; ncand = 0; }
+#endif
+  if (has_query) {
+#if defined(MA_EXP_TILESTAT)
+    uint32_t dummy_r = 0, dummy_c = 0;
+    if (!served) nn_find<false>(px, py, pz, S, best2, bestj, dummy_r, dummy_c);
+#else
+    if (!served) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
+#endif
     if (prev) prev[i] = bestj;
     if (MODE == 1) {
       nn_idx[i] = bestj != kNoMatch ? perm0[bestj] : kNoMatch;
@@ -895,15 +1168,16 @@ float clamp_cell_to_budget(const float lo[3], const float hi[3], float c, uint64
 // keys/vals for `n` raw points + optional histogram; then a stable radix sort by cell id.
 // On return vals_b holds the permutation (sorted position -> original index).
 int sort_by_cell(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, const double o[3],
-                 uint32_t* d_counts) {
+                 uint32_t* d_counts, int brick = 0) {
   HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
   HIPCHK(ctx->keys_b.ensure((size_t)n * 4));
   HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
   HIPCHK(ctx->vals_b.ensure((size_t)n * 4));
   hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0],
-                     o[1], o[2], g, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), d_counts);
+                     o[1], o[2], g, brick, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), d_counts);
   HIPCHK(hipGetLastError());
-  const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
+  const uint64_t ncells = brick ? ((uint64_t)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3)) << 9
+                                : (uint64_t)g.nx * g.ny * g.nz;
   int bits = 1;
   while (bits < 32 && (1ull << bits) < ncells) ++bits;
   size_t tmp_bytes = 0;
@@ -926,7 +1200,7 @@ int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, 
   HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
   HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
   hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0],
-                     o[1], o[2], g, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                     o[1], o[2], g, 0, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
                      ctx->cstart[0].as<uint32_t>());
   HIPCHK(hipGetLastError());
   HIPCHK(ctx->misc.ensure(64));
@@ -1254,10 +1528,11 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
   int rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, lo, hi);
   if (rc) return rc;
   // sort in the cloud's own frame with the gold map's cell edge (coarsened to fit 2^27
-  // cells): consecutive lanes then query neighbouring gold cells under any rigid motion.
+  // cells), brick-major: 256 consecutive points then form a compact patch, so that a
+  // workgroup's queries share one small block of the gold grid under any rigid motion.
   const float c = clamp_cell_to_budget(lo, hi, ctx->grid.c, kMaxCells);
   const GridP g = make_grid(lo, hi, ctx->origin, c);
-  if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, nullptr))) return rc;
+  if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, nullptr, /*brick=*/1))) return rc;
   HIPCHK(ctx->src.ensure((size_t)n * sizeof(float4)));
   HIPCHK(ctx->src_perm.ensure((size_t)n * 4));
   HIPCHK(hipMemcpyAsync(ctx->src_perm.p, ctx->vals_b.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));

