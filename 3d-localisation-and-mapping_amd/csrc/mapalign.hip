@@ -7,9 +7,9 @@
 //                       walk with distance pruning), distance gate, fp64 accumulation of
 //                       {W, s_p, s_q, S, E}; wavefront shuffle reduction -> one fp64
 //                       partial per workgroup (no float atomics => bitwise reproducible)
-//   k_reduce_solve a5-a7 fixed-order sum of the partials, 3x3 Jacobi-SVD Kabsch step,
-//                       transform composition and convergence test, all on the device so
-//                       the loop never synchronises with the host
+//   k_reduce19   a5     fixed-order sum of the partials, one workgroup per accumulator
+//   k_solve      a6-a7  3x3 Jacobi-SVD Kabsch step, transform composition and convergence
+//                       test on the device, so the loop never synchronises with the host
 //   k_unproject  a8     depth image -> world points written straight into the source
 //                       cloud buffer (order-preserving compaction of valid pixels)
 // Everything is written for 64-wide wavefronts; there is no MFMA because the path is a
@@ -69,27 +69,34 @@ struct DevState {
 // ---------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------
-// fp64 add of a DPP-shifted copy (two 32-bit DPP moves + one add; no LDS traffic)
-template <int CTRL, int ROW_MASK, int BANK_MASK>
+// fp64 add of a DPP-shifted copy (two 32-bit DPP moves + one add; no LDS traffic).
+// bound_ctrl = 1 makes lanes without a source read 0, and every row is enabled, so no
+// "old" operand has to be materialised (that cost two extra moves per step before).
+template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, false);
-  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, false);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true);
   return v + __hiloint2double(hi2, lo2);
 }
 // Wavefront sum on the VALU only (DPP row shifts + row broadcasts; no LDS permutes, which
-// measured 6 us per launch slower).  The total ends up in lane 63.
+// measured 6 us per launch slower).  Only lane 63 holds the total: the broadcasts go to
+// all rows, so the other lanes end with partial sums nobody reads.
 __device__ __forceinline__ double wave_sum(double v) {
-  v = dpp_add<0x111, 0xF, 0xF>(v);  // row_shr:1
-  v = dpp_add<0x112, 0xF, 0xF>(v);  // row_shr:2
-  v = dpp_add<0x114, 0xF, 0xF>(v);  // row_shr:4
-  v = dpp_add<0x118, 0xF, 0xF>(v);  // row_shr:8   -> lane 15 of each row holds the row sum
-  v = dpp_add<0x142, 0xA, 0xF>(v);  // row_bcast:15 into rows 1 and 3
-  v = dpp_add<0x143, 0xC, 0xF>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+  v = dpp_add<0x111>(v);  // row_shr:1
+  v = dpp_add<0x112>(v);  // row_shr:2
+  v = dpp_add<0x114>(v);  // row_shr:4
+  v = dpp_add<0x118>(v);  // row_shr:8   -> lane 15 of each row holds the row sum
+  v = dpp_add<0x142>(v);  // row_bcast:15: row r += row sum of row r-1
+  v = dpp_add<0x143>(v);  // row_bcast:31: rows 2,3 += lane 31 -> lane 63 = total
   return v;
 }
 constexpr int kSumLane = kWave - 1;
 
+
+// hardware square root (1 ulp, one instruction instead of the ~18 of the correctly rounded
+// sqrtf).  Only used for search radii, which carry the boundary slack `delta` anyway.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 __device__ __forceinline__ uint32_t cell_of(float x, float y, float z, const GridP& g) {
   int ix = (int)floorf((x - g.ox) * g.inv_c);
@@ -304,7 +311,7 @@ __device__ __forceinline__ void level_pass(const float px, const float py, const
         const float dyq = fmaxf(0.f, fmaxf(ylo - S.delta - py, py - (ylo + V.c + S.delta)));
         const float d2yz = dyq * dyq + dzq * dzq;
         if (d2yz < best2) {
-          const float rx = sqrtf(best2 - d2yz) + S.delta;  // +inf while ungated and unmatched
+          const float rx = fast_sqrt(best2 - d2yz) + S.delta;  // +inf while ungated and unmatched
           const int x0 = (int)fmaxf(floorf((px - rx - S.ox) * V.inv_c), 0.f);
           const int x1 = (int)fminf(floorf((px + rx - S.ox) * V.inv_c), (float)(V.nx - 1));
           if (x0 <= x1) {
@@ -374,7 +381,7 @@ __device__ __forceinline__ void ring_walk(const float px, const float py, const 
               const float dzq = fmaxf(0.f, fmaxf(zlo - S.delta - pz, pz - (zlo + V.c + S.delta)));
               const float d2yz = dyq * dyq + dzq * dzq;
               if (d2yz < best2) {
-                const float rx = sqrtf(best2 - d2yz) + S.delta;
+                const float rx = fast_sqrt(best2 - d2yz) + S.delta;
                 const int x0 = (int)fmaxf(floorf((px - rx - S.ox) * V.inv_c), 0.f);
                 const int x1 = (int)fminf(floorf((px + rx - S.ox) * V.inv_c), (float)(V.nx - 1));
                 if (x0 <= x1) {
@@ -442,7 +449,7 @@ __device__ __forceinline__ void nn_find(const float px, const float py, const fl
 // straddles two rows of the source sort, a first iteration with the full gate as radius on
 // a dense map) falls back to the global-memory search for that workgroup only.
 #ifndef MA_TILE
-#define MA_TILE 1
+#define MA_TILE 0   // measured slower than the global path on MI355X: kept for A/B
 #endif
 constexpr int kTileRows = 128;    // (y,z) rows per tile
 constexpr int kTileWords = 3072;  // 16-bit table entries (row-relative point offsets)
@@ -481,40 +488,63 @@ __device__ __forceinline__ int centre_out(int a, int c, int lo, int hi) {
   return L < R ? c + (a - m) : c - (a - m);
 }
 
-// Returns true if the workgroup was served by the tile (all lanes done, exact); false if
+#ifndef MA_Q
+#define MA_Q 1
+#endif
+constexpr int kQ = MA_Q;   // source points per thread (tile staging and the fp64 reduction are per workgroup)
+
+struct CellRange { int x0, x1, y0, y1, z0, z1; bool ok; };
+
+// cells the sphere (centre p, squared radius r2) reaches, clipped to the level-0 grid
+__device__ __forceinline__ CellRange sphere_cells(const float px, const float py, const float pz,
+                                                  const float r2, const LevelSet& S) {
+  const float inv_c = S.inv_c[0];
+  const int nx = S.nx[0], ny = S.ny[0], nz = S.nz[0];
+  const float r = fast_sqrt(r2) + S.delta;
+  CellRange R;
+  R.x0 = max((int)fmaxf(floorf((px - r - S.ox) * inv_c), -1.f), 0);
+  R.x1 = min((int)fminf(floorf((px + r - S.ox) * inv_c), (float)nx), nx - 1);
+  R.y0 = max((int)fmaxf(floorf((py - r - S.oy) * inv_c), -1.f), 0);
+  R.y1 = min((int)fminf(floorf((py + r - S.oy) * inv_c), (float)ny), ny - 1);
+  R.z0 = max((int)fmaxf(floorf((pz - r - S.oz) * inv_c), -1.f), 0);
+  R.z1 = min((int)fminf(floorf((pz + r - S.oz) * inv_c), (float)nz), nz - 1);
+  R.ok = R.x0 <= R.x1 && R.y0 <= R.y1 && R.z0 <= R.z1;  // else: the sphere misses the grid
+  return R;
+}
+
+// Returns true if the workgroup was served by the tile (all queries done, exact); false if
 // the caller must run the global-memory search.  Must be called by all 256 threads.
 template <bool COUNT>
-__device__ __forceinline__ bool tile_search(TileShared& T, const bool has_query, const float px,
-                                            const float py, const float pz, const LevelSet& S,
-                                            float& best2, uint32_t& bestj, uint32_t& nrows,
-                                            uint32_t& ncand) {
+__device__ __forceinline__ bool tile_search(TileShared& T, const bool (&has)[kQ], const float (&px)[kQ],
+                                            const float (&py)[kQ], const float (&pz)[kQ],
+                                            const LevelSet& S, float (&best2)[kQ], uint32_t (&bestj)[kQ],
+                                            uint32_t& nrows, uint32_t& ncand) {
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   const float c = S.c[0], inv_c = S.inv_c[0];
-  const int nx = S.nx[0], ny = S.ny[0], nz = S.nz[0];
+  const int nx = S.nx[0], ny = S.ny[0];
   const float4* __restrict__ gold0 = S.gold[0];
   const uint32_t* __restrict__ cs0 = S.cs[0];
 
-  // ---- the lane's cell range (its sphere, clipped to the grid)
-  bool ranged = false, bad = false;
-  int ix0 = 0, ix1 = -1, iy0 = 0, iy1 = -1, iz0 = 0, iz1 = -1;
-  if (has_query && isfinite(px) && isfinite(py) && isfinite(pz)) {
-    if (!isfinite(best2)) {
-      bad = true;  // no radius known (ungated, nothing remembered): cannot bound a tile
-    } else {
-      const float r = sqrtf(best2) + S.delta;
-      ix0 = max((int)fmaxf(floorf((px - r - S.ox) * inv_c), -1.f), 0);
-      ix1 = min((int)fminf(floorf((px + r - S.ox) * inv_c), (float)nx), nx - 1);
-      iy0 = max((int)fmaxf(floorf((py - r - S.oy) * inv_c), -1.f), 0);
-      iy1 = min((int)fminf(floorf((py + r - S.oy) * inv_c), (float)ny), ny - 1);
-      iz0 = max((int)fmaxf(floorf((pz - r - S.oz) * inv_c), -1.f), 0);
-      iz1 = min((int)fminf(floorf((pz + r - S.oz) * inv_c), (float)nz), nz - 1);
-      ranged = ix0 <= ix1 && iy0 <= iy1 && iz0 <= iz1;  // else: the sphere misses the grid
+  // ---- union of the lane's spheres, in cells
+  const int big = 0x3FFFFFFF;
+  bool bad = false;
+  int b0 = big, b1 = big, b2 = big, b3 = big, b4 = big, b5 = big;
+#pragma unroll
+  for (int q = 0; q < kQ; ++q) {
+    if (has[q] && isfinite(px[q]) && isfinite(py[q]) && isfinite(pz[q])) {
+      if (!isfinite(best2[q])) {
+        bad = true;  // no radius known (ungated, nothing remembered): cannot bound a tile
+      } else {
+        const CellRange R = sphere_cells(px[q], py[q], pz[q], best2[q], S);
+        if (R.ok) {
+          b0 = min(b0, R.x0); b1 = min(b1, R.y0); b2 = min(b2, R.z0);
+          b3 = min(b3, -R.x1); b4 = min(b4, -R.y1); b5 = min(b5, -R.z1);
+        }
+      }
     }
   }
-  const int big = 0x3FFFFFFF;
-  const int m0 = wave_min_i32(ranged ? ix0 : big), m1 = wave_min_i32(ranged ? iy0 : big);
-  const int m2 = wave_min_i32(ranged ? iz0 : big), m3 = wave_min_i32(ranged ? -ix1 : big);
-  const int m4 = wave_min_i32(ranged ? -iy1 : big), m5 = wave_min_i32(ranged ? -iz1 : big);
+  const int m0 = wave_min_i32(b0), m1 = wave_min_i32(b1), m2 = wave_min_i32(b2);
+  const int m3 = wave_min_i32(b3), m4 = wave_min_i32(b4), m5 = wave_min_i32(b5);
   const int m6 = wave_min_i32(bad ? 0 : 1);
   if (lane == kWave - 1) {
     T.wave_box[wv][0] = m0; T.wave_box[wv][1] = m1; T.wave_box[wv][2] = m2; T.wave_box[wv][3] = m3;
@@ -639,37 +669,47 @@ __device__ __forceinline__ bool tile_search(TileShared& T, const bool has_query,
   if (COUNT && threadIdx.x == 0) { nrows += (uint32_t)(nrow * tw); ncand += npts; }
   __syncthreads();
 
-  // ---- per-lane exact search inside the tile (rows of the lane's own range, centre first)
-  if (ranged) {
-    const int ccy = min(max((int)floorf((py - S.oy) * inv_c), iy0), iy1);
-    const int ccz = min(max((int)floorf((pz - S.oz) * inv_c), iz0), iz1);
-    const int nyr = iy1 - iy0 + 1, nzr = iz1 - iz0 + 1;
-    for (int a = 0; a < nzr; ++a) {
-      const int z = centre_out(a, ccz, iz0, iz1);
-      const float zlo_f = S.oz + (float)z * c;
-      const float dzq = fmaxf(0.f, fmaxf(zlo_f - S.delta - pz, pz - (zlo_f + c + S.delta)));
-      if (dzq * dzq >= best2) continue;
-      for (int bq = 0; bq < nyr; ++bq) {
-        const int y = centre_out(bq, ccy, iy0, iy1);
-        const float ylo_f = S.oy + (float)y * c;
-        const float dyq = fmaxf(0.f, fmaxf(ylo_f - S.delta - py, py - (ylo_f + c + S.delta)));
-        const float d2yz = dyq * dyq + dzq * dzq;
-        if (d2yz >= best2) continue;
-        const float rx = sqrtf(best2 - d2yz) + S.delta;
-        const int x0 = max((int)fmaxf(floorf((px - rx - S.ox) * inv_c), -1.f), ix0);
-        const int x1 = min((int)fminf(floorf((px + rx - S.ox) * inv_c), (float)nx), ix1);
-        if (x0 > x1) continue;
-        const int r = (z - zlo) * ty + (y - ylo);
-        const uint32_t off = T.rowoff[r];
-        const uint32_t ja = off + T.tab[r * tw + (x0 - xlo)], jb = off + T.tab[r * tw + (x1 + 1 - xlo)];
-        for (uint32_t j = ja; j < jb; ++j) {
-          const float4 q = T.pts[j];
-          const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
-          const float d2 = dx * dx + dy * dy + dz * dz;
-          if (d2 < best2) { best2 = d2; bestj = __float_as_uint(q.w); }
+  // ---- per-lane exact search inside the tile (rows of the query's own range, centre first)
+#pragma unroll
+  for (int q = 0; q < kQ; ++q) {
+    if (!(has[q] && isfinite(px[q]) && isfinite(py[q]) && isfinite(pz[q]))) continue;
+    const float qx = px[q], qy = py[q], qz = pz[q];
+    float bb = best2[q];
+    uint32_t bj = bestj[q];
+    const CellRange R = sphere_cells(qx, qy, qz, bb, S);
+    if (R.ok) {
+      const int ccy = min(max((int)floorf((qy - S.oy) * inv_c), R.y0), R.y1);
+      const int ccz = min(max((int)floorf((qz - S.oz) * inv_c), R.z0), R.z1);
+      const int nyr = R.y1 - R.y0 + 1, nzr = R.z1 - R.z0 + 1;
+      for (int a = 0; a < nzr; ++a) {
+        const int z = centre_out(a, ccz, R.z0, R.z1);
+        const float zlo_f = S.oz + (float)z * c;
+        const float dzq = fmaxf(0.f, fmaxf(zlo_f - S.delta - qz, qz - (zlo_f + c + S.delta)));
+        if (dzq * dzq >= bb) continue;
+        for (int bq = 0; bq < nyr; ++bq) {
+          const int y = centre_out(bq, ccy, R.y0, R.y1);
+          const float ylo_f = S.oy + (float)y * c;
+          const float dyq = fmaxf(0.f, fmaxf(ylo_f - S.delta - qy, qy - (ylo_f + c + S.delta)));
+          const float d2yz = dyq * dyq + dzq * dzq;
+          if (d2yz >= bb) continue;
+          const float rx = fast_sqrt(bb - d2yz) + S.delta;
+          const int x0 = max((int)fmaxf(floorf((qx - rx - S.ox) * inv_c), -1.f), R.x0);
+          const int x1 = min((int)fminf(floorf((qx + rx - S.ox) * inv_c), (float)nx), R.x1);
+          if (x0 > x1) continue;
+          const int r = (z - zlo) * ty + (y - ylo);
+          const uint32_t off = T.rowoff[r];
+          const uint32_t ja = off + T.tab[r * tw + (x0 - xlo)], jb = off + T.tab[r * tw + (x1 + 1 - xlo)];
+          for (uint32_t j = ja; j < jb; ++j) {
+            const float4 g = T.pts[j];
+            const float dx = qx - g.x, dy = qy - g.y, dz = qz - g.z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < bb) { bb = d2; bj = __float_as_uint(g.w); }
+          }
         }
       }
     }
+    best2[q] = bb;
+    bestj[q] = bj;
   }
   return true;
 }
@@ -682,8 +722,10 @@ __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t G) {
 }
 
 // a4 + a5 fused.  MODE 0: accumulate only; MODE 1: also write per-point (idx, d2).
-// One source point per thread: the 17 fp64 accumulator terms are formed only after the
-// search, so they do not occupy registers while the search needs them for latency hiding.
+// kQ source points per thread (point base + q*256 + tid: coalesced).  Their loads are
+// batched, the LDS tile is staged once for all kQ*256 points of the workgroup, and the 17
+// fp64 accumulators are carried over the kQ points so that the wavefront/workgroup
+// reduction is paid once per kQ*256 points.
 template <bool COUNT, int MODE>
 __global__ __launch_bounds__(kBlock) void k_nn_accum(
     const float4* __restrict__ src, const uint32_t n, const LevelSet S,
@@ -692,73 +734,103 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
     float* __restrict__ nn_d2) {
   if (MODE == 0 && st->done) return;
   const uint32_t G = gridDim.x;
-  const uint32_t i = xcd_chunk(blockIdx.x, G) * kBlock + threadIdx.x;
+  const uint32_t base = xcd_chunk(blockIdx.x, G) * (uint32_t)(kBlock * kQ) + threadIdx.x;
 
-  double acc[kNAcc];
+  bool has[kQ];
+  float4 s[kQ];
+  uint32_t pj[kQ];
 #pragma unroll
-  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
-
-  const bool has_query = i < n;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  double Px = 0.0, Py = 0.0, Pz = 0.0;
-  float px = 0.f, py = 0.f, pz = 0.f, best2 = best2_init;
-  uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
-  if (has_query) {
-    s = src[i];
-    Px = st->R[0] * s.x + st->R[1] * s.y + st->R[2] * s.z + st->t[0];
-    Py = st->R[3] * s.x + st->R[4] * s.y + st->R[5] * s.z + st->t[1];
-    Pz = st->R[6] * s.x + st->R[7] * s.y + st->R[8] * s.z + st->t[2];
-    px = (float)Px; py = (float)Py; pz = (float)Pz;
-    if (prev) {
-      // temporal coherence: last iteration's match bounds the search radius from the start
-      const uint32_t pj = prev[i];
-      if (pj != kNoMatch) {
-        const float4 c = ld_point(S.gold[0], pj);
-        const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
+  for (int q = 0; q < kQ; ++q) {
+    const uint32_t i = base + (uint32_t)q * kBlock;
+    has[q] = i < n;
+    s[q] = has[q] ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    pj[q] = (has[q] && prev) ? prev[i] : kNoMatch;
+  }
+  float px[kQ], py[kQ], pz[kQ], best2[kQ];
+  uint32_t bestj[kQ], nrows = 0, ncand = 0;
+#pragma unroll
+  for (int q = 0; q < kQ; ++q) {
+    px[q] = (float)(st->R[0] * s[q].x + st->R[1] * s[q].y + st->R[2] * s[q].z + st->t[0]);
+    py[q] = (float)(st->R[3] * s[q].x + st->R[4] * s[q].y + st->R[5] * s[q].z + st->t[1]);
+    pz[q] = (float)(st->R[6] * s[q].x + st->R[7] * s[q].y + st->R[8] * s[q].z + st->t[2]);
+    best2[q] = best2_init;
+    bestj[q] = kNoMatch;
+  }
+  // temporal coherence: last iteration's match bounds the search radius from the start
+  {
+    float4 cnd[kQ];
+#pragma unroll
+    for (int q = 0; q < kQ; ++q)
+      cnd[q] = pj[q] != kNoMatch ? ld_point(S.gold[0], pj[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+      if (pj[q] != kNoMatch) {
+        const float dx = px[q] - cnd[q].x, dy = py[q] - cnd[q].y, dz = pz[q] - cnd[q].z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         if (COUNT) ncand += 1u;
-        if (d2 < best2) { best2 = d2; bestj = pj; }
+        if (d2 < best2[q]) { best2[q] = d2; bestj[q] = pj[q]; }
       }
     }
   }
 #if MA_TILE
   __shared__ TileShared tile;
-  const bool served = tile_search<COUNT>(tile, has_query, px, py, pz, S, best2, bestj, nrows, ncand);
+  const bool served = tile_search<COUNT>(tile, has, px, py, pz, S, best2, bestj, nrows, ncand);
 #else
   const bool served = false;
 #endif
-#if defined(MA_EXP_TILESTAT)
-  if (COUNT && threadIdx.x == 0) { nrows = served ? 1u : 0u; ncand = served ? tile.rowoff[tile.info[TI_NROWS]] : 0u; }
-  else { nrows = 0; ncand = 0; }
-#endif
-  if (has_query) {
-#if defined(MA_EXP_TILESTAT)
-    uint32_t dummy_r = 0, dummy_c = 0;
-    if (!served) nn_find<false>(px, py, pz, S, best2, bestj, dummy_r, dummy_c);
-#else
-    if (!served) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
-#endif
-    if (prev) prev[i] = bestj;
-    if (MODE == 1) {
-      nn_idx[i] = bestj != kNoMatch ? perm0[bestj] : kNoMatch;
-      nn_d2[i] = bestj != kNoMatch ? best2 : INFINITY;
+  if (!served) {
+#pragma unroll 1
+    for (int q = 0; q < kQ; ++q) {
+      // (rolled: one copy of the global search; q-indexed state goes through selects)
+      float bx = 0.f, by = 0.f, bz = 0.f, bb = 0.f;
+      uint32_t bj = kNoMatch;
+      bool h = false;
+#pragma unroll
+      for (int t = 0; t < kQ; ++t)
+        if (t == q) { bx = px[t]; by = py[t]; bz = pz[t]; bb = best2[t]; bj = bestj[t]; h = has[t]; }
+      if (h) nn_find<COUNT>(bx, by, bz, S, bb, bj, nrows, ncand);
+#pragma unroll
+      for (int t = 0; t < kQ; ++t)
+        if (t == q) { best2[t] = bb; bestj[t] = bj; }
     }
-    if (bestj != kNoMatch) {
-      const float4 q = ld_point(S.gold[0], bestj);   // the winner's coordinates (level 0 holds every point)
-      const double w = (double)s.w;
-      const double qx = q.x, qy = q.y, qz = q.z;
-      const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
-      const double wPx = w * Px, wPy = w * Py, wPz = w * Pz;
-      acc[0] = w;
-      acc[1] = wPx; acc[2] = wPy; acc[3] = wPz;
-      acc[4] = w * qx; acc[5] = w * qy; acc[6] = w * qz;
-      acc[7] = wPx * qx;  acc[8] = wPx * qy;  acc[9] = wPx * qz;
-      acc[10] = wPy * qx; acc[11] = wPy * qy; acc[12] = wPy * qz;
-      acc[13] = wPz * qx; acc[14] = wPz * qy; acc[15] = wPz * qz;
-      acc[16] = w * (dx * dx + dy * dy + dz * dz);
-    }
-    if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
   }
+
+  double acc[kNAcc];
+#pragma unroll
+  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
+  {
+    float4 win[kQ];
+#pragma unroll
+    for (int q = 0; q < kQ; ++q)   // the winners' coordinates (level 0 holds every point)
+      win[q] = bestj[q] != kNoMatch ? ld_point(S.gold[0], bestj[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+      const uint32_t i = base + (uint32_t)q * kBlock;
+      if (!has[q]) continue;
+      if (prev) prev[i] = bestj[q];
+      if (MODE == 1) {
+        nn_idx[i] = bestj[q] != kNoMatch ? perm0[bestj[q]] : kNoMatch;
+        nn_d2[i] = bestj[q] != kNoMatch ? best2[q] : INFINITY;
+      }
+      if (bestj[q] != kNoMatch) {
+        const double Px = st->R[0] * s[q].x + st->R[1] * s[q].y + st->R[2] * s[q].z + st->t[0];
+        const double Py = st->R[3] * s[q].x + st->R[4] * s[q].y + st->R[5] * s[q].z + st->t[1];
+        const double Pz = st->R[6] * s[q].x + st->R[7] * s[q].y + st->R[8] * s[q].z + st->t[2];
+        const double w = (double)s[q].w;
+        const double qx = win[q].x, qy = win[q].y, qz = win[q].z;
+        const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
+        const double wPx = w * Px, wPy = w * Py, wPz = w * Pz;
+        acc[0] += w;
+        acc[1] += wPx; acc[2] += wPy; acc[3] += wPz;
+        acc[4] += w * qx; acc[5] += w * qy; acc[6] += w * qz;
+        acc[7] += wPx * qx;  acc[8] += wPx * qy;  acc[9] += wPx * qz;
+        acc[10] += wPy * qx; acc[11] += wPy * qy; acc[12] += wPy * qz;
+        acc[13] += wPz * qx; acc[14] += wPz * qy; acc[15] += wPz * qz;
+        acc[16] += w * (dx * dx + dy * dy + dz * dz);
+      }
+    }
+  }
+  if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
 
   // wavefront shuffle reduction, then a fixed-order sum over the 4 wavefronts
   __shared__ double red[kBlock / kWave][kNAcc];
@@ -779,72 +851,45 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
   }
 }
 
-// a5 (final sum) + a6 + a7.  One workgroup of 1024 threads (16 wavefronts).
-//   do_reduce: acc = fixed-order sum of partials[k][0..G); optionally stored to acc_out
-//   else     : acc = acc_in[0..19)
-//   do_solve : Kabsch step, composition, convergence test, trace row
-// All 2 x 19 partial loads of a thread are issued before the first use, so the kernel pays
-// one memory round trip, not 19; the serial tail is one lane of fp64 Jacobi sweeps.
-constexpr int kSolveBlock = 1024;
-constexpr int kSolveWaves = kSolveBlock / kWave;
-
-__global__ __launch_bounds__(kSolveBlock) void k_reduce_solve(
-    const double* __restrict__ partials, const int G, const double* __restrict__ acc_in,
-    double* __restrict__ acc_out, DevState* __restrict__ st, double* __restrict__ trace,
-    const int trace_cap, const double tol, const int do_reduce, const int do_solve) {
+// a5 (final sum): one workgroup PER ACCUMULATOR sums that accumulator's G partials — 19
+// CUs pull 31 KB each instead of one CU pulling 0.6 MB (one CU's load bandwidth, not the
+// arithmetic, is what a single-workgroup reduction waits for).  Fixed assignment partial ->
+// thread, fixed order within a thread, DPP + LDS tree: deterministic.
+__global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ partials, const int G,
+                                                     const DevState* __restrict__ st,
+                                                     double* __restrict__ acc_out) {
   if (st->done) return;
-  __shared__ double red[kSolveWaves][kNAcc];
-  __shared__ double acc[kNAcc];
-  // thread 0 fetches the state while the partials are in flight
-  DevState s0;
-  if (threadIdx.x == 0 && do_solve) s0 = *st;
-  if (do_reduce) {
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    double v[kNAcc];
+  const int k = blockIdx.x;
+  const double* __restrict__ p = partials + (size_t)k * G;
+  double v = 0.0;
+  for (int b0 = threadIdx.x; b0 < G; b0 += 8 * kBlock) {
+    double u[8];
 #pragma unroll
-    for (int k = 0; k < kNAcc; ++k) v[k] = 0.0;
-    // fixed assignment partial -> thread and fixed order within a thread: deterministic.
-    // All 19 loads of one trip are independent (one memory round trip per trip).
-    // two trips at a time with every load issued before the first add (2 x 19 loads in
-    // flight per thread; 1024 threads cap the kernel at 128 VGPRs): the 1M-point case
-    // (G = 3912) is two memory round trips
-    for (int b0 = threadIdx.x; b0 < G; b0 += 2 * kSolveBlock) {
-      double u[2][kNAcc];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int b = b0 + t * kSolveBlock;
-#pragma unroll
-        for (int k = 0; k < kNAcc; ++k) u[t][k] = b < G ? partials[(size_t)k * G + b] : 0.0;
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int k = 0; k < kNAcc; ++k) v[k] += u[t][k];
-      }
+    for (int t = 0; t < 8; ++t) {     // eight independent loads in flight per thread
+      const int b = b0 + t * kBlock;
+      u[t] = b < G ? p[b] : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < kNAcc; ++k) {
-      const double r = wave_sum(v[k]);
-      if (lane == kSumLane) red[wv][k] = r;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNAcc) {
-      const int k = threadIdx.x;
-      double v = red[0][k];
-#pragma unroll
-      for (int w = 1; w < kSolveWaves; ++w) v += red[w][k];
-      acc[k] = v;
-      if (acc_out) acc_out[k] = v;
-    }
-  } else if (threadIdx.x < kNAcc) {
-    acc[threadIdx.x] = acc_in[threadIdx.x];
+    for (int t = 0; t < 8; ++t) v += u[t];
   }
+  __shared__ double red[kBlock / kWave];
+  v = wave_sum(v);
+  if ((threadIdx.x & (kWave - 1)) == kSumLane) red[threadIdx.x / kWave] = v;
   __syncthreads();
-  if (!do_solve || threadIdx.x != 0) return;
+  if (threadIdx.x == 0) acc_out[k] = ((red[0] + red[1]) + red[2]) + red[3];
+}
 
+// a6 + a7: one wavefront, lane 0: Kabsch step from the 19 reduced values, transform
+// composition, convergence test, trace row.  (Kept out of the search kernel: its fp64
+// Jacobi code needs ~110 VGPRs and would halve the occupancy of the search.)
+__global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_in, DevState* __restrict__ st,
+                                                 double* __restrict__ trace, const int trace_cap,
+                                                 const double tol) {
+  if (st->done || threadIdx.x != 0) return;
+  DevState s0 = *st;
   double a[kNAcc];
 #pragma unroll
-  for (int k = 0; k < kNAcc; ++k) a[k] = acc[k];
+  for (int k = 0; k < kNAcc; ++k) a[k] = acc_in[k];
   const int it = s0.iter;
   const double W = a[0];
   const double rmse = W > 0.0 ? sqrt(a[16] / W) : NAN;
@@ -858,12 +903,7 @@ __global__ __launch_bounds__(kSolveBlock) void k_reduce_solve(
   s0.last_rmse = rmse;
   s0.last_W = W;
   double dR[9], dt[3];
-#if defined(MA_EXP_NO_KABSCH)
-  dR[0] = dR[4] = dR[8] = 1.0; dR[1] = dR[2] = dR[3] = dR[5] = dR[6] = dR[7] = 0.0; dt[0] = dt[1] = dt[2] = a[1] * 1e-30;
-  if (false) {
-#else
   if (ma::kabsch_from_acc(a, dR, dt)) {
-#endif
     s0.degenerate = 1;
     s0.done = 1;
     *st = s0;
@@ -1216,9 +1256,9 @@ int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, 
   return MA_OK;
 }
 
-// one source point per thread; G a multiple of 8 so that the XCD remap is a bijection
+// kQ source points per thread; G a multiple of 8 so that the XCD remap is a bijection
 uint32_t grid_for(uint32_t n) {
-  const uint32_t G = div_up(n, kBlock);
+  const uint32_t G = div_up(n, (uint64_t)kBlock * kQ);
   return std::max<uint32_t>(8, (G + 7u) / 8u * 8u);
 }
 
@@ -1267,11 +1307,17 @@ int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float
   return MA_OK;
 }
 
-int launch_reduce_solve(ma_ctx* ctx, const double* acc_in, double* acc_out, double tol, int do_reduce,
-                        int do_solve) {
-  hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(kSolveBlock), 0, ctx->stream, ctx->partials.as<double>(),
-                     ctx->last_G, acc_in, acc_out, ctx->state.as<DevState>(), ctx->trace.as<double>(),
-                     ctx->trace_cap, tol, do_reduce, do_solve);
+// partials -> ctx->acc19 (19 workgroups), then optionally the solve (one wavefront)
+int launch_reduce(ma_ctx* ctx) {
+  hipLaunchKernelGGL(k_reduce19, dim3(kNAcc), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
+                     ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>());
+  HIPCHK(hipGetLastError());
+  return MA_OK;
+}
+
+int launch_solve(ma_ctx* ctx, double tol) {
+  hipLaunchKernelGGL(k_solve, dim3(1), dim3(kWave), 0, ctx->stream, ctx->acc19.as<double>(),
+                     ctx->state.as<DevState>(), ctx->trace.as<double>(), ctx->trace_cap, tol);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
@@ -1652,7 +1698,8 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   for (int k = 0; k < params->max_iter; ++k) {
     if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
-    if ((rc = launch_reduce_solve(ctx, nullptr, nullptr, params->tol, 1, 1))) return rc;
+    if ((rc = launch_reduce(ctx))) return rc;
+    if ((rc = launch_solve(ctx, params->tol))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 2], ctx->stream));
   }
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
@@ -1711,7 +1758,8 @@ int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16], dou
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = upload_state(ctx, T_in))) return rc;
   if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
-  if ((rc = launch_reduce_solve(ctx, nullptr, ctx->acc19.as<double>(), params->tol, 1, 1))) return rc;
+  if ((rc = launch_reduce(ctx))) return rc;
+  if ((rc = launch_solve(ctx, params->tol))) return rc;
   double a[kNAcc];
   HIPCHK(hipMemcpyAsync(a, ctx->acc19.p, sizeof(a), hipMemcpyDeviceToHost, ctx->stream));
   DevState s;
@@ -1782,7 +1830,7 @@ int ma_step_accumulate(ma_ctx* ctx, const ma_params* params, void* acc_dev) {
   if (!acc_dev) return ctx->fail(MA_ERR_INVALID, "acc_dev is NULL");
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
-  if ((rc = launch_reduce_solve(ctx, nullptr, ctx->acc19.as<double>(), params->tol, 1, 0))) return rc;
+  if ((rc = launch_reduce(ctx))) return rc;
   HIPCHK(hipMemcpyAsync(acc_dev, ctx->acc19.p, MA_ACC_LEN * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return MA_OK;
 }
@@ -1796,7 +1844,7 @@ int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev) {
   HIPCHK(hipSetDevice(ctx->device));
   // rows 17,18 (work counters) keep the local values of the accumulate step
   HIPCHK(hipMemcpyAsync(ctx->acc19.p, acc_dev, MA_ACC_LEN * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  return launch_reduce_solve(ctx, ctx->acc19.as<double>(), nullptr, params->tol, 0, 1);
+  return launch_solve(ctx, params->tol);
 }
 
 }  // extern "C"
