@@ -218,6 +218,43 @@ __global__ __launch_bounds__(kBlock) void k_invert_perm(const uint32_t* __restri
   if (pos < n) inv[perm[pos]] = pos;
 }
 
+// Chebyshev distance (in cells, capped at kOccCap) from every level-0 cell to the nearest
+// occupied one: k_occ_init marks occupied cells 0 / others kOccCap, then kOccCap - 1 rounds of
+// k_occ_relax (d = min(d, min over the 26 neighbours + 1)).  A query whose cell has distance
+// k cannot have a gold point closer than (k-1)*c: one byte read settles "nothing within the
+// gate" for points of the scan that the gold map does not cover, instead of a full ring walk.
+constexpr int kOccCap = 9;
+
+__global__ __launch_bounds__(kBlock) void k_occ_init(const uint32_t* __restrict__ cstart, uint32_t ncells,
+                                                     uint8_t* __restrict__ d) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < ncells) d[i] = cstart[i + 1] != cstart[i] ? 0 : kOccCap;
+}
+
+__global__ __launch_bounds__(kBlock) void k_occ_relax(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                      int nx, int ny, int nz) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= (uint32_t)nx * ny * nz) return;
+  const int x = i % nx, y = (i / nx) % ny, z = i / (nx * ny);
+  int best = in[i];
+  if (best > 0) {
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int zz = z + dz;
+      if ((unsigned)zz >= (unsigned)nz) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy >= (unsigned)ny) continue;
+        const uint8_t* row = in + ((size_t)zz * ny + yy) * nx;
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int xx = x + dx;
+          if ((unsigned)xx < (unsigned)nx) best = min(best, (int)row[xx] + 1);
+        }
+      }
+    }
+  }
+  out[i] = (uint8_t)best;
+}
+
 // ---------------------------------------------------------------------------------------
 // a4: exact nearest neighbour through a multi-resolution grid
 // ---------------------------------------------------------------------------------------
@@ -240,6 +277,7 @@ struct LevelSet {
   int nx[kLevels], ny[kLevels], nz[kLevels];
   float ox, oy, oz;                // common min corner (centred frame)
   float delta;                     // boundary slack (a few ulp of the largest coordinate)
+  const uint8_t* occ_dist;         // level 0: Chebyshev distance (cells, capped) to the nearest occupied cell
 };
 
 struct LevelView {
@@ -418,6 +456,22 @@ __device__ __forceinline__ void nn_find(const float px, const float py, const fl
   //    where the same two steps cover eight times the volume per table read.
   constexpr float kWalkCells = 6.f;
   bool active = isfinite(px) && isfinite(py) && isfinite(pz);
+  // 0. A search sphere wider than ~1.5 cells (an early iteration, or a point with nothing
+  //    remembered) first asks the distance-to-occupied table: if even the nearest occupied
+  //    cell is farther than the sphere, there is nothing to find (the remembered match, if
+  //    any, stays) — one byte instead of a ring walk through empty space.
+  {
+    const float c0 = S.c[0], wide0 = 1.5f * c0;
+    if (active && best2 > wide0 * wide0) {
+      const float ux = (px - S.ox) * S.inv_c[0], uy = (py - S.oy) * S.inv_c[0], uz = (pz - S.oz) * S.inv_c[0];
+      if (ux >= 0.f && uy >= 0.f && uz >= 0.f && ux < (float)S.nx[0] && uy < (float)S.ny[0] && uz < (float)S.nz[0]) {
+        const uint32_t cell = ((uint32_t)uz * (uint32_t)S.ny[0] + (uint32_t)uy) * (uint32_t)S.nx[0] + (uint32_t)ux;
+        const int k = S.occ_dist[cell];
+        const float lb = (float)max(k - 1, 0) * c0 - S.delta;
+        if (lb > 0.f && lb * lb >= best2) active = false;
+      }
+    }
+  }
 #pragma unroll 1
   for (int l = 0; l < kLevels; ++l) {
     if (!__any(active)) break;
@@ -832,22 +886,20 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
   }
   if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
 
-  // wavefront shuffle reduction, then a fixed-order sum over the 4 wavefronts
+  // wavefront DPP sums, then a fixed-order sum over the 4 wavefronts.  Without work
+  // counting only the 17 real accumulators take part (the two counter slots stay zero).
+  constexpr int kLive = COUNT ? kNAcc : ma::kAccLen;
   __shared__ double red[kBlock / kWave][kNAcc];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-#if defined(MA_EXP_NO_REDUCE)
-  if (lane == kSumLane) { for (int k = 0; k < kNAcc; ++k) red[wv][k] = acc[k]; }
-#else
 #pragma unroll
-  for (int k = 0; k < kNAcc; ++k) {
+  for (int k = 0; k < kLive; ++k) {
     const double v = wave_sum(acc[k]);
     if (lane == kSumLane) red[wv][k] = v;
   }
-#endif
   __syncthreads();
   if (threadIdx.x < kNAcc) {
     const int k = threadIdx.x;
-    partials[(size_t)k * G + blockIdx.x] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    partials[(size_t)k * G + blockIdx.x] = k < kLive ? ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k] : 0.0;
   }
 }
 
@@ -1063,7 +1115,7 @@ struct ma_ctx {
   GridP grid{};                 // level 0 (finest)
   uint64_t ncells = 0, noccupied = 0;
   double build_ms = 0;
-  DevBuf gold[kLevels], cstart[kLevels], perm0, inv0;
+  DevBuf gold[kLevels], cstart[kLevels], perm0, inv0, occ_a, occ_b;
   LevelSet levels{};
 
   // source cloud
@@ -1400,7 +1452,7 @@ int ma_destroy(ma_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (int l = 0; l < kLevels; ++l) { ctx->gold[l].release(); ctx->cstart[l].release(); }
-  for (DevBuf* b : {&ctx->perm0, &ctx->inv0, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
+  for (DevBuf* b : {&ctx->perm0, &ctx->inv0, &ctx->occ_a, &ctx->occ_b, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
                     &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc, &ctx->depth_in,
                     &ctx->state, &ctx->partials, &ctx->trace, &ctx->acc19, &ctx->nn_idx, &ctx->nn_d2,
                     &ctx->nn_tmp, &ctx->prev})
@@ -1527,6 +1579,23 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
     L.nx[l] = g.nx; L.ny[l] = g.ny; L.nz[l] = g.nz;
     L.ox = g.ox; L.oy = g.oy; L.oz = g.oz;
     if (l == 0) L.delta = g.delta;
+  }
+  // distance-to-occupied table of level 0 (ping-pong relaxations; the result ends in occ_a)
+  {
+    const uint32_t nc = (uint32_t)ncells0;
+    HIPCHK(ctx->occ_a.ensure(nc));
+    HIPCHK(ctx->occ_b.ensure(nc));
+    hipLaunchKernelGGL(k_occ_init, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       ctx->cstart[0].as<uint32_t>(), nc, ctx->occ_a.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    uint8_t* a = ctx->occ_a.as<uint8_t>();
+    uint8_t* b = ctx->occ_b.as<uint8_t>();
+    for (int it = 0; it < kOccCap - 1 + ((kOccCap - 1) & 1); ++it) {   // even count: result back in occ_a
+      hipLaunchKernelGGL(k_occ_relax, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream, a, b, g0.nx, g0.ny, g0.nz);
+      HIPCHK(hipGetLastError());
+      std::swap(a, b);
+    }
+    L.occ_dist = ctx->occ_a.as<uint8_t>();
   }
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
