@@ -1,0 +1,36 @@
+"""rocprofv3 --pmc CSVs -> profiles/pmc_traffic.json (HBM-side bytes of k_nn_accum per launch).
+
+Corrections per MI355X_MICROARCH.md §HBM: FETCH_SIZE (KB) = TCC_EA0_RDREQ x 64 B on gfx950, i.e. a
+128-byte request is tallied as 64 B.  With the per-size request counters the read bytes are
+exact: 32 B x n32 + 64 B x n64 + 128 B x n128; both figures are recorded.  WRITE_SIZE (KB) reads
+exactly for streaming stores."""
+import collections, csv, glob, json, os, sys
+d, out = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(list)
+for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+    per = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if "k_nn_accum" not in r["Kernel_Name"]:
+            continue
+        per.setdefault(int(r["Dispatch_Id"]), collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
+    for vals in list(per.values())[-50:]:       # the measured 50-iteration run
+        for c, v in vals.items():
+            agg[c].append(v)
+m = {c: sum(v) / len(v) for c, v in agg.items()}
+n32, n64, n128 = m.get("TCC_EA0_RDREQ_32B_sum", 0.0), m.get("TCC_EA0_RDREQ_64B_sum", 0.0), m.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+nreq = m.get("TCC_EA0_RDREQ_sum", 0.0)
+other = max(nreq - n32 - n64 - n128, 0.0)
+read_exact = 32 * n32 + 64 * n64 + 128 * n128 + 64 * other
+res = {
+    "kernel": "k_nn_accum", "launches_averaged": max((len(v) for v in agg.values()), default=0),
+    "FETCH_SIZE_KB": m.get("FETCH_SIZE"), "WRITE_SIZE_KB": m.get("WRITE_SIZE"),
+    "TCC_EA0_RDREQ": nreq, "RDREQ_32B": n32, "RDREQ_64B": n64, "RDREQ_128B": n128,
+    "read_bytes_by_request_size": read_exact,
+    "read_bytes_fetch_size_x1": (m.get("FETCH_SIZE") or 0) * 1024.0,
+    "write_bytes": (m.get("WRITE_SIZE") or 0) * 1024.0,
+    "TCC_HIT": m.get("TCC_HIT_sum"), "TCC_MISS": m.get("TCC_MISS_sum"),
+    "k_nn_accum_hbm_bytes_per_launch": read_exact + (m.get("WRITE_SIZE") or 0) * 1024.0,
+    "note": "memory-side (fabric) requests of the L2s; Infinity-Cache hits are included, so this is an upper bound on DRAM bytes",
+}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
