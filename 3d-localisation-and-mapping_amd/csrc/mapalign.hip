@@ -1052,6 +1052,28 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
   }
 }
 
+// a10: one thread per box corner.  cam.T here is the plain camera->world matrix (world frame).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_lift_boxes(const T* __restrict__ depth, const int width,
+                                                       const int height, const Pinhole cam,
+                                                       const float* __restrict__ boxes, const uint32_t ncorners,
+                                                       double* __restrict__ out, uint8_t* __restrict__ valid) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= ncorners) return;
+  const uint32_t b = i >> 2, k = i & 3u;
+  const float bx = boxes[4 * b + ((k == 1u || k == 2u) ? 2 : 0)];   // x1 x2 x2 x1
+  const float by = boxes[4 * b + ((k >= 2u) ? 3 : 1)];               // y1 y1 y2 y2
+  const int u = min(max((int)bx, 0), width - 1), v = min(max((int)by, 0), height - 1);  // int(x), int(y)
+  double z = (double)depth[(size_t)v * width + u] * cam.inv_scale;
+  const bool ok = isfinite(z) && z > 0.0;
+  if (!ok) z = NAN;
+  const double X = ((double)u - cam.cx) * z * cam.fx_inv, Y = ((double)v - cam.cy) * z * cam.fy_inv;
+  out[3 * (size_t)i] = cam.T[0] * X + cam.T[1] * Y + cam.T[2] * z + cam.T[3];
+  out[3 * (size_t)i + 1] = cam.T[4] * X + cam.T[5] * Y + cam.T[6] * z + cam.T[7];
+  out[3 * (size_t)i + 2] = cam.T[8] * X + cam.T[9] * Y + cam.T[10] * z + cam.T[11];
+  if (valid) valid[i] = ok ? 1 : 0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_uncentre(const float4* __restrict__ src, uint32_t n,
                                                      double o0, double o1, double o2,
                                                      float* __restrict__ xyz) {
@@ -1123,6 +1145,9 @@ struct ma_ctx {
   bool src_sorted = false;
   uint32_t n = 0;
   DevBuf src, src_perm;
+
+  // last uploaded depth frame (ma_set_source_from_depth / ma_lift_boxes)
+  int depth_w = 0, depth_h = 0, depth_dtype = -1;
 
   // scratch for builds
   DevBuf raw, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
@@ -1677,6 +1702,7 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   const size_t esz = dtype == 0 ? 4 : 2;
   HIPCHK(ctx->depth_in.ensure((size_t)npx * esz));
   HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, (size_t)npx * esz, hipMemcpyHostToDevice, ctx->stream));
+  ctx->depth_w = width; ctx->depth_h = height; ctx->depth_dtype = dtype;
   Pinhole cam{};
   cam.fx_inv = 1.0 / (double)K[0];
   cam.fy_inv = 1.0 / (double)K[1];
@@ -1724,6 +1750,54 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   ctx->n = total;
   ctx->src_sorted = false;
   ctx->have_src = true;
+  return MA_OK;
+}
+
+int ma_lift_boxes(ma_ctx* ctx, const void* depth, int dtype, int width, int height, const float K[4],
+                  const double T[16], float depth_scale, const float* boxes_xyxy, uint64_t n_boxes,
+                  double* corners_out, uint8_t* valid_out) {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!K || !T || (!boxes_xyxy && n_boxes) || (!corners_out && n_boxes)) return ctx->fail(MA_ERR_INVALID, "NULL argument");
+  if (n_boxes == 0) return MA_OK;
+  if (n_boxes > (1ull << 28)) return ctx->fail(MA_ERR_TOO_LARGE, "too many boxes");
+  if (!(K[0] != 0.f) || !(K[1] != 0.f) || !(depth_scale > 0.f) || !std::isfinite(depth_scale)) return ctx->fail(MA_ERR_INVALID, "bad intrinsics / depth_scale");
+  for (int i = 0; i < 16; ++i) if (!std::isfinite(T[i])) return ctx->fail(MA_ERR_INVALID, "non-finite camera pose");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (depth) {
+    if (dtype != 0 && dtype != 1) return ctx->fail(MA_ERR_INVALID, "dtype must be 0 (float32) or 1 (uint16)");
+    if (width <= 0 || height <= 0 || (uint64_t)width * height >= 0xFFFFFFFEull) return ctx->fail(MA_ERR_INVALID, "bad image size");
+    const size_t bytes = (size_t)width * height * (dtype == 0 ? 4 : 2);
+    HIPCHK(ctx->depth_in.ensure(bytes));
+    HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->depth_w = width; ctx->depth_h = height; ctx->depth_dtype = dtype;
+  } else if (ctx->depth_dtype < 0) {
+    return ctx->fail(MA_ERR_STATE, "no depth frame uploaded yet");
+  }
+  Pinhole cam{};
+  cam.fx_inv = 1.0 / (double)K[0];
+  cam.fy_inv = 1.0 / (double)K[1];
+  cam.cx = K[2];
+  cam.cy = K[3];
+  cam.inv_scale = 1.0 / (double)depth_scale;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) cam.T[4 * r + c] = T[4 * r + c];
+  const uint32_t nc = (uint32_t)n_boxes * 4u;
+  HIPCHK(ctx->raw.ensure((size_t)n_boxes * 16));
+  HIPCHK(ctx->misc.ensure((size_t)nc * 24 + nc));
+  HIPCHK(hipMemcpyAsync(ctx->raw.p, boxes_xyxy, (size_t)n_boxes * 16, hipMemcpyHostToDevice, ctx->stream));
+  double* d_out = ctx->misc.as<double>();
+  uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_out + (size_t)nc * 3);
+  if (ctx->depth_dtype == 0) {
+    hipLaunchKernelGGL(k_lift_boxes<float>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
+                       ctx->depth_w, ctx->depth_h, cam, ctx->raw.as<float>(), nc, d_out, d_valid);
+  } else {
+    hipLaunchKernelGGL(k_lift_boxes<uint16_t>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       ctx->depth_in.as<uint16_t>(), ctx->depth_w, ctx->depth_h, cam, ctx->raw.as<float>(), nc, d_out, d_valid);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(corners_out, d_out, (size_t)nc * 24, hipMemcpyDeviceToHost, ctx->stream));
+  if (valid_out) HIPCHK(hipMemcpyAsync(valid_out, d_valid, nc, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return MA_OK;
 }
 

@@ -162,6 +162,29 @@ class MapAligner:
         self.n_source = int(nv.value)
         return self.n_source
 
+    def lift_boxes(self, boxes_xyxy, K, T_cam_to_world, depth=None, depth_scale=1000.0):
+        """Row a10: corners (x1,y1) (x2,y1) (x2,y2) (x1,y2) of each box -> global 3-D points.
+
+        ``boxes_xyxy`` [B,4] in depth-image pixels; ``depth=None`` reuses the frame uploaded by the
+        last set_source_from_depth / lift_boxes call.  Returns (corners f64 [B,4,3], valid bool [B,4])."""
+        b = np.ascontiguousarray(boxes_xyxy, dtype=np.float32).reshape(-1, 4)
+        Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
+        T = np.ascontiguousarray(T_cam_to_world, dtype=np.float64).reshape(4, 4)
+        out = np.empty((b.shape[0], 4, 3), dtype=np.float64)
+        valid = np.zeros((b.shape[0], 4), dtype=np.uint8)
+        dptr, dtype, w, h = None, 0, 0, 0
+        if depth is not None:
+            d = np.asarray(depth)
+            if d.ndim != 2:
+                raise ValueError("depth must be a 2-D image")
+            dtype = 1 if d.dtype == np.uint16 else 0
+            d = np.ascontiguousarray(d if dtype == 1 else d.astype(np.float32, copy=False))
+            dptr, w, h = d.ctypes.data_as(C.c_void_p), d.shape[1], d.shape[0]
+        self._chk(self._lib.ma_lift_boxes(self._ctx, dptr, dtype, w, h, Kf.ctypes.data_as(C.POINTER(C.c_float)),
+                                          _f64p(T), float(depth_scale), b.ctypes.data_as(C.POINTER(C.c_float)),
+                                          b.shape[0], _f64p(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out, valid.astype(bool)
+
     def get_source(self):
         n = C.c_uint64(0)
         self._chk(self._lib.ma_get_source(self._ctx, None, C.byref(n)))

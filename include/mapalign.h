@@ -114,6 +114,19 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
 int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height,
                              const float K[4], const double T_cam_to_world[16],
                              float depth_scale, uint64_t* n_valid);
+/* Row a10: lift 2-D box corners to 3-D global coordinates (pose_processor.py:172-208):
+ * for each of the n_boxes boxes [x1,y1,x2,y2] (pixels AT DEPTH RESOLUTION, i.e. after the
+ * reference's scale_bounding_box), the four corners (x1,y1) (x2,y1) (x2,y2) (x1,y2) are
+ * truncated to integer pixels, clamped into the image, unprojected with the pinhole model
+ * of ma_set_source_from_depth (_depth_to_3d call shape, pose_processor.py:184-196) and
+ * moved to the global frame (_transform_to_global, pose_processor.py:242-260).
+ * depth == NULL reuses the frame of the last ma_set_source_from_depth / ma_lift_boxes call.
+ * corners_out: n_boxes x 4 x 3 doubles; valid_out (optional): n_boxes x 4 bytes, 0 where the
+ * depth at the corner pixel is <= 0 / NaN / inf (the corner is then NaN). */
+int ma_lift_boxes(ma_ctx* ctx, const void* depth, int dtype, int width, int height, const float K[4],
+                  const double T_cam_to_world[16], float depth_scale, const float* boxes_xyxy,
+                  uint64_t n_boxes, double* corners_out, uint8_t* valid_out);
+
 /* Copy the current source cloud back (world frame, storage order); *n in = capacity in
  * points, out = points written.  For parity tests of the unprojection kernel. */
 int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n);

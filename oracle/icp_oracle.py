@@ -185,6 +185,28 @@ def unproject_oracle(depth, K, T_cam_to_world, depth_scale=1000.0):
     return cam @ T[:3, :3].T + T[:3, 3], mask
 
 
+def lift_boxes_oracle(boxes_xyxy, depth, K, T_cam_to_world, depth_scale=1000.0):
+    """Row a10: corners (x1,y1) (x2,y1) (x2,y2) (x1,y2) at int() pixels (clamped into the
+    image) -> global points; call shape of pose_processor.py:181-201.  Returns
+    (corners [B,4,3], valid [B,4])."""
+    depth = np.asarray(depth)
+    h, w = depth.shape
+    fx, fy, cx, cy = (float(v) for v in K)
+    T = np.asarray(T_cam_to_world, dtype=np.float64).reshape(4, 4)
+    b = np.asarray(boxes_xyxy, dtype=np.float32).reshape(-1, 4)
+    out = np.full((len(b), 4, 3), np.nan)
+    valid = np.zeros((len(b), 4), dtype=bool)
+    for i, (x1, y1, x2, y2) in enumerate(b):
+        for k, (x, y) in enumerate(((x1, y1), (x2, y1), (x2, y2), (x1, y2))):
+            u, v = min(max(int(x), 0), w - 1), min(max(int(y), 0), h - 1)
+            z = float(depth[v, u]) / float(depth_scale)
+            if np.isfinite(z) and z > 0:
+                cam = np.array([(u - cx) * z / fx, (v - cy) * z / fy, z])
+                out[i, k] = T[:3, :3] @ cam + T[:3, 3]
+                valid[i, k] = True
+    return out, valid
+
+
 def rt_error(R, t, R_ref, t_ref):
     """(||R-R_ref||_F, ||t-t_ref||_2) — the two parity figures of BASELINE.json."""
     return (float(np.linalg.norm(np.asarray(R) - np.asarray(R_ref))),

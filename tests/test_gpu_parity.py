@@ -485,3 +485,36 @@ def test_alignment_adaptor_far_start_with_ply_and_pickle(tmp_path):
     res = boxes.match_bboxes(gold_boxes, aligned, max_dist=0.1)
     assert res["matches"] and res["matches"][0][2] < 0.03 and res["damaged"] == [0] and not res["missing"]
     assert len(gold_pts) == len(gold)
+
+
+# ----------------------------------------------------------------------------- row a10
+def test_lift_boxes_vs_oracle_and_frame_helper(engine):
+    from mapalign import lifting
+    depth, K, T = syn.make_depth_frame(3, width=192, height=256, fx=150.0, fy=150.0, cx=95.5, cy=127.5)
+    depth = depth.copy()
+    depth[10, 10] = 0.0
+    depth[200, 150] = np.nan
+    rng = np.random.default_rng(0)
+    x1 = rng.uniform(-5, 150, 40); y1 = rng.uniform(-5, 200, 40)
+    boxes = np.stack([x1, y1, x1 + rng.uniform(1, 60, 40), y1 + rng.uniform(1, 70, 40)], 1).astype(np.float32)
+    boxes[0] = [10.2, 10.9, 150.7, 200.1]                     # two corners on invalid pixels
+    boxes[1] = [-20.0, -3.0, 500.0, 900.0]                    # clamped into the image
+    oc, ov = orc.lift_boxes_oracle(boxes, depth, K, T, 1000.0)
+    corners, valid = engine.lift_boxes(boxes, K, T, depth, 1000.0)
+    assert np.array_equal(valid, ov) and not valid[0, 0] and not valid[0, 2]
+    assert np.allclose(corners[valid], oc[ov], atol=1e-9) and np.isnan(corners[~valid]).all()
+    c2, v2 = engine.lift_boxes(boxes, K, T, None, 1000.0)     # reuse the uploaded frame
+    assert np.array_equal(np.nan_to_num(c2), np.nan_to_num(corners)) and np.array_equal(v2, valid)
+    # uint16 depth and the per-frame helper mirroring pose_processor._3d_processing
+    d16 = np.clip(np.round(np.nan_to_num(depth)), 0, 65535).astype(np.uint16)
+    intr = {"image_width": 1920, "image_height": 2560, "fx": 1500.0, "fy": 1500.0, "cx": 955.0, "cy": 1275.0}
+    pose = [1.0, 0.5, 1.2, 0.0, 0.0, 0.38268343, 0.92387953]
+    dets = [[400.0, 500.0, 900.0, 1500.0, 2, 0.9, "exit"], [1000.0, 100.0, 1500.0, 700.0, 0, 0.5, "fire"]]
+    rows = lifting.lift_frame_bboxes(engine, dets, d16, intr, pose, 192, 256)
+    assert len(rows) == 2 and rows[0][4:] == [2, 0.9, "exit"] and len(rows[0]) == 7   # pose_processor.py:208
+    Kd = lifting.rescaled_intrinsics(intr, 192)
+    sb = np.array([lifting.scale_bounding_box(d[:4], (1920, 2560), (192, 256)) for d in dets])
+    oc, _ = orc.lift_boxes_oracle(sb, d16, Kd, syn.pose_to_matrix(pose), 1000.0)
+    assert np.allclose(np.array(rows[0][:4]), oc[0], atol=1e-9) and np.allclose(np.array(rows[1][:4]), oc[1], atol=1e-9)
+    with pytest.raises(mapalign.MapAlignError):
+        mapalign.MapAligner(0).lift_boxes(boxes, K, T, None)   # no frame uploaded yet

@@ -112,3 +112,14 @@ def test_coarse_candidates_contain_the_true_rotation():
     cands = coarse.candidate_rotations(ag, ac)
     assert all(abs(np.linalg.det(R) - 1) < 1e-9 for R in cands)
     assert min(np.linalg.norm(R - R_true) for R in cands) < 1e-3
+
+
+def test_detector_row_schema_helpers():
+    from mapalign import lifting
+    row = lifting.parse_yolo_label_line("3 0.5 0.5 0.25 0.5 0.87", 640, 480)
+    assert row == [240.0, 120.0, 400.0, 360.0, 0.87, 3]              # detector.py:155
+    assert lifting.insert_damage_class(row, 2) == [240.0, 120.0, 400.0, 360.0, 2, 0.87, 3]   # detector.py:126-127
+    assert lifting.scale_bounding_box([100, 50, 300, 200], (1000, 500), (100, 50)) == [10.0, 5.0, 30.0, 20.0]
+    K = lifting.rescaled_intrinsics({"image_width": 1920, "image_height": 1440, "fx": 1500.0, "fy": 1500.0,
+                                     "cx": 960.0, "cy": 720.0}, 192)
+    assert np.allclose(K, (150.0, 150.0, 96.0, 72.0))                 # pose_processor.py:133-137
