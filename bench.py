@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--mode", choices=["pairs", "sharded"], default="pairs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    # rehearsal on a one-GPU box only: several ranks share device 0 and rendezvous over gloo
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--force-device", type=int, default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -107,15 +110,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    if args.force_device is not None:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":      # RCCL
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     # ---- inputs: resident in HBM before the timed region --------------------------------
@@ -217,7 +227,7 @@ def main():
             line["speedup_vs_cpu_baseline"] = value / cpu["value"]
     eng.close()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
     if line is not None:
         print(json.dumps(line), flush=True)
