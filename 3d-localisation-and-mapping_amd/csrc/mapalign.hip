@@ -490,284 +490,6 @@ __device__ __forceinline__ void nn_find(const float px, const float py, const fl
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// LDS-tiled search: the workgroup's 256 (cell-sorted, hence neighbouring) queries share one
-// block of the level-0 grid
-// ---------------------------------------------------------------------------------------
-// Every lane knows an upper bound r of its neighbour distance before the search starts (the
-// remembered match, or the gate).  The union of the lanes' spheres, in cells, is the tile:
-// its table rows and its points are copied ONCE per workgroup with fully coalesced reads
-// (a row segment of the table and the points of a row segment are both contiguous), after
-// which all per-lane random access — the part that saturates the texture addresser when it
-// goes to global memory — is served by LDS.  A tile that would not fit (a workgroup that
-// straddles two rows of the source sort, a first iteration with the full gate as radius on
-// a dense map) falls back to the global-memory search for that workgroup only.
-#ifndef MA_TILE
-#define MA_TILE 0   // measured slower than the global path on MI355X: kept for A/B
-#endif
-constexpr int kTileRows = 128;    // (y,z) rows per tile
-constexpr int kTileWords = 3072;  // 16-bit table entries (row-relative point offsets)
-constexpr int kTilePts = 1536;    // staged float4 points
-
-struct TileShared {
-  float4 pts[kTilePts];            // 24 KB: xyz + position in gold[0]
-  uint16_t tab[kTileWords];        // 6 KB : cstart[row + x] - cstart[row + xlo]
-  uint32_t rowbase[kTileRows];     // cstart[row + xlo]
-  uint32_t rowoff[kTileRows + 1];  // offset of the row's points in pts
-  int wave_box[kBlock / kWave][8];
-  int info[8];                     // xlo, ylo, zlo, tw, ty, feasible, nrows, -
-};
-enum { TI_XLO = 0, TI_YLO, TI_ZLO, TI_TW, TI_TY, TI_OK, TI_NROWS };
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_min_step(int v) {
-  return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false));
-}
-// minimum over the wavefront, valid in lane 63
-__device__ __forceinline__ int wave_min_i32(int v) {
-  v = dpp_min_step<0x111, 0xF>(v);
-  v = dpp_min_step<0x112, 0xF>(v);
-  v = dpp_min_step<0x114, 0xF>(v);
-  v = dpp_min_step<0x118, 0xF>(v);
-  v = dpp_min_step<0x142, 0xA>(v);
-  v = dpp_min_step<0x143, 0xC>(v);
-  return v;
-}
-
-// a-th element of the centre-out enumeration c, c-1, c+1, c-2, ... of the range [lo, hi]
-// (once one side is exhausted the other continues); a = 0 .. hi-lo
-__device__ __forceinline__ int centre_out(int a, int c, int lo, int hi) {
-  const int L = c - lo, R = hi - c, m = min(L, R);
-  if (a <= 2 * m) return c + ((a & 1) ? -((a + 1) >> 1) : (a >> 1));
-  return L < R ? c + (a - m) : c - (a - m);
-}
-
-#ifndef MA_Q
-#define MA_Q 1
-#endif
-constexpr int kQ = MA_Q;   // source points per thread (tile staging and the fp64 reduction are per workgroup)
-
-struct CellRange { int x0, x1, y0, y1, z0, z1; bool ok; };
-
-// cells the sphere (centre p, squared radius r2) reaches, clipped to the level-0 grid
-__device__ __forceinline__ CellRange sphere_cells(const float px, const float py, const float pz,
-                                                  const float r2, const LevelSet& S) {
-  const float inv_c = S.inv_c[0];
-  const int nx = S.nx[0], ny = S.ny[0], nz = S.nz[0];
-  const float r = fast_sqrt(r2) + S.delta;
-  CellRange R;
-  R.x0 = max((int)fmaxf(floorf((px - r - S.ox) * inv_c), -1.f), 0);
-  R.x1 = min((int)fminf(floorf((px + r - S.ox) * inv_c), (float)nx), nx - 1);
-  R.y0 = max((int)fmaxf(floorf((py - r - S.oy) * inv_c), -1.f), 0);
-  R.y1 = min((int)fminf(floorf((py + r - S.oy) * inv_c), (float)ny), ny - 1);
-  R.z0 = max((int)fmaxf(floorf((pz - r - S.oz) * inv_c), -1.f), 0);
-  R.z1 = min((int)fminf(floorf((pz + r - S.oz) * inv_c), (float)nz), nz - 1);
-  R.ok = R.x0 <= R.x1 && R.y0 <= R.y1 && R.z0 <= R.z1;  // else: the sphere misses the grid
-  return R;
-}
-
-// Returns true if the workgroup was served by the tile (all queries done, exact); false if
-// the caller must run the global-memory search.  Must be called by all 256 threads.
-template <bool COUNT>
-__device__ __forceinline__ bool tile_search(TileShared& T, const bool (&has)[kQ], const float (&px)[kQ],
-                                            const float (&py)[kQ], const float (&pz)[kQ],
-                                            const LevelSet& S, float (&best2)[kQ], uint32_t (&bestj)[kQ],
-                                            uint32_t& nrows, uint32_t& ncand) {
-  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-  const float c = S.c[0], inv_c = S.inv_c[0];
-  const int nx = S.nx[0], ny = S.ny[0];
-  const float4* __restrict__ gold0 = S.gold[0];
-  const uint32_t* __restrict__ cs0 = S.cs[0];
-
-  // ---- union of the lane's spheres, in cells
-  const int big = 0x3FFFFFFF;
-  bool bad = false;
-  int b0 = big, b1 = big, b2 = big, b3 = big, b4 = big, b5 = big;
-#pragma unroll
-  for (int q = 0; q < kQ; ++q) {
-    if (has[q] && isfinite(px[q]) && isfinite(py[q]) && isfinite(pz[q])) {
-      if (!isfinite(best2[q])) {
-        bad = true;  // no radius known (ungated, nothing remembered): cannot bound a tile
-      } else {
-        const CellRange R = sphere_cells(px[q], py[q], pz[q], best2[q], S);
-        if (R.ok) {
-          b0 = min(b0, R.x0); b1 = min(b1, R.y0); b2 = min(b2, R.z0);
-          b3 = min(b3, -R.x1); b4 = min(b4, -R.y1); b5 = min(b5, -R.z1);
-        }
-      }
-    }
-  }
-  const int m0 = wave_min_i32(b0), m1 = wave_min_i32(b1), m2 = wave_min_i32(b2);
-  const int m3 = wave_min_i32(b3), m4 = wave_min_i32(b4), m5 = wave_min_i32(b5);
-  const int m6 = wave_min_i32(bad ? 0 : 1);
-  if (lane == kWave - 1) {
-    T.wave_box[wv][0] = m0; T.wave_box[wv][1] = m1; T.wave_box[wv][2] = m2; T.wave_box[wv][3] = m3;
-    T.wave_box[wv][4] = m4; T.wave_box[wv][5] = m5; T.wave_box[wv][6] = m6;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int b[7];
-    for (int k = 0; k < 7; ++k) {
-      int v = T.wave_box[0][k];
-      for (int w = 1; w < kBlock / kWave; ++w) v = min(v, T.wave_box[w][k]);
-      b[k] = v;
-    }
-    int ok = b[6] != 0;
-    int tw = 0, ty = 0, tz = 0;
-    if (b[0] == big) {
-      ok = ok ? 2 : 0;  // nobody needs anything: trivially served
-    } else {
-      tw = (-b[3]) - b[0] + 2;  // cells + 1 table entries per row
-      ty = (-b[4]) - b[1] + 1;
-      tz = (-b[5]) - b[2] + 1;
-      if (ty * tz > kTileRows || ty * tz * tw > kTileWords || tw > 2 * kWave) ok = 0;
-    }
-    T.info[TI_XLO] = b[0]; T.info[TI_YLO] = b[1]; T.info[TI_ZLO] = b[2];
-    T.info[TI_TW] = tw; T.info[TI_TY] = ty; T.info[TI_NROWS] = ty * tz; T.info[TI_OK] = ok;
-  }
-  __syncthreads();
-  int ok = T.info[TI_OK];
-  if (ok == 0) return false;
-  if (ok == 2) return true;
-  const int xlo = T.info[TI_XLO], ylo = T.info[TI_YLO], zlo = T.info[TI_ZLO];
-  const int tw = T.info[TI_TW], ty = T.info[TI_TY], nrow = T.info[TI_NROWS];
-
-  // ---- stage the table: wavefront w takes rows w, w+4, ...; lane k reads entry k of the row
-  // (coalesced).  Eight rows per trip, all eight loads issued before the first use, so a
-  // trip costs one memory round trip; no integer division anywhere (row -> (y,z) is kept
-  // incrementally).
-  {
-    constexpr int kNW = kBlock / kWave, kRowsPerTrip = 8;
-    int yi = wv % ty, zi = wv / ty;       // wave-uniform: scalar unit
-    for (int r0 = wv; r0 < nrow; r0 += kNW * kRowsPerTrip) {
-      uint32_t word[kRowsPerTrip][2];
-      int yy = yi, zz = zi;
-#pragma unroll
-      for (int u = 0; u < kRowsPerTrip; ++u) {
-        const int r = r0 + u * kNW;
-        word[u][0] = word[u][1] = 0u;
-        if (r < nrow) {
-          const uint32_t base = (uint32_t)(((zlo + zz) * ny + (ylo + yy)) * nx + xlo);
-          if (lane < tw) word[u][0] = ld_cell(cs0, base + (uint32_t)lane);
-          if (lane + kWave < tw) word[u][1] = ld_cell(cs0, base + (uint32_t)(lane + kWave));
-        }
-        yy += kNW;
-        while (yy >= ty) { yy -= ty; ++zz; }
-      }
-#pragma unroll
-      for (int u = 0; u < kRowsPerTrip; ++u) {
-        const int r = r0 + u * kNW;
-        if (r < nrow) {
-          const uint32_t first = __shfl(word[u][0], 0, kWave);
-          if (lane < tw) T.tab[r * tw + lane] = (uint16_t)(word[u][0] - first);
-          if (lane + kWave < tw) T.tab[r * tw + lane + kWave] = (uint16_t)(word[u][1] - first);
-          const int kl = tw - 1;   // last entry: cstart[row + xhi + 1]
-          const uint32_t last = __shfl(kl < kWave ? word[u][0] : word[u][1], kl & (kWave - 1), kWave);
-          if (lane == 0) {
-            T.rowoff[r] = last - first;   // the row's point count, scanned below
-            T.rowbase[r] = first;
-            if (last - first > 0xFFFFu) T.info[TI_OK] = 0;  // 16-bit offsets would overflow
-          }
-        }
-      }
-      yi = yy; zi = zz;
-    }
-  }
-  __syncthreads();
-  // ---- exclusive scan of the row counts (wavefront 0, two rows per lane)
-  if (wv == 0) {
-    const int r0 = 2 * lane, r1 = 2 * lane + 1;
-    const uint32_t c0 = r0 < nrow ? T.rowoff[r0] : 0u, c1 = r1 < nrow ? T.rowoff[r1] : 0u;
-    uint32_t incl = c0 + c1;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const uint32_t u = __shfl_up(incl, off, kWave);
-      if (lane >= off) incl += u;
-    }
-    const uint32_t excl = incl - (c0 + c1);
-    if (r0 < nrow) T.rowoff[r0] = excl;
-    if (r1 < nrow) T.rowoff[r1] = excl + c0;
-    if (lane == kWave - 1) {
-      T.rowoff[nrow] = incl;   // kTileRows <= 2 * kWave, so every row is covered
-      if (incl > (uint32_t)kTilePts) T.info[TI_OK] = 0;
-    }
-  }
-  __syncthreads();
-  if (T.info[TI_OK] == 0) return false;
-
-  // ---- stage the points: flat point index -> row by binary search in rowoff (LDS); the
-  // points of a row segment are contiguous in gold[0], so consecutive threads read
-  // consecutive addresses, and a thread's up to 6 loads are all in flight together
-  const uint32_t npts = T.rowoff[nrow];
-  constexpr int kPtsPerThread = (kTilePts + kBlock - 1) / kBlock;
-  {
-    float4 q[kPtsPerThread];
-#pragma unroll
-    for (int u = 0; u < kPtsPerThread; ++u) {
-      const uint32_t f = threadIdx.x + (uint32_t)u * kBlock;
-      if (f < npts) {
-        int lo = 0, hi = nrow;          // invariant: rowoff[lo] <= f < rowoff[hi]
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (T.rowoff[mid] <= f) lo = mid; else hi = mid;
-        }
-        q[u] = ld_point(gold0, T.rowbase[lo] + (f - T.rowoff[lo]));
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kPtsPerThread; ++u) {
-      const uint32_t f = threadIdx.x + (uint32_t)u * kBlock;
-      if (f < npts) T.pts[f] = q[u];
-    }
-  }
-  if (COUNT && threadIdx.x == 0) { nrows += (uint32_t)(nrow * tw); ncand += npts; }
-  __syncthreads();
-
-  // ---- per-lane exact search inside the tile (rows of the query's own range, centre first)
-#pragma unroll
-  for (int q = 0; q < kQ; ++q) {
-    if (!(has[q] && isfinite(px[q]) && isfinite(py[q]) && isfinite(pz[q]))) continue;
-    const float qx = px[q], qy = py[q], qz = pz[q];
-    float bb = best2[q];
-    uint32_t bj = bestj[q];
-    const CellRange R = sphere_cells(qx, qy, qz, bb, S);
-    if (R.ok) {
-      const int ccy = min(max((int)floorf((qy - S.oy) * inv_c), R.y0), R.y1);
-      const int ccz = min(max((int)floorf((qz - S.oz) * inv_c), R.z0), R.z1);
-      const int nyr = R.y1 - R.y0 + 1, nzr = R.z1 - R.z0 + 1;
-      for (int a = 0; a < nzr; ++a) {
-        const int z = centre_out(a, ccz, R.z0, R.z1);
-        const float zlo_f = S.oz + (float)z * c;
-        const float dzq = fmaxf(0.f, fmaxf(zlo_f - S.delta - qz, qz - (zlo_f + c + S.delta)));
-        if (dzq * dzq >= bb) continue;
-        for (int bq = 0; bq < nyr; ++bq) {
-          const int y = centre_out(bq, ccy, R.y0, R.y1);
-          const float ylo_f = S.oy + (float)y * c;
-          const float dyq = fmaxf(0.f, fmaxf(ylo_f - S.delta - qy, qy - (ylo_f + c + S.delta)));
-          const float d2yz = dyq * dyq + dzq * dzq;
-          if (d2yz >= bb) continue;
-          const float rx = fast_sqrt(bb - d2yz) + S.delta;
-          const int x0 = max((int)fmaxf(floorf((qx - rx - S.ox) * inv_c), -1.f), R.x0);
-          const int x1 = min((int)fminf(floorf((qx + rx - S.ox) * inv_c), (float)nx), R.x1);
-          if (x0 > x1) continue;
-          const int r = (z - zlo) * ty + (y - ylo);
-          const uint32_t off = T.rowoff[r];
-          const uint32_t ja = off + T.tab[r * tw + (x0 - xlo)], jb = off + T.tab[r * tw + (x1 + 1 - xlo)];
-          for (uint32_t j = ja; j < jb; ++j) {
-            const float4 g = T.pts[j];
-            const float dx = qx - g.x, dy = qy - g.y, dz = qz - g.z;
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 < bb) { bb = d2; bj = __float_as_uint(g.w); }
-          }
-        }
-      }
-    }
-    best2[q] = bb;
-    bestj[q] = bj;
-  }
-  return true;
-}
-
 // XCD-aware chunk order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
 // and b+8 share an L2.  Chunk (b%8)*(G/8) + b/8 gives every XCD one contiguous eighth of
 // the (cell-sorted) source cloud, i.e. one slab of the gold grid in its private L2.
@@ -775,11 +497,10 @@ __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t G) {
   return (G % 8u == 0u) ? (b % 8u) * (G / 8u) + b / 8u : b;
 }
 
-// a4 + a5 fused.  MODE 0: accumulate only; MODE 1: also write per-point (idx, d2).
-// kQ source points per thread (point base + q*256 + tid: coalesced).  Their loads are
-// batched, the LDS tile is staged once for all kQ*256 points of the workgroup, and the 17
-// fp64 accumulators are carried over the kQ points so that the wavefront/workgroup
-// reduction is paid once per kQ*256 points.
+// a4 + a5 fused.  MODE 0: accumulate only; MODE 1: per-point (idx, d2) only (ma_nn).
+// One source point per thread: many short-lived wavefronts hide the search's memory latency
+// best (2 and 4 points per thread measured 25-70 % slower), and the 17 fp64 accumulator terms
+// are formed only after the search, so they hold no registers during it.
 template <bool COUNT, int MODE>
 __global__ __launch_bounds__(kBlock) void k_nn_accum(
     const float4* __restrict__ src, const uint32_t n, const LevelSet S,
@@ -788,103 +509,54 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
     float* __restrict__ nn_d2) {
   if (MODE == 0 && st->done) return;
   const uint32_t G = gridDim.x;
-  const uint32_t base = xcd_chunk(blockIdx.x, G) * (uint32_t)(kBlock * kQ) + threadIdx.x;
-
-  bool has[kQ];
-  float4 s[kQ];
-  uint32_t pj[kQ];
-#pragma unroll
-  for (int q = 0; q < kQ; ++q) {
-    const uint32_t i = base + (uint32_t)q * kBlock;
-    has[q] = i < n;
-    s[q] = has[q] ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    pj[q] = (has[q] && prev) ? prev[i] : kNoMatch;
-  }
-  float px[kQ], py[kQ], pz[kQ], best2[kQ];
-  uint32_t bestj[kQ], nrows = 0, ncand = 0;
-#pragma unroll
-  for (int q = 0; q < kQ; ++q) {
-    px[q] = (float)(st->R[0] * s[q].x + st->R[1] * s[q].y + st->R[2] * s[q].z + st->t[0]);
-    py[q] = (float)(st->R[3] * s[q].x + st->R[4] * s[q].y + st->R[5] * s[q].z + st->t[1]);
-    pz[q] = (float)(st->R[6] * s[q].x + st->R[7] * s[q].y + st->R[8] * s[q].z + st->t[2]);
-    best2[q] = best2_init;
-    bestj[q] = kNoMatch;
-  }
-  // temporal coherence: last iteration's match bounds the search radius from the start
-  {
-    float4 cnd[kQ];
-#pragma unroll
-    for (int q = 0; q < kQ; ++q)
-      cnd[q] = pj[q] != kNoMatch ? ld_point(S.gold[0], pj[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int q = 0; q < kQ; ++q) {
-      if (pj[q] != kNoMatch) {
-        const float dx = px[q] - cnd[q].x, dy = py[q] - cnd[q].y, dz = pz[q] - cnd[q].z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        if (COUNT) ncand += 1u;
-        if (d2 < best2[q]) { best2[q] = d2; bestj[q] = pj[q]; }
-      }
-    }
-  }
-#if MA_TILE
-  __shared__ TileShared tile;
-  const bool served = tile_search<COUNT>(tile, has, px, py, pz, S, best2, bestj, nrows, ncand);
-#else
-  const bool served = false;
-#endif
-  if (!served) {
-#pragma unroll 1
-    for (int q = 0; q < kQ; ++q) {
-      // (rolled: one copy of the global search; q-indexed state goes through selects)
-      float bx = 0.f, by = 0.f, bz = 0.f, bb = 0.f;
-      uint32_t bj = kNoMatch;
-      bool h = false;
-#pragma unroll
-      for (int t = 0; t < kQ; ++t)
-        if (t == q) { bx = px[t]; by = py[t]; bz = pz[t]; bb = best2[t]; bj = bestj[t]; h = has[t]; }
-      if (h) nn_find<COUNT>(bx, by, bz, S, bb, bj, nrows, ncand);
-#pragma unroll
-      for (int t = 0; t < kQ; ++t)
-        if (t == q) { best2[t] = bb; bestj[t] = bj; }
-    }
-  }
+  const uint32_t i = xcd_chunk(blockIdx.x, G) * kBlock + threadIdx.x;
 
   double acc[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
-  {
-    float4 win[kQ];
-#pragma unroll
-    for (int q = 0; q < kQ; ++q)   // the winners' coordinates (level 0 holds every point)
-      win[q] = bestj[q] != kNoMatch ? ld_point(S.gold[0], bestj[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int q = 0; q < kQ; ++q) {
-      const uint32_t i = base + (uint32_t)q * kBlock;
-      if (!has[q]) continue;
-      if (prev) prev[i] = bestj[q];
-      if (MODE == 1) {
-        nn_idx[i] = bestj[q] != kNoMatch ? perm0[bestj[q]] : kNoMatch;
-        nn_d2[i] = bestj[q] != kNoMatch ? best2[q] : INFINITY;
-      }
-      if (bestj[q] != kNoMatch) {
-        const double Px = st->R[0] * s[q].x + st->R[1] * s[q].y + st->R[2] * s[q].z + st->t[0];
-        const double Py = st->R[3] * s[q].x + st->R[4] * s[q].y + st->R[5] * s[q].z + st->t[1];
-        const double Pz = st->R[6] * s[q].x + st->R[7] * s[q].y + st->R[8] * s[q].z + st->t[2];
-        const double w = (double)s[q].w;
-        const double qx = win[q].x, qy = win[q].y, qz = win[q].z;
-        const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
-        const double wPx = w * Px, wPy = w * Py, wPz = w * Pz;
-        acc[0] += w;
-        acc[1] += wPx; acc[2] += wPy; acc[3] += wPz;
-        acc[4] += w * qx; acc[5] += w * qy; acc[6] += w * qz;
-        acc[7] += wPx * qx;  acc[8] += wPx * qy;  acc[9] += wPx * qz;
-        acc[10] += wPy * qx; acc[11] += wPy * qy; acc[12] += wPy * qz;
-        acc[13] += wPz * qx; acc[14] += wPz * qy; acc[15] += wPz * qz;
-        acc[16] += w * (dx * dx + dy * dy + dz * dz);
+
+  if (i < n) {
+    const float4 s = src[i];
+    const double Px = st->R[0] * s.x + st->R[1] * s.y + st->R[2] * s.z + st->t[0];
+    const double Py = st->R[3] * s.x + st->R[4] * s.y + st->R[5] * s.z + st->t[1];
+    const double Pz = st->R[6] * s.x + st->R[7] * s.y + st->R[8] * s.z + st->t[2];
+    const float px = (float)Px, py = (float)Py, pz = (float)Pz;
+    float best2 = best2_init;
+    uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
+    if (prev) {
+      // temporal coherence: last iteration's match bounds the search radius from the start
+      const uint32_t pj = prev[i];
+      if (pj != kNoMatch) {
+        const float4 c = ld_point(S.gold[0], pj);
+        const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (COUNT) ncand += 1u;
+        if (d2 < best2) { best2 = d2; bestj = pj; }
       }
     }
+    nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
+    if (prev) prev[i] = bestj;
+    if (MODE == 1) {
+      nn_idx[i] = bestj != kNoMatch ? perm0[bestj] : kNoMatch;
+      nn_d2[i] = bestj != kNoMatch ? best2 : INFINITY;
+    }
+    if (MODE == 0 && bestj != kNoMatch) {
+      const float4 q = ld_point(S.gold[0], bestj);   // the winner's coordinates (level 0 holds every point)
+      const double w = (double)s.w;
+      const double qx = q.x, qy = q.y, qz = q.z;
+      const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
+      const double wPx = w * Px, wPy = w * Py, wPz = w * Pz;
+      acc[0] = w;
+      acc[1] = wPx; acc[2] = wPy; acc[3] = wPz;
+      acc[4] = w * qx; acc[5] = w * qy; acc[6] = w * qz;
+      acc[7] = wPx * qx;  acc[8] = wPx * qy;  acc[9] = wPx * qz;
+      acc[10] = wPy * qx; acc[11] = wPy * qy; acc[12] = wPy * qz;
+      acc[13] = wPz * qx; acc[14] = wPz * qy; acc[15] = wPz * qz;
+      acc[16] = w * (dx * dx + dy * dy + dz * dz);
+    }
+    if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
   }
-  if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
+  if (MODE == 1) return;  // ma_nn: per-point outputs only
 
   // wavefront DPP sums, then a fixed-order sum over the 4 wavefronts.  Without work
   // counting only the 17 real accumulators take part (the two counter slots stay zero).
@@ -1333,9 +1005,9 @@ int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, 
   return MA_OK;
 }
 
-// kQ source points per thread; G a multiple of 8 so that the XCD remap is a bijection
+// one source point per thread; G a multiple of 8 so that the XCD remap is a bijection
 uint32_t grid_for(uint32_t n) {
-  const uint32_t G = div_up(n, (uint64_t)kBlock * kQ);
+  const uint32_t G = div_up(n, kBlock);
   return std::max<uint32_t>(8, (G + 7u) / 8u * 8u);
 }
 
