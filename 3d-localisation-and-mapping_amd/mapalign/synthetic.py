@@ -172,9 +172,9 @@ def render_depth(rects, T_cam_to_world, width, height, fx, fy, cx, cy, *, chunk=
             denom = d @ nrm
             with np.errstate(divide="ignore", invalid="ignore"):
                 lam = ((o - tcw) @ nrm) / denom
-            hit = tcw + lam[:, None] * d - o
-            a = (hit @ u) / (u @ u)
-            b = (hit @ v) / (v @ v)
+                hit = tcw + lam[:, None] * d - o
+                a = (hit @ u) / (u @ u)
+                b = (hit @ v) / (v @ v)
             ok = (np.abs(denom) > 1e-12) & (lam > 1e-3) & (lam < max_range) \
                 & (a >= 0) & (a <= 1) & (b >= 0) & (b <= 1)
             best = np.where(ok & (lam < best), lam, best)

@@ -518,3 +518,30 @@ def test_lift_boxes_vs_oracle_and_frame_helper(engine):
     assert np.allclose(np.array(rows[0][:4]), oc[0], atol=1e-9) and np.allclose(np.array(rows[1][:4]), oc[1], atol=1e-9)
     with pytest.raises(mapalign.MapAlignError):
         mapalign.MapAligner(0).lift_boxes(boxes, K, T, None)   # no frame uploaded yet
+
+
+# ----------------------------------------------------------------------------- config C3 at full size
+def test_config3_full_size_depth_frame_against_1m_gold(engine):
+    """BASELINE configs[2]: 1280x960 depth image -> fused unprojection -> alignment against a
+    1M-point gold map.  Unprojection: exact pixel count + coordinates vs the oracle; alignment:
+    a perturbed camera pose is recovered, and 5 iterations match the oracle's 5."""
+    depth, K, T = syn.make_depth_frame(0)                     # 1280 x 960, fx = fy = 1000
+    gold, _, _, _ = syn.make_pair(0, 1_000_000)
+    engine.set_gold(gold)
+    dT = np.eye(4)
+    dT[:3, :3] = syn.rotation_about_axis([0.1, 0.9, 0.2], np.deg2rad(0.4))
+    dT[:3, 3] = [0.025, -0.015, 0.02]
+    n = engine.set_source_from_depth(depth, K, dT @ T, 1000.0)
+    opts, mask = orc.unproject_oracle(depth, K, dT @ T, 1000.0)
+    assert n == int(mask.sum()) and n > 1_100_000
+    pts = engine.get_source()
+    assert np.abs(pts.astype(np.float64) - opts).max() <= 8e-6      # camera sees up to ~18 m: 2 ulp fp32
+    res5 = engine.icp(5, 0.0, 0.10)
+    ref5 = orc.icp_oracle(gold, pts, max_iter=5, max_corr_dist=0.10, n_jobs=-1)
+    eR, et = orc.rt_error(res5.R, res5.t, ref5["R"], ref5["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    assert abs(res5.inliers - ref5["inliers"]) <= 4
+    res = engine.icp(50, 0.0, 0.10)
+    # the frame samples the gold surfaces (analytic render, no jitter): the perturbation is undone
+    err = np.linalg.inv(dT) @ np.linalg.inv(res.T)            # should be ~identity
+    assert np.linalg.norm(err[:3, :3] - np.eye(3)) <= 2e-3 and np.linalg.norm(err[:3, 3]) <= 1e-2
