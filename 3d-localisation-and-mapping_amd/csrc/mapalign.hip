@@ -155,7 +155,12 @@ __global__ __launch_bounds__(kBlock) void k_minmax(const float* __restrict__ xyz
 
 // key = cell id, val = original index; also the per-cell histogram (integer atomics:
 // the counts are order-independent, hence deterministic).
-// brick != 0: the key is brick-major — 8 x 8 x 8-cell bricks in x-fastest order, cells
+#ifndef MA_BRICK_SHIFT
+#define MA_BRICK_SHIFT 4
+#endif
+constexpr uint32_t kBrickShift = MA_BRICK_SHIFT;   // bricks of 2^shift cells per axis
+
+// brick != 0: the key is brick-major — 16 x 16 x 16-cell bricks in x-fastest order, cells
 // x-fastest inside a brick — so that 256 consecutive points of the sorted SOURCE cloud form
 // a compact patch (small LDS tile) instead of a 2 m long line of cells.
 __global__ __launch_bounds__(kBlock) void k_cell_keys(const float* __restrict__ xyz, uint32_t n,
@@ -170,9 +175,10 @@ __global__ __launch_bounds__(kBlock) void k_cell_keys(const float* __restrict__ 
   const float z = (float)((double)xyz[3 * (size_t)i + 2] - o2);
   uint32_t c = cell_of(x, y, z, g);
   if (brick) {
+    constexpr uint32_t B = kBrickShift, M = (1u << B) - 1u;
     const uint32_t ix = c % (uint32_t)g.nx, iy = (c / (uint32_t)g.nx) % (uint32_t)g.ny, iz = c / ((uint32_t)g.nx * g.ny);
-    const uint32_t nbx = ((uint32_t)g.nx + 7u) >> 3, nby = ((uint32_t)g.ny + 7u) >> 3;
-    c = ((((iz >> 3) * nby + (iy >> 3)) * nbx + (ix >> 3)) << 9) | ((iz & 7u) << 6) | ((iy & 7u) << 3) | (ix & 7u);
+    const uint32_t nbx = ((uint32_t)g.nx + M) >> B, nby = ((uint32_t)g.ny + M) >> B;
+    c = ((((iz >> B) * nby + (iy >> B)) * nbx + (ix >> B)) << (3 * B)) | ((iz & M) << (2 * B)) | ((iy & M) << B) | (ix & M);
   }
   keys[i] = c;
   vals[i] = i;
@@ -302,20 +308,22 @@ __device__ __forceinline__ u4_unaligned ld_cell4(const uint32_t* __restrict__ ba
   return *reinterpret_cast<const u4_unaligned*>(reinterpret_cast<const char*>(base) + (c << 2));
 }
 
-// Two candidates per trip: the run is contiguous, so both loads are in flight together.
+// Four candidates per trip: the run is contiguous, so the four loads are in flight together
+// (indices past the end are clamped to the last point: a duplicate changes nothing).
 // Only (distance, position) of the winner are tracked; its coordinates are re-read once.
 __device__ __forceinline__ void scan_run(const float px, const float py, const float pz,
                                          const float4* __restrict__ gold, const uint32_t a,
                                          const uint32_t b, float& best2, uint32_t& bestj) {
-  for (uint32_t j = a; j < b; j += 2u) {
-    const float4 q0 = ld_point(gold, j);
-    const float4 q1 = ld_point(gold, min(j + 1u, b - 1u));
-    const float dx0 = px - q0.x, dy0 = py - q0.y, dz0 = pz - q0.z;
-    const float dx1 = px - q1.x, dy1 = py - q1.y, dz1 = pz - q1.z;
-    const float d0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
-    const float d1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
-    if (d0 < best2) { best2 = d0; bestj = __float_as_uint(q0.w); }
-    if (d1 < best2) { best2 = d1; bestj = __float_as_uint(q1.w); }
+  for (uint32_t j = a; j < b; j += 4u) {
+    float4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = ld_point(gold, min(j + (uint32_t)u, b - 1u));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float dx = px - q[u].x, dy = py - q[u].y, dz = pz - q[u].z;
+      const float d = dx * dx + dy * dy + dz * dz;
+      if (d < best2) { best2 = d; bestj = __float_as_uint(q[u].w); }
+    }
   }
 }
 
@@ -965,7 +973,9 @@ int sort_by_cell(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, co
   hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0],
                      o[1], o[2], g, brick, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), d_counts);
   HIPCHK(hipGetLastError());
-  const uint64_t ncells = brick ? ((uint64_t)((g.nx + 7) >> 3) * ((g.ny + 7) >> 3) * ((g.nz + 7) >> 3)) << 9
+  const int bm = (1 << kBrickShift) - 1;
+  const uint64_t ncells = brick ? ((uint64_t)((g.nx + bm) >> kBrickShift) * ((g.ny + bm) >> kBrickShift) *
+                                   ((g.nz + bm) >> kBrickShift)) << (3 * kBrickShift)
                                 : (uint64_t)g.nx * g.ny * g.nz;
   int bits = 1;
   while (bits < 32 && (1ull << bits) < ncells) ++bits;
@@ -1229,6 +1239,32 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
   }
   c = clamp_cell_to_budget(lo, hi, c, kMaxCells);
   if (!(c > 0.f) || !std::isfinite(c)) return ctx->fail(MA_ERR_INVALID, "could not choose a cell edge");
+
+  // Grid phase: a surface that runs along a cell boundary (walls and floors of man-made
+  // scenes are axis-aligned once the scan is levelled) puts its points into two layers of
+  // cells, and every query near it then needs both.  Per axis, try the grid shifted by
+  // 0, 1/4, 1/2 and 3/4 of a cell and keep the shift with the fewest occupied cells.
+  if (cell <= 0.f) {
+    float best_lo[3] = {lo[0], lo[1], lo[2]};
+    uint64_t best_occ = 0;
+    {
+      const GridP g = make_grid(best_lo, hi, ctx->origin, c);
+      if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g, ctx->origin, &best_occ))) return rc;
+    }
+    for (int a = 0; a < 3; ++a) {
+      const float base = best_lo[a];
+      for (int ph = 1; ph < 4; ++ph) {
+        float trial[3] = {best_lo[0], best_lo[1], best_lo[2]};
+        trial[a] = base - 0.25f * (float)ph * c;
+        const GridP g = make_grid(trial, hi, ctx->origin, c);
+        if ((uint64_t)g.nx * g.ny * g.nz > kMaxCells) continue;
+        uint64_t occ = 0;
+        if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g, ctx->origin, &occ))) return rc;
+        if (occ < best_occ) { best_occ = occ; best_lo[a] = trial[a]; }
+      }
+    }
+    for (int a = 0; a < 3; ++a) lo[a] = best_lo[a];
+  }
 
   // one grid per level: cell edges c, 2c, 4c, 8c over the same box
   DevBuf& hist = ctx->misc;
