@@ -34,11 +34,48 @@ def _f64p(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def _cloud(a, name):
+def _check_cloud(a, name):
     a = np.asarray(a)
     if a.ndim != 2 or a.shape[1] != 3:
         raise ValueError(f"{name} must have shape [N,3], got {a.shape}")
+    return a
+
+
+def _cloud(a, name, shift=None):
+    """[N,3] array-like -> contiguous float32, after subtracting the host-side shift in fp64."""
+    a = _check_cloud(a, name)
+    if shift is not None and np.any(shift != 0.0):
+        a = np.asarray(a, dtype=np.float64) - shift
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# Georeferenced maps (UTM-like coordinates of 1e5..1e7 m) lose centimetres to decimetres when
+# squeezed into fp32.  The device library re-centres internally, but its ABI takes fp32, so the
+# host subtracts an integer-metre shift in fp64 FIRST whenever coordinates exceed this bound,
+# and maps every result back (T_world = S T_local S^-1).
+LARGE_COORDINATE_M = 1000.0
+
+
+def _conj_shift(T_local, shift, inverse=False):
+    """Local-frame 4x4 -> world frame (or back): p_world = p_local + shift."""
+    if T_local is None or not np.any(shift != 0.0):
+        return T_local
+    T = np.array(T_local, dtype=np.float64)
+    R, t = T[:3, :3], T[:3, 3]
+    T[:3, 3] = (t - shift + R @ shift) if inverse else (t + shift - R @ shift)
+    return T
+
+
+def _acc_shift(acc, shift):
+    """17 accumulators from the shifted frame to the world frame (p = p_l + s, q = q_l + s)."""
+    if not np.any(shift != 0.0):
+        return acc
+    a = np.array(acc, dtype=np.float64)
+    W, sp, sq = a[0], a[1:4].copy(), a[4:7].copy()
+    a[1:4] = sp + W * shift
+    a[4:7] = sq + W * shift
+    a[7:16] = (a[7:16].reshape(3, 3) + np.outer(sp, shift) + np.outer(shift, sq) + W * np.outer(shift, shift)).ravel()
+    return a
 
 
 @dataclass
@@ -74,6 +111,7 @@ class MapAligner:
         self.device = int(device)
         self.n_gold = 0
         self.n_source = 0
+        self._shift = np.zeros(3)
 
     # -- lifetime -------------------------------------------------------------------
     def close(self):
@@ -117,7 +155,13 @@ class MapAligner:
 
     # -- clouds ---------------------------------------------------------------------
     def set_gold(self, gold_cloud, cell=0.0):
-        g = _cloud(gold_cloud, "gold_cloud")
+        raw = _check_cloud(gold_cloud, "gold_cloud")
+        self._shift = np.zeros(3)
+        if raw.shape[0] and raw.dtype != np.float32:
+            lo, hi = np.min(raw, axis=0).astype(np.float64), np.max(raw, axis=0).astype(np.float64)
+            if np.all(np.isfinite(lo)) and np.all(np.isfinite(hi)) and max(np.abs(lo).max(), np.abs(hi).max()) > LARGE_COORDINATE_M:
+                self._shift = np.round(0.5 * (lo + hi))
+        g = _cloud(raw, "gold_cloud", self._shift)
         self._chk(self._lib.ma_set_gold(self._ctx, g.ctypes.data_as(C.POINTER(C.c_float)), g.shape[0], float(cell)))
         self.n_gold = g.shape[0]
         self.n_source = 0
@@ -127,11 +171,11 @@ class MapAligner:
         gi = ma_grid_info()
         self._chk(self._lib.ma_grid_info_get(self._ctx, C.byref(gi)))
         return {"cell": float(gi.cell), "dims": (gi.nx, gi.ny, gi.nz), "n_cells": int(gi.n_cells),
-                "n_occupied": int(gi.n_occupied), "origin": np.array(list(gi.origin)),
+                "n_occupied": int(gi.n_occupied), "origin": np.array(list(gi.origin)) + self._shift,
                 "build_ms": float(gi.build_ms)}
 
     def set_source(self, comparison_cloud, weights=None):
-        s = _cloud(comparison_cloud, "comparison_cloud")
+        s = _cloud(comparison_cloud, "comparison_cloud", self._shift)
         w = None
         if weights is not None:
             w = np.ascontiguousarray(weights, dtype=np.float32).reshape(-1)
@@ -154,7 +198,9 @@ class MapAligner:
             dtype = 0
         d = np.ascontiguousarray(d)
         Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
-        T = np.ascontiguousarray(T_cam_to_world, dtype=np.float64).reshape(4, 4)
+        T = np.array(T_cam_to_world, dtype=np.float64).reshape(4, 4)
+        T[:3, 3] -= self._shift
+        T = np.ascontiguousarray(T)
         nv = C.c_uint64(0)
         self._chk(self._lib.ma_set_source_from_depth(
             self._ctx, d.ctypes.data_as(C.c_void_p), dtype, d.shape[1], d.shape[0],
@@ -169,7 +215,9 @@ class MapAligner:
         last set_source_from_depth / lift_boxes call.  Returns (corners f64 [B,4,3], valid bool [B,4])."""
         b = np.ascontiguousarray(boxes_xyxy, dtype=np.float32).reshape(-1, 4)
         Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
-        T = np.ascontiguousarray(T_cam_to_world, dtype=np.float64).reshape(4, 4)
+        T = np.array(T_cam_to_world, dtype=np.float64).reshape(4, 4)
+        T[:3, 3] -= self._shift
+        T = np.ascontiguousarray(T)
         out = np.empty((b.shape[0], 4, 3), dtype=np.float64)
         valid = np.zeros((b.shape[0], 4), dtype=np.uint8)
         dptr, dtype, w, h = None, 0, 0, 0
@@ -183,23 +231,24 @@ class MapAligner:
         self._chk(self._lib.ma_lift_boxes(self._ctx, dptr, dtype, w, h, Kf.ctypes.data_as(C.POINTER(C.c_float)),
                                           _f64p(T), float(depth_scale), b.ctypes.data_as(C.POINTER(C.c_float)),
                                           b.shape[0], _f64p(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
-        return out, valid.astype(bool)
+        return out + self._shift, valid.astype(bool)
 
     def get_source(self):
         n = C.c_uint64(0)
         self._chk(self._lib.ma_get_source(self._ctx, None, C.byref(n)))
         out = np.empty((int(n.value), 3), dtype=np.float32)
         self._chk(self._lib.ma_get_source(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
-        return out
+        return out if not np.any(self._shift != 0.0) else out.astype(np.float64) + self._shift
 
     # -- the loop -------------------------------------------------------------------
     def icp(self, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None, count_work=False, with_trace=False,
             time_kernels=False):
         p = self._params(max_iter, tol, max_corr_dist, count_work, time_kernels)
-        Tin = _as_T(init)
+        Tin = _conj_shift(_as_T(init), self._shift, inverse=True)
         Tout = np.empty((4, 4), dtype=np.float64)
         st = ma_stats()
         self._chk(self._lib.ma_icp(self._ctx, C.byref(p), _f64p(Tin), _f64p(Tout), C.byref(st)))
+        Tout = _conj_shift(Tout, self._shift)
         tr = self.trace(st.iterations) if with_trace else None
         return AlignResult(Tout, int(st.iterations), float(st.rmse), float(st.inliers), bool(st.converged),
                            float(st.gpu_ms), tr)
@@ -213,20 +262,24 @@ class MapAligner:
     def trace(self, max_rows=4096):
         buf = np.zeros((max(int(max_rows), 1), MA_TRACE_STRIDE), dtype=np.float64)
         rows = self._chk(self._lib.ma_get_trace(self._ctx, _f64p(buf), buf.shape[0]))
-        return buf[:rows].copy()
+        out = buf[:rows].copy()
+        if np.any(self._shift != 0.0):
+            for r in out:
+                r[:MA_ACC_LEN] = _acc_shift(r[:MA_ACC_LEN], self._shift)
+        return out
 
     def icp_step(self, T_in=None, max_corr_dist=0.10, count_work=False):
         """One iteration at T_in: (acc17 world-frame, T_next)."""
         p = self._params(1, 0.0, max_corr_dist, count_work)
-        Tin = _as_T(T_in)
+        Tin = _conj_shift(_as_T(T_in), self._shift, inverse=True)
         acc = np.empty(MA_ACC_LEN, dtype=np.float64)
         Tout = np.empty((4, 4), dtype=np.float64)
         self._chk(self._lib.ma_icp_step(self._ctx, C.byref(p), _f64p(Tin), _f64p(acc), _f64p(Tout)))
-        return acc, Tout
+        return _acc_shift(acc, self._shift), _conj_shift(Tout, self._shift)
 
     def nn(self, T=None, max_corr_dist=np.inf):
         """Nearest gold index (original order; 0xFFFFFFFF = none within the gate) and d^2 per source point."""
-        Tin = _as_T(T)
+        Tin = _conj_shift(_as_T(T), self._shift, inverse=True)
         idx = np.empty(self.n_source, dtype=np.uint32)
         d2 = np.empty(self.n_source, dtype=np.float32)
         self._chk(self._lib.ma_nn(self._ctx, _f64p(Tin), float(max_corr_dist),
@@ -236,13 +289,13 @@ class MapAligner:
 
     # -- split stepping (sharded-source multi-GPU mode) -------------------------------
     def state_set(self, T=None):
-        self._chk(self._lib.ma_state_set(self._ctx, _f64p(_as_T(T))))
+        self._chk(self._lib.ma_state_set(self._ctx, _f64p(_conj_shift(_as_T(T), self._shift, inverse=True))))
 
     def state_get(self):
         Tout = np.empty((4, 4), dtype=np.float64)
         st = ma_stats()
         self._chk(self._lib.ma_state_get(self._ctx, _f64p(Tout), C.byref(st)))
-        return Tout, {"iterations": int(st.iterations), "converged": bool(st.converged),
+        return _conj_shift(Tout, self._shift), {"iterations": int(st.iterations), "converged": bool(st.converged),
                       "degenerate": bool(st.degenerate), "rmse": float(st.rmse), "inliers": float(st.inliers)}
 
     def step_accumulate(self, acc_dev_ptr, max_corr_dist=0.10, count_work=False):

@@ -545,3 +545,36 @@ def test_config3_full_size_depth_frame_against_1m_gold(engine):
     # the frame samples the gold surfaces (analytic render, no jitter): the perturbation is undone
     err = np.linalg.inv(dT) @ np.linalg.inv(res.T)            # should be ~identity
     assert np.linalg.norm(err[:3, :3] - np.eye(3)) <= 2e-3 and np.linalg.norm(err[:3, 3]) <= 1e-2
+
+
+def test_georeferenced_coordinates_fp64_inputs(engine):
+    """UTM-like coordinates (1e5..1e7 m) as float64: the host shift keeps millimetre parity
+    (plain fp32 storage would quantise them to 0.03..0.5 m)."""
+    gold, comp, R0, t0 = syn.make_pair(18, 30_000, 25_000)
+    off = np.array([412_345.0, 5_234_567.0, 120.0])
+    gold64, comp64 = gold.astype(np.float64) + off, comp.astype(np.float64) + off
+    gi = engine.set_gold(gold64)
+    engine.set_source(comp64)
+    assert np.abs(gi["origin"] - (off + [10, 1.5, 1.25])).max() < 1.0
+    res = engine.icp(30, 0.0, 0.10, with_trace=True)
+    # oracle on the un-offset clouds, conjugated by the offset (exact algebra).  The fp64 oracle
+    # run directly at 5e6 m is itself only good to ~1e-2: its world-frame cross-covariance
+    # S - W mu mu^T cancels 12 of its 16 digits — which is why the device works in a centred frame.
+    ref = orc.icp_oracle(gold, comp, max_iter=30, max_corr_dist=0.10, n_jobs=8)
+    # t at the world origin has a 5000 km lever arm (1e-10 in R moves it by 0.5 mm), so the
+    # translation is compared where it acts: on the cloud
+    t_ref = ref["t"] + off - ref["R"] @ off
+    assert np.linalg.norm(res.R - ref["R"]) <= R_TOL_FRO
+    moved = comp64[::97] @ res.R.T + res.t
+    moved_ref = comp64[::97] @ ref["R"].T + t_ref
+    assert np.abs(moved - moved_ref).max() <= T_TOL_M * 1e-2
+    assert res.trace[0, 0] == ref["trace"][0]["acc"][0] and abs(res.trace[-1, 17] - ref["rmse"]) < 1e-6
+    # same answer as the un-offset problem, conjugated by the offset
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    loc = engine.icp(30, 0.0, 0.10)
+    assert np.allclose(res.R, loc.R, atol=1e-9)
+    assert np.abs((comp64[::97] @ res.R.T + res.t) - (comp64[::97] @ loc.R.T + loc.t + off - loc.R @ off)).max() <= 1e-5
+    idx64, d264 = (lambda e: (e.set_gold(gold64), e.set_source(comp64), e.nn(res.T, 0.1))[2])(engine)
+    oi, od2 = orc.GoldIndex(gold64, n_jobs=8).query(comp64 @ res.R.T + res.t)
+    assert_nn_matches(idx64, d264, oi, od2, gate=0.1)
