@@ -498,11 +498,20 @@ __device__ __forceinline__ void nn_find(const float px, const float py, const fl
   }
 }
 
-// XCD-aware chunk order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
-// and b+8 share an L2.  Chunk (b%8)*(G/8) + b/8 gives every XCD one contiguous eighth of
-// the (cell-sorted) source cloud, i.e. one slab of the gold grid in its private L2.
+// XCD-aware chunk order: workgroups are dealt round-robin over the 8 XCDs, so workgroups b
+// and b+8 share an L2.  The sorted source cloud is cut into segments of kXcdSeg consecutive
+// chunks and the segments are dealt over the XCDs: every XCD works on contiguous pieces
+// (neighbouring workgroups share gold cells in its private L2) but gets pieces from all
+// over the cloud, so that an expensive region (e.g. a part of the scan the gold map does
+// not cover) is not one XCD's problem alone.
+#ifndef MA_XCD_SEG
+#define MA_XCD_SEG 16
+#endif
 __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t G) {
-  return (G % 8u == 0u) ? (b % 8u) * (G / 8u) + b / 8u : b;
+  constexpr uint32_t S = MA_XCD_SEG;
+  if (G % (8u * S) != 0u) return b;                     // (the host rounds G up to a multiple of 8 * S)
+  const uint32_t xcd = b % 8u, seg = b / 8u;            // seg: index among this XCD's workgroups
+  return ((seg / S) * 8u + xcd) * S + seg % S;
 }
 
 // a4 + a5 fused.  MODE 0: accumulate only; MODE 1: per-point (idx, d2) only (ma_nn).
@@ -1015,10 +1024,10 @@ int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, 
   return MA_OK;
 }
 
-// one source point per thread; G a multiple of 8 so that the XCD remap is a bijection
+// one source point per thread; G a multiple of 8 * MA_XCD_SEG so that the XCD remap is a bijection
 uint32_t grid_for(uint32_t n) {
-  const uint32_t G = div_up(n, kBlock);
-  return std::max<uint32_t>(8, (G + 7u) / 8u * 8u);
+  const uint32_t G = div_up(n, kBlock), q = 8u * MA_XCD_SEG;
+  return std::max<uint32_t>(q, (G + q - 1u) / q * q);
 }
 
 int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
