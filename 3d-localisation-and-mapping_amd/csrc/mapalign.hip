@@ -42,6 +42,10 @@
 namespace {
 
 constexpr int kBlock = 256;           // 4 wavefronts
+#ifndef MA_NN_BLOCK
+#define MA_NN_BLOCK 256
+#endif
+constexpr int kNNBlock = MA_NN_BLOCK;  // workgroup of the search kernel
 constexpr int kWave = 64;
 constexpr int kNAcc = 19;             // 17 accumulators + rows visited + candidates
 constexpr uint64_t kMaxCells = 1ull << 27;
@@ -519,14 +523,14 @@ __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t G) {
 // best (2 and 4 points per thread measured 25-70 % slower), and the 17 fp64 accumulator terms
 // are formed only after the search, so they hold no registers during it.
 template <bool COUNT, int MODE>
-__global__ __launch_bounds__(kBlock) void k_nn_accum(
+__global__ __launch_bounds__(kNNBlock) void k_nn_accum(
     const float4* __restrict__ src, const uint32_t n, const LevelSet S,
     const uint32_t* __restrict__ perm0, const DevState* __restrict__ st, const float best2_init,
     double* __restrict__ partials, uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx,
     float* __restrict__ nn_d2) {
   if (MODE == 0 && st->done) return;
   const uint32_t G = gridDim.x;
-  const uint32_t i = xcd_chunk(blockIdx.x, G) * kBlock + threadIdx.x;
+  const uint32_t i = xcd_chunk(blockIdx.x, G) * kNNBlock + threadIdx.x;
 
   double acc[kNAcc];
 #pragma unroll
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
   // wavefront DPP sums, then a fixed-order sum over the 4 wavefronts.  Without work
   // counting only the 17 real accumulators take part (the two counter slots stay zero).
   constexpr int kLive = COUNT ? kNAcc : ma::kAccLen;
-  __shared__ double red[kBlock / kWave][kNAcc];
+  __shared__ double red[kNNBlock / kWave][kNAcc];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
 #pragma unroll
   for (int k = 0; k < kLive; ++k) {
@@ -588,7 +592,13 @@ __global__ __launch_bounds__(kBlock) void k_nn_accum(
   __syncthreads();
   if (threadIdx.x < kNAcc) {
     const int k = threadIdx.x;
-    partials[(size_t)k * G + blockIdx.x] = k < kLive ? ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k] : 0.0;
+    double v = 0.0;
+    if (k < kLive) {
+      v = red[0][k];
+#pragma unroll
+      for (int w = 1; w < kNNBlock / kWave; ++w) v += red[w][k];
+    }
+    partials[(size_t)k * G + blockIdx.x] = v;
   }
 }
 
@@ -1026,7 +1036,7 @@ int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, 
 
 // one source point per thread; G a multiple of 8 * MA_XCD_SEG so that the XCD remap is a bijection
 uint32_t grid_for(uint32_t n) {
-  const uint32_t G = div_up(n, kBlock), q = 8u * MA_XCD_SEG;
+  const uint32_t G = div_up(n, kNNBlock), q = 8u * MA_XCD_SEG;
   return std::max<uint32_t>(q, (G + q - 1u) / q * q);
 }
 
@@ -1064,7 +1074,7 @@ int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float
   const uint32_t G = grid_for(ctx->n);
   ctx->last_G = (int)G;
   auto args = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(G), dim3(kBlock), 0, ctx->stream, ctx->src.as<float4>(), ctx->n,
+    hipLaunchKernelGGL(kern, dim3(G), dim3(kNNBlock), 0, ctx->stream, ctx->src.as<float4>(), ctx->n,
                        ctx->levels, ctx->perm0.as<uint32_t>(), ctx->state.as<DevState>(), best2_init,
                        ctx->partials.as<double>(),
                        MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, nn_idx, nn_d2);
