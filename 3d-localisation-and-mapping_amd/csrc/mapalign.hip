@@ -1231,8 +1231,10 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
     // table reads vs candidates on MI355X).  Scans are surfaces,
     // so occupancy grows ~ c^2; two histogram probes estimate the exponent.
     const double target = 4.5;
+    // table budget of the density-driven choice: at most 32 cells (128 B of table) per point
+    const uint64_t auto_cells = std::min<uint64_t>(kMaxCells, std::max<uint64_t>(1ull << 20, 32ull * n));
     const double ext = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-6});
-    float c0 = clamp_cell_to_budget(lo, hi, (float)(ext / 256.0), kMaxCells / 8);
+    float c0 = clamp_cell_to_budget(lo, hi, (float)(ext / 256.0), auto_cells);
     uint64_t occ = 0;
     GridP g0 = make_grid(lo, hi, ctx->origin, c0);
     if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g0, ctx->origin, &occ))) return rc;
@@ -1240,7 +1242,7 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
     double expo = 2.0;
     float c1 = (float)(c0 * std::pow(target / rho0, 1.0 / expo));
     c1 = std::min(std::max(c1, c0 / 16.f), c0 * 16.f);
-    c1 = clamp_cell_to_budget(lo, hi, c1, kMaxCells / 8);
+    c1 = clamp_cell_to_budget(lo, hi, c1, auto_cells);
     if (std::fabs(c1 / c0 - 1.f) > 0.05f) {
       GridP g1 = make_grid(lo, hi, ctx->origin, c1);
       if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g1, ctx->origin, &occ))) return rc;
@@ -1251,7 +1253,7 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
       }
       float c2 = (float)(c1 * std::pow(target / rho1, 1.0 / expo));
       c2 = std::min(std::max(c2, c1 / 4.f), c1 * 4.f);
-      c = clamp_cell_to_budget(lo, hi, c2, kMaxCells / 8);
+      c = clamp_cell_to_budget(lo, hi, c2, auto_cells);
     } else {
       c = c1;
     }
