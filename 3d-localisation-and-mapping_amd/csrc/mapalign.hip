@@ -579,24 +579,39 @@ __global__ __launch_bounds__(kNNBlock) void k_nn_accum(
   }
   if (MODE == 1) return;  // ma_nn: per-point outputs only
 
-  // wavefront DPP sums, then a fixed-order sum over the 4 wavefronts.  Without work
-  // counting only the 17 real accumulators take part (the two counter slots stay zero).
+  // Workgroup reduction of the live accumulators, fixed order (deterministic):
+  //   1. two DPP steps fold each group of 4 lanes (6 VALU ops per value; a full wavefront
+  //      reduction in DPP costs 18 and was a quarter of this kernel's VALU work);
+  //   2. the 16 group sums per wavefront go to LDS; 8 threads per accumulator each add
+  //      their share in index order;
+  //   3. one thread per accumulator adds the 8 partial sums and writes the partial.
+  // Without work counting only the 17 real accumulators take part (the counter slots stay 0).
   constexpr int kLive = COUNT ? kNAcc : ma::kAccLen;
-  __shared__ double red[kNNBlock / kWave][kNAcc];
+  constexpr int kNW = kNNBlock / kWave, kVals = kNW * 16, kParts = 8, kPer = kVals / kParts;
+  __shared__ double sh_v[kNAcc][kVals];
+  __shared__ double sh_part[kNAcc][kParts];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
 #pragma unroll
   for (int k = 0; k < kLive; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == kSumLane) red[wv][k] = v;
+    double v = dpp_add<0x111>(acc[k]);
+    v = dpp_add<0x112>(v);
+    if ((lane & 3) == 3) sh_v[k][wv * 16 + (lane >> 2)] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLive * kParts) {
+    const int k = threadIdx.x / kParts, part = threadIdx.x % kParts;
+    double v = 0.0;
+#pragma unroll
+    for (int t = 0; t < kPer; ++t) v += sh_v[k][part * kPer + t];
+    sh_part[k][part] = v;
   }
   __syncthreads();
   if (threadIdx.x < kNAcc) {
     const int k = threadIdx.x;
     double v = 0.0;
     if (k < kLive) {
-      v = red[0][k];
 #pragma unroll
-      for (int w = 1; w < kNNBlock / kWave; ++w) v += red[w][k];
+      for (int t = 0; t < kParts; ++t) v += sh_part[k][t];
     }
     partials[(size_t)k * G + blockIdx.x] = v;
   }
