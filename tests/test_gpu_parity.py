@@ -578,3 +578,21 @@ def test_georeferenced_coordinates_fp64_inputs(engine):
     idx64, d264 = (lambda e: (e.set_gold(gold64), e.set_source(comp64), e.nn(res.T, 0.1))[2])(engine)
     oi, od2 = orc.GoldIndex(gold64, n_jobs=8).query(comp64 @ res.R.T + res.t)
     assert_nn_matches(idx64, d264, oi, od2, gate=0.1)
+
+
+def test_maximum_sizes_are_refused_not_truncated(engine):
+    """Clouds beyond the 32-bit offset range fail loudly before any memory is touched."""
+    import ctypes as C
+    from mapalign import _lib
+    lib, ctx = engine._lib, engine._ctx
+    small = np.zeros((4, 3), np.float32)
+    p = small.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib.ma_set_gold(ctx, p, 1 << 28, 0.0) == _lib.MA_ERR_TOO_LARGE
+    gold, comp, _, _ = syn.make_pair(19, 500)
+    engine.set_gold(gold)
+    assert lib.ma_set_source(ctx, p, None, 0xFFFFFFFE) == _lib.MA_ERR_TOO_LARGE
+    K = (C.c_float * 4)(50, 50, 8, 8)
+    T = (C.c_double * 16)(*np.eye(4).ravel())
+    nv = C.c_uint64(0)
+    assert lib.ma_set_source_from_depth(ctx, p, 0, 70000, 70000, K, T, 1000.0, C.byref(nv)) == _lib.MA_ERR_INVALID
+    assert b"2^28" in lib.ma_last_error(ctx) or b"image" in lib.ma_last_error(ctx)
