@@ -766,6 +766,51 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
   }
 }
 
+// N4: voxel keys of the accumulated map points (21 bits per axis around the map origin)
+__global__ __launch_bounds__(kBlock) void k_voxel_keys(const float4* __restrict__ pts, uint32_t n, float inv_voxel,
+                                                       unsigned long long* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  const long long half = 1ll << 20;
+  auto q = [&](float v) -> unsigned long long {
+    long long c = (long long)floorf(v * inv_voxel) + half;
+    c = c < 0 ? 0 : (c > 2 * half - 1 ? 2 * half - 1 : c);
+    return (unsigned long long)c;
+  };
+  keys[i] = (q(p.z) << 42) | (q(p.y) << 21) | q(p.x);
+  vals[i] = i;
+}
+
+__global__ __launch_bounds__(kBlock) void k_voxel_heads(const unsigned long long* __restrict__ keys, uint32_t n,
+                                                        uint32_t* __restrict__ flags /*[n+1]*/) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > n) return;
+  flags[i] = (i < n && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
+}
+
+// one thread per voxel: fp64 centroid of its points in sorted (= insertion) order
+__global__ __launch_bounds__(kBlock) void k_voxel_mean(const unsigned long long* __restrict__ keys,
+                                                       const uint32_t* __restrict__ vals,
+                                                       const uint32_t* __restrict__ flags,
+                                                       const uint32_t* __restrict__ segid, uint32_t n,
+                                                       const float4* __restrict__ pts, double o0, double o1, double o2,
+                                                       float* __restrict__ xyz) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n || !flags[i]) return;
+  const unsigned long long key = keys[i];
+  double sx = 0.0, sy = 0.0, sz = 0.0, cnt = 0.0;
+  for (uint32_t j = i; j < n && keys[j] == key; ++j) {
+    const float4 p = pts[vals[j]];
+    sx += p.x; sy += p.y; sz += p.z; cnt += 1.0;
+  }
+  const uint32_t s = segid[i];
+  xyz[3 * (size_t)s] = (float)(sx / cnt + o0);
+  xyz[3 * (size_t)s + 1] = (float)(sy / cnt + o1);
+  xyz[3 * (size_t)s + 2] = (float)(sz / cnt + o2);
+}
+
 // a10: one thread per box corner.  cam.T here is the plain camera->world matrix (world frame).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_lift_boxes(const T* __restrict__ depth, const int width,
@@ -862,6 +907,13 @@ struct ma_ctx {
 
   // last uploaded depth frame (ma_set_source_from_depth / ma_lift_boxes)
   int depth_w = 0, depth_h = 0, depth_dtype = -1;
+
+  // map builder (N4)
+  DevBuf map_pts, map_keys_a, map_keys_b, map_flags, map_seg;
+  uint64_t map_n = 0, map_cap = 0;
+  float map_voxel = 0.f;
+  double map_origin[3] = {0, 0, 0};
+  bool map_has_origin = false;
 
   // scratch for builds
   DevBuf raw, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
@@ -1137,6 +1189,10 @@ void fill_stats(const DevState& s, double gpu_ms, ma_stats* st) {
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
+// Builds the gold map (grids of all levels, distance table) from the n x 3 fp32 world-frame
+// points already resident in ctx->raw; ev0 must have been recorded by the caller.
+static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell);
+
 extern "C" {
 
 int ma_version(void) { return MA_VERSION; }
@@ -1193,7 +1249,7 @@ int ma_destroy(ma_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (int l = 0; l < kLevels; ++l) { ctx->gold[l].release(); ctx->cstart[l].release(); }
-  for (DevBuf* b : {&ctx->perm0, &ctx->inv0, &ctx->occ_a, &ctx->occ_b, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
+  for (DevBuf* b : {&ctx->map_pts, &ctx->map_keys_a, &ctx->map_keys_b, &ctx->map_flags, &ctx->map_seg, &ctx->perm0, &ctx->inv0, &ctx->occ_a, &ctx->occ_b, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
                     &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc, &ctx->depth_in,
                     &ctx->state, &ctx->partials, &ctx->trace, &ctx->acc19, &ctx->nn_idx, &ctx->nn_d2,
                     &ctx->nn_tmp, &ctx->prev})
@@ -1234,6 +1290,10 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
   HIPCHK(ctx->raw.ensure((size_t)n * 12));
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+  return build_gold_from_raw(ctx, n, cell);
+}
+
+static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   float lo[3], hi[3];
   int rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, lo, hi);
   if (rc) return rc;
@@ -1494,6 +1554,144 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   ctx->n = total;
   ctx->src_sorted = false;
   ctx->have_src = true;
+  return MA_OK;
+}
+
+int ma_map_begin(ma_ctx* ctx, float voxel, uint64_t capacity_points) {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!(voxel > 0.f) || !std::isfinite(voxel)) return ctx->fail(MA_ERR_INVALID, "voxel must be > 0");
+  if (capacity_points == 0 || capacity_points >= (1ull << 31)) return ctx->fail(MA_ERR_INVALID, "capacity must be in [1, 2^31)");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(ctx->map_pts.ensure(capacity_points * sizeof(float4)));
+  ctx->map_cap = capacity_points;
+  ctx->map_n = 0;
+  ctx->map_voxel = voxel;
+  ctx->map_has_origin = false;
+  return MA_OK;
+}
+
+int ma_map_add_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height, const float K[4],
+                     const double T[16], float depth_scale, uint64_t* n_added) {
+  if (!ctx) return MA_ERR_INVALID;
+  if (ctx->map_cap == 0) return ctx->fail(MA_ERR_STATE, "ma_map_begin first");
+  if (!depth || !K || !T) return ctx->fail(MA_ERR_INVALID, "NULL argument");
+  if (dtype != 0 && dtype != 1) return ctx->fail(MA_ERR_INVALID, "dtype must be 0 (float32) or 1 (uint16)");
+  if (width <= 0 || height <= 0 || (uint64_t)width * height >= 0xFFFFFFFEull) return ctx->fail(MA_ERR_INVALID, "bad image size");
+  if (!(K[0] != 0.f) || !(K[1] != 0.f) || !(depth_scale > 0.f) || !std::isfinite(depth_scale)) return ctx->fail(MA_ERR_INVALID, "bad intrinsics / depth_scale");
+  for (int i = 0; i < 16; ++i) if (!std::isfinite(T[i])) return ctx->fail(MA_ERR_INVALID, "non-finite camera pose");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t npx = (uint32_t)((uint64_t)width * height);
+  if (ctx->map_n + npx > ctx->map_cap) return ctx->fail(MA_ERR_TOO_LARGE, "map capacity exceeded (ma_map_begin capacity_points)");
+  if (!ctx->map_has_origin) {   // points are stored relative to the first camera position (fp32 precision)
+    for (int r = 0; r < 3; ++r) ctx->map_origin[r] = std::round(T[4 * r + 3]);
+    ctx->map_has_origin = true;
+  }
+  const size_t esz = dtype == 0 ? 4 : 2;
+  HIPCHK(ctx->depth_in.ensure((size_t)npx * esz));
+  HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, (size_t)npx * esz, hipMemcpyHostToDevice, ctx->stream));
+  ctx->depth_w = width; ctx->depth_h = height; ctx->depth_dtype = dtype;
+  Pinhole cam{};
+  cam.fx_inv = 1.0 / (double)K[0];
+  cam.fy_inv = 1.0 / (double)K[1];
+  cam.cx = K[2];
+  cam.cy = K[3];
+  cam.inv_scale = 1.0 / (double)depth_scale;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) cam.T[4 * r + c] = T[4 * r + c];
+    cam.T[4 * r + 3] = T[4 * r + 3] - ctx->map_origin[r];
+  }
+  const uint32_t nb = div_up(npx, kPxPerBlock);
+  HIPCHK(ctx->keys_a.ensure((size_t)(nb + 1) * 4));
+  HIPCHK(ctx->keys_b.ensure((size_t)(nb + 1) * 4));
+  HIPCHK(hipMemsetAsync(ctx->keys_a.p, 0, (size_t)(nb + 1) * 4, ctx->stream));
+  float4* out = ctx->map_pts.as<float4>() + ctx->map_n;
+  if (dtype == 0) {
+    hipLaunchKernelGGL((k_unproject<float, 0>), dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
+                       width, npx, cam, ctx->keys_a.as<uint32_t>(), (const uint32_t*)nullptr, (float4*)nullptr);
+  } else {
+    hipLaunchKernelGGL((k_unproject<uint16_t, 0>), dim3(nb), dim3(kBlock), 0, ctx->stream,
+                       ctx->depth_in.as<uint16_t>(), width, npx, cam, ctx->keys_a.as<uint32_t>(),
+                       (const uint32_t*)nullptr, (float4*)nullptr);
+  }
+  HIPCHK(hipGetLastError());
+  size_t tmp_bytes = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(),
+                                          ctx->keys_b.as<uint32_t>(), (int)(nb + 1), ctx->stream));
+  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(),
+                                          ctx->keys_b.as<uint32_t>(), (int)(nb + 1), ctx->stream));
+  if (dtype == 0) {
+    hipLaunchKernelGGL((k_unproject<float, 1>), dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
+                       width, npx, cam, (uint32_t*)nullptr, ctx->keys_b.as<uint32_t>(), out);
+  } else {
+    hipLaunchKernelGGL((k_unproject<uint16_t, 1>), dim3(nb), dim3(kBlock), 0, ctx->stream,
+                       ctx->depth_in.as<uint16_t>(), width, npx, cam, (uint32_t*)nullptr,
+                       ctx->keys_b.as<uint32_t>(), out);
+  }
+  HIPCHK(hipGetLastError());
+  uint32_t total = 0;
+  HIPCHK(hipMemcpyAsync(&total, ctx->keys_b.as<uint32_t>() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->map_n += total;
+  if (n_added) *n_added = total;
+  return MA_OK;
+}
+
+int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t* n_io) {
+  if (!ctx || !n_io) return MA_ERR_INVALID;
+  if (ctx->map_cap == 0) return ctx->fail(MA_ERR_STATE, "ma_map_begin first");
+  if (ctx->map_n == 0) return ctx->fail(MA_ERR_EMPTY, "the map holds no point");
+  if (std::isnan(cell) || std::isinf(cell)) return ctx->fail(MA_ERR_INVALID, "cell must be finite");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t n = (uint32_t)ctx->map_n;
+  HIPCHK(ctx->map_keys_a.ensure((size_t)n * 8));
+  HIPCHK(ctx->map_keys_b.ensure((size_t)n * 8));
+  HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
+  HIPCHK(ctx->vals_b.ensure((size_t)n * 4));
+  HIPCHK(ctx->map_flags.ensure((size_t)(n + 1) * 4));
+  HIPCHK(ctx->map_seg.ensure((size_t)(n + 1) * 4));
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_voxel_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->map_pts.as<float4>(), n,
+                     1.0f / ctx->map_voxel, ctx->map_keys_a.as<unsigned long long>(), ctx->vals_a.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  size_t tmp_bytes = 0;
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->map_keys_a.as<unsigned long long>(),
+                                            ctx->map_keys_b.as<unsigned long long>(), ctx->vals_a.as<uint32_t>(),
+                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, 63, ctx->stream));
+  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp_bytes, ctx->map_keys_a.as<unsigned long long>(),
+                                            ctx->map_keys_b.as<unsigned long long>(), ctx->vals_a.as<uint32_t>(),
+                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, 63, ctx->stream));
+  hipLaunchKernelGGL(k_voxel_heads, dim3(div_up((uint64_t)n + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     ctx->map_keys_b.as<unsigned long long>(), n, ctx->map_flags.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ctx->map_flags.as<uint32_t>(), ctx->map_seg.as<uint32_t>(),
+                                          (int)(n + 1), ctx->stream));
+  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, ctx->map_flags.as<uint32_t>(),
+                                          ctx->map_seg.as<uint32_t>(), (int)(n + 1), ctx->stream));
+  uint32_t nvox = 0;
+  HIPCHK(hipMemcpyAsync(&nvox, ctx->map_seg.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx->raw.ensure((size_t)nvox * 12));
+  hipLaunchKernelGGL(k_voxel_mean, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream,
+                     ctx->map_keys_b.as<unsigned long long>(), ctx->vals_b.as<uint32_t>(), ctx->map_flags.as<uint32_t>(),
+                     ctx->map_seg.as<uint32_t>(), n, ctx->map_pts.as<float4>(), ctx->map_origin[0], ctx->map_origin[1],
+                     ctx->map_origin[2], ctx->raw.as<float>());
+  HIPCHK(hipGetLastError());
+  if (xyz_out) {
+    if (*n_io < nvox) { *n_io = nvox; return ctx->fail(MA_ERR_INVALID, "output capacity too small"); }
+    HIPCHK(hipMemcpyAsync(xyz_out, ctx->raw.p, (size_t)nvox * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  *n_io = nvox;
+  if (as_gold) {
+    if (nvox >= (1u << 28)) return ctx->fail(MA_ERR_TOO_LARGE, "map has 2^28 or more voxels");
+    ctx->have_gold = false;
+    ctx->have_src = false;
+    return build_gold_from_raw(ctx, nvox, cell);   // ctx->raw already holds the voxel centroids
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return MA_OK;
 }
 

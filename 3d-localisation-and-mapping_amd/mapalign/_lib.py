@@ -79,6 +79,9 @@ ABI = {
     "ma_set_source": (C.c_int, [_ctx_p, _f32p, _f32p, C.c_uint64]),
     "ma_set_source_from_depth": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p, _f64p,
                                            C.c_float, _u64p]),
+    "ma_map_begin": (C.c_int, [_ctx_p, C.c_float, C.c_uint64]),
+    "ma_map_add_depth": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p, _f64p, C.c_float, _u64p]),
+    "ma_map_finish": (C.c_int, [_ctx_p, C.c_int, C.c_float, _f32p, _u64p]),
     "ma_lift_boxes": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p, _f64p, C.c_float, _f32p,
                                 C.c_uint64, _f64p, C.POINTER(C.c_uint8)]),
     "ma_get_source": (C.c_int, [_ctx_p, _f32p, _u64p]),

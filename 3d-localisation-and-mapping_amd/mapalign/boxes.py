@@ -39,6 +39,27 @@ def flatten(bboxes):
     return centres, rows
 
 
+def suppress_bboxes(global_bboxes_data, dist_thresh=0.3):
+    """3-D non-maximum suppression of the per-frame global boxes (the step
+    ``BoundingBoxProcessor(global_bboxes_data, pose_df).suppress_bboxes()`` performs at
+    ``task_def.py:145-149``; its body is absent from the snapshot).  Greedy by confidence: a box
+    is dropped when a kept box with the same label has its centre within ``dist_thresh`` metres.
+    Returns the same ``dict[frame] -> rows`` container with the survivors."""
+    centres, rows = flatten(global_bboxes_data)
+    frames = [frame for frame in global_bboxes_data for _ in global_bboxes_data[frame]]
+    conf = np.array([float(r[5]) if len(r) > 5 else 1.0 for r in rows]) if rows else np.zeros(0)
+    keep = []
+    for i in np.argsort(-conf, kind="stable"):
+        lab = rows[i][6] if len(rows[i]) > 6 else None
+        if all((rows[j][6] if len(rows[j]) > 6 else None) != lab or
+               np.linalg.norm(centres[i] - centres[j]) > dist_thresh for j in keep):
+            keep.append(int(i))
+    out = {}
+    for i in sorted(keep):
+        out.setdefault(frames[i], []).append(rows[i])
+    return out
+
+
 def match_bboxes(gold_bboxes, aligned_bboxes, max_dist=0.5, csv_output_file=None):
     """Minimum-cost bipartite matching on centre distance, gated at ``max_dist`` metres.
 

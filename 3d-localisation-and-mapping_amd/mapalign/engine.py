@@ -112,6 +112,7 @@ class MapAligner:
         self.n_gold = 0
         self.n_source = 0
         self._shift = np.zeros(3)
+        self._map_shift = None
 
     # -- lifetime -------------------------------------------------------------------
     def close(self):
@@ -207,6 +208,50 @@ class MapAligner:
             Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T), float(depth_scale), C.byref(nv)))
         self.n_source = int(nv.value)
         return self.n_source
+
+    # -- map builder (N4): depth frames + poses -> one voxel-deduplicated cloud on the device
+    def map_begin(self, voxel, capacity_points):
+        self._chk(self._lib.ma_map_begin(self._ctx, float(voxel), int(capacity_points)))
+        self._map_shift = None
+
+    def map_add_depth(self, depth, K, T_cam_to_world, depth_scale=1000.0):
+        d = np.asarray(depth)
+        if d.ndim != 2:
+            raise ValueError("depth must be a 2-D image")
+        dtype = 1 if d.dtype == np.uint16 else 0
+        d = np.ascontiguousarray(d if dtype == 1 else d.astype(np.float32, copy=False))
+        Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
+        T = np.array(T_cam_to_world, dtype=np.float64).reshape(4, 4)
+        if self._map_shift is None:      # georeferenced poses: integer-metre host shift, as for clouds
+            t = T[:3, 3]
+            self._map_shift = np.round(t) if np.abs(t).max() > LARGE_COORDINATE_M else np.zeros(3)
+        T[:3, 3] -= self._map_shift
+        T = np.ascontiguousarray(T)
+        nv = C.c_uint64(0)
+        self._chk(self._lib.ma_map_add_depth(self._ctx, d.ctypes.data_as(C.c_void_p), dtype, d.shape[1], d.shape[0],
+                                             Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T), float(depth_scale),
+                                             C.byref(nv)))
+        return int(nv.value)
+
+    def map_finish(self, as_gold=False, cell=0.0, fetch=True):
+        """Voxel centroids of everything added since map_begin.  ``as_gold`` installs them as this
+        context's gold map on the device.  Returns the [V,3] array (float64 if shifted) or the count."""
+        n = C.c_uint64(0)
+        shift = self._map_shift if self._map_shift is not None else np.zeros(3)
+        if not fetch:
+            self._chk(self._lib.ma_map_finish(self._ctx, 1 if as_gold else 0, float(cell), None, C.byref(n)))
+            out = int(n.value)
+        else:
+            self._chk(self._lib.ma_map_finish(self._ctx, 0, float(cell), None, C.byref(n)))    # size query
+            arr = np.empty((int(n.value), 3), dtype=np.float32)
+            self._chk(self._lib.ma_map_finish(self._ctx, 1 if as_gold else 0, float(cell),
+                                              arr.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
+            out = arr if not np.any(shift != 0.0) else arr.astype(np.float64) + shift
+        if as_gold:
+            self._shift = shift.copy()
+            self.n_gold = int(n.value)
+            self.n_source = 0
+        return out
 
     def lift_boxes(self, boxes_xyxy, K, T_cam_to_world, depth=None, depth_scale=1000.0):
         """Row a10: corners (x1,y1) (x2,y1) (x2,y2) (x1,y2) of each box -> global 3-D points.

@@ -114,6 +114,19 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
 int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height,
                              const float K[4], const double T_cam_to_world[16],
                              float depth_scale, uint64_t* n_valid);
+/* Row N4: full-frame map builder — what RTAB-Map's .ply export does for the
+ * reference, on the device: every depth frame is unprojected with its pose (same pinhole
+ * model as ma_set_source_from_depth, pose_processor.py:88-122,262-271) into one buffer, and
+ * ma_map_finish reduces the points of each voxel of edge `voxel` to their centroid (the
+ * semantics of Open3D's voxel_down_sample; deterministic: stable sort by voxel key, fixed
+ * summation order).  as_gold != 0 installs the result as the gold map of this ctx without a
+ * host round trip (cell as in ma_set_gold).  xyz_out may be NULL; *n: in = capacity of
+ * xyz_out in points, out = number of voxels. */
+int ma_map_begin(ma_ctx* ctx, float voxel, uint64_t capacity_points);
+int ma_map_add_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height, const float K[4],
+                     const double T_cam_to_world[16], float depth_scale, uint64_t* n_added);
+int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t* n);
+
 /* Row a10: lift 2-D box corners to 3-D global coordinates (pose_processor.py:172-208):
  * for each of the n_boxes boxes [x1,y1,x2,y2] (pixels AT DEPTH RESOLUTION, i.e. after the
  * reference's scale_bounding_box), the four corners (x1,y1) (x2,y1) (x2,y2) (x1,y2) are

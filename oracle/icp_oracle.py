@@ -185,6 +185,26 @@ def unproject_oracle(depth, K, T_cam_to_world, depth_scale=1000.0):
     return cam @ T[:3, :3].T + T[:3, 3], mask
 
 
+def voxel_centroids_oracle(points, voxel, origin):
+    """Row N4: centroid of the points of each voxel (Open3D voxel_down_sample semantics).
+    Voxel index = floor((p - origin) / voxel) evaluated in float32 like the device does; output
+    sorted by (z, y, x) voxel index."""
+    p = np.asarray(points, dtype=np.float64)
+    rel = (p - np.asarray(origin, dtype=np.float64)).astype(np.float32)
+    idx = np.floor(rel * np.float32(1.0 / np.float32(voxel))).astype(np.int64)
+    key = ((idx[:, 2] + (1 << 20)) << 42) | ((idx[:, 1] + (1 << 20)) << 21) | (idx[:, 0] + (1 << 20))
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    heads = np.concatenate([[True], ks[1:] != ks[:-1]])
+    seg = np.cumsum(heads) - 1
+    out = np.zeros((seg[-1] + 1, 3))
+    cnt = np.bincount(seg)
+    relo = rel[order].astype(np.float64)
+    for a in range(3):
+        out[:, a] = np.bincount(seg, weights=relo[:, a]) / cnt
+    return out + np.asarray(origin, dtype=np.float64)
+
+
 def lift_boxes_oracle(boxes_xyxy, depth, K, T_cam_to_world, depth_scale=1000.0):
     """Row a10: corners (x1,y1) (x2,y1) (x2,y2) (x1,y2) at int() pixels (clamped into the
     image) -> global points; call shape of pose_processor.py:181-201.  Returns

@@ -596,3 +596,50 @@ def test_maximum_sizes_are_refused_not_truncated(engine):
     nv = C.c_uint64(0)
     assert lib.ma_set_source_from_depth(ctx, p, 0, 70000, 70000, K, T, 1000.0, C.byref(nv)) == _lib.MA_ERR_INVALID
     assert b"2^28" in lib.ma_last_error(ctx) or b"image" in lib.ma_last_error(ctx)
+
+
+# ----------------------------------------------------------------------------- row N4: map builder
+def test_map_builder_voxel_centroids_and_as_gold(engine):
+    """Depth frames + poses -> one voxel-deduplicated cloud on the device, checked against the
+    NumPy restatement; then used as the gold map for a fourth frame without a host round trip."""
+    K = (250.0, 250.0, 159.5, 119.5)
+    rects = syn.carriage_rectangles(np.random.default_rng(5))
+    poses = []
+    for k, x in enumerate((2.0, 4.0, 6.0)):
+        T = syn.default_camera_pose()
+        T[:3, 3] = (x, 1.4 + 0.1 * k, 1.3)
+        T[:3, :3] = T[:3, :3] @ syn.rotation_about_axis([0, 1, 0], 0.1 * k)
+        poses.append(T)
+    frames = [syn.render_depth(rects, T, 320, 240, *K) for T in poses]
+    voxel = 0.05
+    engine.map_begin(voxel, 4 * 320 * 240)
+    added = [engine.map_add_depth(d, K, T) for d, T in zip(frames, poses)]
+    pts = np.concatenate([orc.unproject_oracle(d, K, T, 1000.0)[0] for d, T in zip(frames, poses)])
+    assert sum(added) == len(pts)
+    cloud = engine.map_finish()
+    origin = np.round(poses[0][:3, 3])
+    ref = orc.voxel_centroids_oracle(pts, voxel, origin)
+    assert cloud.shape == ref.shape
+    # same voxels in the same (z,y,x) order; centroids agree to fp32 storage precision
+    assert np.abs(cloud.astype(np.float64) - ref).max() <= 2e-5
+    assert len(cloud) < 0.5 * len(pts)                       # overlapping frames really were merged
+    # a fourth frame aligned against the map built on the device
+    n_vox = engine.map_finish(as_gold=True, fetch=False)
+    assert n_vox == len(ref) and engine.grid_info()["n_occupied"] > 0
+    T4 = syn.default_camera_pose()
+    T4[:3, 3] = (3.0, 1.5, 1.3)
+    d4 = syn.render_depth(rects, T4, 320, 240, *K)
+    dT = np.eye(4)
+    dT[:3, :3] = syn.rotation_about_axis([0.3, 1.0, 0.2], np.deg2rad(0.5))
+    dT[:3, 3] = [0.02, -0.015, 0.01]
+    engine.set_source_from_depth(d4, K, dT @ T4)
+    res = engine.icp(30, 0.0, 0.10)
+    refi = orc.icp_oracle(cloud, engine.get_source(), max_iter=30, max_corr_dist=0.10, n_jobs=8)
+    eR, et = orc.rt_error(res.R, res.t, refi["R"], refi["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    with pytest.raises(mapalign.MapAlignError):
+        mapalign.MapAligner(0).map_add_depth(d4, K, T4)       # map_begin missing
+    engine.map_begin(0.05, 1000)
+    with pytest.raises(mapalign.MapAlignError) as e:
+        engine.map_add_depth(d4, K, T4)                        # capacity exceeded
+    assert e.value.status == -7

@@ -123,3 +123,14 @@ def test_detector_row_schema_helpers():
     K = lifting.rescaled_intrinsics({"image_width": 1920, "image_height": 1440, "fx": 1500.0, "fy": 1500.0,
                                      "cx": 960.0, "cy": 720.0}, 192)
     assert np.allclose(K, (150.0, 150.0, 96.0, 72.0))                 # pose_processor.py:133-137
+
+
+def test_suppress_bboxes_3d_nms():
+    # the same sign seen in three frames + a different sign nearby + the same label far away
+    data = {0: [_box([0, 0, 0], conf=0.7, label="exit")],
+            1: [_box([0.05, 0.02, 0], conf=0.9, label="exit"), _box([0.1, 0, 0], conf=0.8, label="fire")],
+            2: [_box([0.02, -0.03, 0.01], conf=0.6, label="exit"), _box([5, 0, 0], conf=0.5, label="exit")]}
+    kept = boxes.suppress_bboxes(data, dist_thresh=0.3)
+    assert sorted(kept) == [1, 2]
+    assert [r[5] for r in kept[1]] == [0.9, 0.8] and [r[5] for r in kept[2]] == [0.5]
+    assert boxes.suppress_bboxes({}) == {}
