@@ -502,6 +502,206 @@ __device__ __forceinline__ void nn_find(const float px, const float py, const fl
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Wavefront-cooperative search: work queues in LDS instead of per-lane control flow
+// ---------------------------------------------------------------------------------------
+// The per-lane search wastes about half of its VALU lane-slots: a wavefront executes every
+// row test and every candidate trip that ANY of its 64 queries needs.  Here the wavefront
+// turns the work into ITEMS and spreads them evenly over its lanes:
+//   phase 1  every query tests its candidate rows geometrically (cheap, all lanes busy) and
+//            pushes the rows its sphere reaches into a row queue (ballot-prefix compaction);
+//   phase 2  the row items are dealt to the lanes: x-range, table read, and the run is cut
+//            into chunks of <= 8 candidates pushed into a chunk queue;
+//   phase 3  the chunk items are dealt to the lanes: distances, and a 64-bit LDS atomic min
+//            on (distance bits << 32 | position) per query — order-independent, hence
+//            deterministic (equal distances resolve to the smaller position).
+// Rounds: the 3 x 3 rows first, then one ring per round while some query's sphere reaches it.
+constexpr int kRowCap = 128, kChunkCap = 256, kChunkLen = 8;
+
+struct WaveLds {
+  float4 pos[kWave];
+  unsigned long long best[kWave];
+  uint32_t row_cell[kRowCap];
+  float row_d2yz[kRowCap];
+  uint32_t chunk_a[kChunkCap];
+  uint8_t row_lane[kRowCap];
+  uint8_t chunk_lane[kChunkCap];
+  uint8_t chunk_cnt[kChunkCap];
+};
+
+__device__ __forceinline__ unsigned long long pack_best(float d2, uint32_t j) {
+  return ((unsigned long long)__float_as_uint(d2) << 32) | j;
+}
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, const float4* __restrict__ gold0,
+                                                uint32_t& nchunk, uint32_t& ncand) {
+  for (uint32_t j0 = 0; j0 < nchunk; j0 += kWave) {
+    const uint32_t j = j0 + lane;
+    if (j < nchunk) {
+      const uint32_t lq = W.chunk_lane[j], a = W.chunk_a[j], cnt = W.chunk_cnt[j];
+      const float4 p = W.pos[lq];
+      float b2 = __uint_as_float((uint32_t)(W.best[lq] >> 32));
+      const float b2_in = b2;
+      uint32_t bj = kNoMatch;
+      for (uint32_t t = 0; t < cnt; t += 4u) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = ld_point(gold0, a + min(t + (uint32_t)u, cnt - 1u));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float dx = p.x - q[u].x, dy = p.y - q[u].y, dz = p.z - q[u].z;
+          const float d = dx * dx + dy * dy + dz * dz;
+          if (d < b2) { b2 = d; bj = __float_as_uint(q[u].w); }
+        }
+      }
+      if (COUNT) ncand += cnt;
+      if (b2 < b2_in) atomicMin(&W.best[lq], pack_best(b2, bj));
+    }
+  }
+  nchunk = 0;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const LevelSet& S, uint32_t& nrow,
+                                              uint32_t& nchunk, uint32_t& nrows_cnt, uint32_t& ncand) {
+  const float4* __restrict__ gold0 = S.gold[0];
+  const uint32_t* __restrict__ cs0 = S.cs[0];
+  const float inv_c = S.inv_c[0];
+  const int nx = S.nx[0];
+  for (uint32_t i0 = 0; i0 < nrow; i0 += kWave) {
+    const uint32_t i = i0 + lane;
+    uint32_t a = 0, b = 0, lq = 0;
+    if (i < nrow) {
+      lq = W.row_lane[i];
+      const float d2yz = W.row_d2yz[i];
+      const float4 p = W.pos[lq];
+      const float b2 = __uint_as_float((uint32_t)(W.best[lq] >> 32));
+      if (d2yz < b2) {
+        const float rx = fast_sqrt(b2 - d2yz) + S.delta;
+        const int x0 = (int)fmaxf(floorf((p.x - rx - S.ox) * inv_c), 0.f);
+        const int x1 = (int)fminf(floorf((p.x + rx - S.ox) * inv_c), (float)(nx - 1));
+        if (x0 <= x1) {
+          const uint32_t cell = W.row_cell[i] + (uint32_t)x0;
+          const int span = x1 - x0;
+          if (span <= 2) {
+            const u4_unaligned v = ld_cell4(cs0, cell);
+            a = v.x;
+            b = span == 0 ? v.y : (span == 1 ? v.z : v.w);
+          } else {
+            a = ld_cell(cs0, cell);
+            b = ld_cell(cs0, cell + (uint32_t)span + 1u);
+          }
+          if (COUNT) nrows_cnt += span <= 2 ? 4u : 2u;
+        }
+      }
+    }
+    // cut [a,b) into chunks; trip k pushes chunk k of every lane that still has one
+    for (uint32_t k = 0;; ++k) {
+      const bool has = a + k * kChunkLen < b;
+      const unsigned long long mask = __ballot(has);
+      if (mask == 0ull) break;
+      const uint32_t cnt = (uint32_t)__popcll(mask);
+      if (nchunk + cnt > (uint32_t)kChunkCap) wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
+      if (has) {
+        const uint32_t pos = nchunk + lane_prefix(mask), ca = a + k * kChunkLen;
+        W.chunk_a[pos] = ca;
+        W.chunk_lane[pos] = (uint8_t)lq;
+        W.chunk_cnt[pos] = (uint8_t)min((uint32_t)kChunkLen, b - ca);
+      }
+      nchunk += cnt;
+    }
+  }
+  nrow = 0;
+}
+
+// All 64 lanes of the wavefront must call this together.
+template <bool COUNT>
+__device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bool has_query, const float px,
+                                            const float py, const float pz, const LevelSet& S, float& best2,
+                                            uint32_t& bestj, uint32_t& nrows_cnt, uint32_t& ncand) {
+  const float c = S.c[0], inv_c = S.inv_c[0];
+  const int nx = S.nx[0], ny = S.ny[0], nz = S.nz[0];
+  const float4* __restrict__ gold0 = S.gold[0];
+  const bool finite = has_query && isfinite(px) && isfinite(py) && isfinite(pz);
+  W.pos[lane] = make_float4(px, py, pz, 0.f);
+  W.best[lane] = pack_best(best2, bestj);
+  const float uy = fminf(fmaxf((py - S.oy) * inv_c, -1.f), (float)ny);
+  const float uz = fminf(fmaxf((pz - S.oz) * inv_c, -1.f), (float)nz);
+  const int cy = (int)floorf(uy), cz = (int)floorf(uz);
+  const int rmax = max(max(cy, ny - 1 - cy), max(cz, nz - 1 - cz));
+  uint32_t nrow = 0, nchunk = 0;
+
+  auto push_row = [&](const bool pred, const int y, const int z, const float d2yz) {
+    const unsigned long long mask = __ballot(pred);
+    const uint32_t cnt = (uint32_t)__popcll(mask);
+    if (cnt == 0u) return;
+    if (nrow + cnt > (uint32_t)kRowCap) wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
+    if (pred) {
+      const uint32_t pos = nrow + lane_prefix(mask);
+      W.row_cell[pos] = (uint32_t)((z * ny + y) * nx);
+      W.row_d2yz[pos] = d2yz;
+      W.row_lane[pos] = (uint8_t)lane;
+    }
+    nrow += cnt;
+  };
+  auto geo = [&](const int y, const int z, float& d2yz) -> bool {
+    if ((unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz) return false;
+    const float ylo = S.oy + (float)y * c, zlo = S.oz + (float)z * c;
+    const float dyq = fmaxf(0.f, fmaxf(ylo - S.delta - py, py - (ylo + c + S.delta)));
+    const float dzq = fmaxf(0.f, fmaxf(zlo - S.delta - pz, pz - (zlo + c + S.delta)));
+    d2yz = dyq * dyq + dzq * dzq;
+    return d2yz < best2;
+  };
+
+  // ---- round 0: the 3 x 3 rows (rings 0 and 1), centre row first
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int dy = (k % 3 == 0) ? 0 : (k % 3 == 1 ? -1 : 1), dz = (k / 3 == 0) ? 0 : (k / 3 == 1 ? -1 : 1);
+    float d2yz = 0.f;
+    const bool pred = finite && geo(cy + dy, cz + dz, d2yz);
+    push_row(pred, cy + dy, cz + dz, d2yz);
+  }
+  wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
+  wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
+  {
+    const unsigned long long key = W.best[lane];
+    best2 = __uint_as_float((uint32_t)(key >> 32));
+    bestj = (uint32_t)key;
+  }
+  // ---- further rounds: ring r while some query's sphere reaches it (same level; a sphere
+  // wider than kWalk cells is left to the per-lane multi-level search)
+  constexpr float kWalk = 6.f;
+  const float lim = c - S.delta, wide = kWalk * c;
+  bool more = finite && best2 > lim * lim && best2 <= wide * wide;
+  const bool fallback = finite && best2 > wide * wide;
+  for (int r = 2; __any(more); ++r) {
+    const float lb = (float)(r - 1) * c - S.delta;
+    more = more && r <= rmax && lb * lb < best2;
+    if (!__any(more)) break;
+    for (int k = 0; k < 8 * r; ++k) {
+      const int side = k / (2 * r), o = k - side * 2 * r;     // wave-uniform
+      int dy, dz;
+      if (side == 0)      { dy = o - r; dz = -r; }
+      else if (side == 1) { dy = r;     dz = o - r; }
+      else if (side == 2) { dy = r - o; dz = r; }
+      else                { dy = -r;    dz = r - o; }
+      float d2yz = 0.f;
+      const bool pred = more && geo(cy + dy, cz + dz, d2yz);
+      push_row(pred, cy + dy, cz + dz, d2yz);
+    }
+    wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
+    wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
+    const unsigned long long key = W.best[lane];
+    best2 = __uint_as_float((uint32_t)(key >> 32));
+    bestj = (uint32_t)key;
+  }
+  if (fallback) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows_cnt, ncand);
+}
+
 // XCD-aware chunk order: workgroups are dealt round-robin over the 8 XCDs, so workgroups b
 // and b+8 share an L2.  The sorted source cloud is cut into segments of kXcdSeg consecutive
 // chunks and the segments are dealt over the XCDs: every XCD works on contiguous pieces
@@ -522,6 +722,10 @@ __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t G) {
 // One source point per thread: many short-lived wavefronts hide the search's memory latency
 // best (2 and 4 points per thread measured 25-70 % slower), and the 17 fp64 accumulator terms
 // are formed only after the search, so they hold no registers during it.
+#ifndef MA_WAVEQ
+#define MA_WAVEQ 1
+#endif
+
 template <bool COUNT, int MODE>
 __global__ __launch_bounds__(kNNBlock) void k_nn_accum(
     const float4* __restrict__ src, const uint32_t n, const LevelSet S,
@@ -529,21 +733,28 @@ __global__ __launch_bounds__(kNNBlock) void k_nn_accum(
     double* __restrict__ partials, uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx,
     float* __restrict__ nn_d2) {
   if (MODE == 0 && st->done) return;
+  constexpr int kNW = kNNBlock / kWave;
   const uint32_t G = gridDim.x;
   const uint32_t i = xcd_chunk(blockIdx.x, G) * kNNBlock + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  // per-wavefront LDS: the work queues during the search, the group sums afterwards
+  union WaveShared {
+    WaveLds q;
+    double v[kNAcc][16];
+  };
+  __shared__ WaveShared sh_w[kNW];
 
-  double acc[kNAcc];
-#pragma unroll
-  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
-
-  if (i < n) {
-    const float4 s = src[i];
-    const double Px = st->R[0] * s.x + st->R[1] * s.y + st->R[2] * s.z + st->t[0];
-    const double Py = st->R[3] * s.x + st->R[4] * s.y + st->R[5] * s.z + st->t[1];
-    const double Pz = st->R[6] * s.x + st->R[7] * s.y + st->R[8] * s.z + st->t[2];
-    const float px = (float)Px, py = (float)Py, pz = (float)Pz;
-    float best2 = best2_init;
-    uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
+  const bool has = i < n;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  double Px = 0.0, Py = 0.0, Pz = 0.0;
+  float px = 0.f, py = 0.f, pz = 0.f, best2 = best2_init;
+  uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
+  if (has) {
+    s = src[i];
+    Px = st->R[0] * s.x + st->R[1] * s.y + st->R[2] * s.z + st->t[0];
+    Py = st->R[3] * s.x + st->R[4] * s.y + st->R[5] * s.z + st->t[1];
+    Pz = st->R[6] * s.x + st->R[7] * s.y + st->R[8] * s.z + st->t[2];
+    px = (float)Px; py = (float)Py; pz = (float)Pz;
     if (prev) {
       // temporal coherence: last iteration's match bounds the search radius from the start
       const uint32_t pj = prev[i];
@@ -555,7 +766,17 @@ __global__ __launch_bounds__(kNNBlock) void k_nn_accum(
         if (d2 < best2) { best2 = d2; bestj = pj; }
       }
     }
-    nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
+  }
+#if MA_WAVEQ
+  wave_search<COUNT>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand);
+#else
+  if (has) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
+#endif
+
+  double acc[kNAcc];
+#pragma unroll
+  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
+  if (has) {
     if (prev) prev[i] = bestj;
     if (MODE == 1) {
       nn_idx[i] = bestj != kNoMatch ? perm0[bestj] : kNoMatch;
@@ -587,22 +808,23 @@ __global__ __launch_bounds__(kNNBlock) void k_nn_accum(
   //   3. one thread per accumulator adds the 8 partial sums and writes the partial.
   // Without work counting only the 17 real accumulators take part (the counter slots stay 0).
   constexpr int kLive = COUNT ? kNAcc : ma::kAccLen;
-  constexpr int kNW = kNNBlock / kWave, kVals = kNW * 16, kParts = 8, kPer = kVals / kParts;
-  __shared__ double sh_v[kNAcc][kVals];
+  constexpr int kVals = kNW * 16, kParts = 8, kPer = kVals / kParts;
   __shared__ double sh_part[kNAcc][kParts];
-  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
 #pragma unroll
   for (int k = 0; k < kLive; ++k) {
     double v = dpp_add<0x111>(acc[k]);
     v = dpp_add<0x112>(v);
-    if ((lane & 3) == 3) sh_v[k][wv * 16 + (lane >> 2)] = v;
+    if ((lane & 3) == 3) sh_w[wv].v[k][lane >> 2] = v;
   }
   __syncthreads();
   if (threadIdx.x < kLive * kParts) {
     const int k = threadIdx.x / kParts, part = threadIdx.x % kParts;
     double v = 0.0;
 #pragma unroll
-    for (int t = 0; t < kPer; ++t) v += sh_v[k][part * kPer + t];
+    for (int t = 0; t < kPer; ++t) {
+      const int idx = part * kPer + t;
+      v += sh_w[idx / 16].v[k][idx % 16];
+    }
     sh_part[k][part] = v;
   }
   __syncthreads();
