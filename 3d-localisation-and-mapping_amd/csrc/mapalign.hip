@@ -516,7 +516,16 @@ __device__ __forceinline__ void nn_find(const float px, const float py, const fl
 //            on (distance bits << 32 | position) per query — order-independent, hence
 //            deterministic (equal distances resolve to the smaller position).
 // Rounds: the 3 x 3 rows first, then one ring per round while some query's sphere reaches it.
-constexpr int kRowCap = 128, kChunkCap = 256, kChunkLen = 8;
+#ifndef MA_CHUNK
+#define MA_CHUNK 8
+#endif
+#ifndef MA_ROWCAP
+#define MA_ROWCAP 128
+#endif
+#ifndef MA_CHUNKCAP
+#define MA_CHUNKCAP 256
+#endif
+constexpr int kRowCap = MA_ROWCAP, kChunkCap = MA_CHUNKCAP, kChunkLen = MA_CHUNK;
 
 struct WaveLds {
   float4 pos[kWave];
@@ -648,6 +657,7 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     }
     nrow += cnt;
   };
+  // geometric test of row (y, z): can the query's current sphere reach it?
   auto geo = [&](const int y, const int z, float& d2yz) -> bool {
     if ((unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz) return false;
     const float ylo = S.oy + (float)y * c, zlo = S.oz + (float)z * c;
