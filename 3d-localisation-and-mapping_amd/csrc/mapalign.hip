@@ -3,13 +3,16 @@
 // Hot path (the reference body src/map_alignment/align.py is
 // absent, call site /root/reference/task_def.py:175-187):
 //   k_nn_accum   a4+a5  per source point: rigid transform (fp64), exact nearest gold
-//                       point through a uniform grid stored in HBM (ring-expanding row
-//                       walk with distance pruning), distance gate, fp64 accumulation of
-//                       {W, s_p, s_q, S, E}; wavefront shuffle reduction -> one fp64
-//                       partial per workgroup (no float atomics => bitwise reproducible)
-//   k_reduce19   a5     fixed-order sum of the partials, one workgroup per accumulator
-//   k_solve      a6-a7  3x3 Jacobi-SVD Kabsch step, transform composition and convergence
-//                       test on the device, so the loop never synchronises with the host
+//                       point through a uniform grid stored in HBM (wavefront-cooperative
+//                       row / chunk work queues in LDS, ring by ring with distance
+//                       pruning), distance gate, fp64 accumulation of {W, s_p, s_q, S, E};
+//                       DPP + LDS reduction -> one fp64 partial per workgroup (no float
+//                       atomics => bitwise reproducible)
+//   k_reduce_solve a5-a7 fixed-order sum of the partials, one workgroup per accumulator; the
+//                       last-arriving workgroup runs the 3x3 Jacobi-SVD Kabsch step, the
+//                       transform composition and the convergence test
+//                       on the device, so the loop never synchronises with the host
+//   k_reduce19, k_solve the same two halves as separate launches (sharded-source stepping)
 //   k_unproject  a8     depth image -> world points written straight into the source
 //                       cloud buffer (order-preserving compaction of valid pixels)
 // Everything is written for 64-wide wavefronts; there is no MFMA because the path is a
@@ -516,16 +519,9 @@ __device__ __forceinline__ void nn_find(const float px, const float py, const fl
 //            on (distance bits << 32 | position) per query — order-independent, hence
 //            deterministic (equal distances resolve to the smaller position).
 // Rounds: the 3 x 3 rows first, then one ring per round while some query's sphere reaches it.
-#ifndef MA_CHUNK
-#define MA_CHUNK 8
-#endif
-#ifndef MA_ROWCAP
-#define MA_ROWCAP 128
-#endif
-#ifndef MA_CHUNKCAP
-#define MA_CHUNKCAP 256
-#endif
-constexpr int kRowCap = MA_ROWCAP, kChunkCap = MA_CHUNKCAP, kChunkLen = MA_CHUNK;
+// capacities per wavefront (A/B on MI355X: doubling them costs occupancy, 3.39 vs 3.08 ms;
+// halving 3.12; chunks of 4, 6, 12 candidates: 3.39, 3.28, 3.30 ms against 3.08 for 8)
+constexpr int kRowCap = 128, kChunkCap = 256, kChunkLen = 8;
 
 struct WaveLds {
   float4 pos[kWave];
@@ -877,17 +873,12 @@ __global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ 
   if (threadIdx.x == 0) acc_out[k] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-// a6 + a7: one wavefront, lane 0: Kabsch step from the 19 reduced values, transform
-// composition, convergence test, trace row.  (Kept out of the search kernel: its fp64
-// Jacobi code needs ~110 VGPRs and would halve the occupancy of the search.)
-__global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_in, DevState* __restrict__ st,
-                                                 double* __restrict__ trace, const int trace_cap,
-                                                 const double tol) {
-  if (st->done || threadIdx.x != 0) return;
+// a6 + a7 for one thread: Kabsch step from the 19 reduced values, transform composition,
+// convergence test, trace row.  (Kept out of the search kernel: its fp64 Jacobi code needs
+// ~110 VGPRs and would halve the occupancy of the search.)
+__device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState* __restrict__ st,
+                                           double* __restrict__ trace, const int trace_cap, const double tol) {
   DevState s0 = *st;
-  double a[kNAcc];
-#pragma unroll
-  for (int k = 0; k < kNAcc; ++k) a[k] = acc_in[k];
   const int it = s0.iter;
   const double W = a[0];
   const double rmse = W > 0.0 ? sqrt(a[16] / W) : NAN;
@@ -925,6 +916,59 @@ __global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_
   }
   s0.prev_rmse = rmse;
   *st = s0;
+}
+
+// The solve alone (sharded-source stepping: the 17 sums come back from the all-reduce).
+__global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_in, DevState* __restrict__ st,
+                                                 double* __restrict__ trace, const int trace_cap,
+                                                 const double tol) {
+  if (st->done || threadIdx.x != 0) return;
+  double a[kNAcc];
+#pragma unroll
+  for (int k = 0; k < kNAcc; ++k) a[k] = acc_in[k];
+  solve_step(a, st, trace, trace_cap, tol);
+}
+
+// a5 (final sum) + a6 + a7 in ONE launch: the 19 reducing workgroups of k_reduce19, and the
+// one whose arrival ticket comes back last runs the solve (saves a dependent launch, ~4 us
+// of every iteration).  Hand-off across CUs / XCDs without L2 write-back fences: each sum is
+// stored write-through (agent-scope relaxed atomic store = `sc1`), drained (`vmcnt(0)`),
+// then the same lane takes its ticket with an agent-scope atomic add; the last arriver reads
+// the 19 sums with agent-scope relaxed loads (`sc1`, never L1-served) after its add returned.
+__global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restrict__ partials, const int G,
+                                                         DevState* __restrict__ st, double* __restrict__ acc_out,
+                                                         uint32_t* __restrict__ ticket, double* __restrict__ trace,
+                                                         const int trace_cap, const double tol) {
+  if (st->done) return;   // (written only by the last arriver, after every workgroup got past this line)
+  const int k = blockIdx.x;
+  const double* __restrict__ p = partials + (size_t)k * G;
+  double v = 0.0;
+  for (int b0 = threadIdx.x; b0 < G; b0 += 8 * kBlock) {
+    double u[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int b = b0 + t * kBlock;
+      u[t] = b < G ? p[b] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v += u[t];
+  }
+  __shared__ double red[kBlock / kWave];
+  v = wave_sum(v);
+  if ((threadIdx.x & (kWave - 1)) == kSumLane) red[threadIdx.x / kWave] = v;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  __hip_atomic_store(&acc_out[k], ((red[0] + red[1]) + red[2]) + red[3], __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (arrived != (uint32_t)(kNAcc - 1)) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (compiler barrier: the loads below stay below the add)
+  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  double a[kNAcc];
+#pragma unroll
+  for (int t = 0; t < kNAcc; ++t) a[t] = __hip_atomic_load(&acc_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  solve_step(a, st, trace, trace_cap, tol);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1151,7 +1195,7 @@ struct ma_ctx {
   DevBuf raw, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
 
   // loop state
-  DevBuf state, partials, trace, acc19, nn_idx, nn_d2, nn_tmp, prev;
+  DevBuf state, partials, trace, acc19, ticket, nn_idx, nn_d2, nn_tmp, prev;
   int trace_cap = 0;
   int last_G = 0;
   std::vector<hipEvent_t> kev;   // MA_FLAG_TIME_KERNELS
@@ -1343,6 +1387,10 @@ int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
   HIPCHK(ctx->state.ensure(sizeof(DevState)));
   HIPCHK(ctx->partials.ensure((size_t)kNAcc * grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(double)));
   HIPCHK(ctx->acc19.ensure(kNAcc * sizeof(double)));
+  if (!ctx->ticket.p) {   // arrival counter of k_reduce_solve: every launch leaves it at 0 again
+    HIPCHK(ctx->ticket.ensure(sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(ctx->ticket.p, 0, sizeof(uint32_t), ctx->stream));
+  }
   if (trace_rows > ctx->trace_cap) {
     HIPCHK(ctx->trace.ensure((size_t)trace_rows * MA_TRACE_STRIDE * sizeof(double)));
     ctx->trace_cap = trace_rows;
@@ -1388,6 +1436,15 @@ int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float
 int launch_reduce(ma_ctx* ctx) {
   hipLaunchKernelGGL(k_reduce19, dim3(kNAcc), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
                      ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>());
+  HIPCHK(hipGetLastError());
+  return MA_OK;
+}
+
+// the same sum plus the solve by the last-arriving workgroup, one launch
+int launch_reduce_solve(ma_ctx* ctx, double tol) {
+  hipLaunchKernelGGL(k_reduce_solve, dim3(kNAcc), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
+                     ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>(), ctx->ticket.as<uint32_t>(),
+                     ctx->trace.as<double>(), ctx->trace_cap, tol);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
@@ -1483,7 +1540,7 @@ int ma_destroy(ma_ctx* ctx) {
   for (int l = 0; l < kLevels; ++l) { ctx->gold[l].release(); ctx->cstart[l].release(); }
   for (DevBuf* b : {&ctx->map_pts, &ctx->map_keys_a, &ctx->map_keys_b, &ctx->map_flags, &ctx->map_seg, &ctx->perm0, &ctx->inv0, &ctx->occ_a, &ctx->occ_b, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
                     &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc, &ctx->depth_in,
-                    &ctx->state, &ctx->partials, &ctx->trace, &ctx->acc19, &ctx->nn_idx, &ctx->nn_d2,
+                    &ctx->state, &ctx->partials, &ctx->trace, &ctx->acc19, &ctx->ticket, &ctx->nn_idx, &ctx->nn_d2,
                     &ctx->nn_tmp, &ctx->prev})
     b->release();
   for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
@@ -2015,8 +2072,7 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   for (int k = 0; k < params->max_iter; ++k) {
     if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
-    if ((rc = launch_reduce(ctx))) return rc;
-    if ((rc = launch_solve(ctx, params->tol))) return rc;
+    if ((rc = launch_reduce_solve(ctx, params->tol))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 2], ctx->stream));
   }
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));

@@ -22,6 +22,7 @@ FETCH_SIZE
 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum TCC_READ_sum
 GRBM_GUI_ACTIVE GRBM_TA_BUSY
+SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU
 GROUPS
 cd $R
 python3 tools/pmc_summary.py $OUT

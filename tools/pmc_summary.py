@@ -14,7 +14,7 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recu
     for (did, k), vals in per_disp.items():
         by_kernel[k].append(vals)
     for k, lst in by_kernel.items():
-        short = "k_nn_accum" if "k_nn_accum" in k else ("k_reduce_solve" if "k_reduce_solve" in k else None)
+        short = "k_nn_accum" if "k_nn_accum" in k else ("k_reduce19" if "k_reduce19" in k else ("k_solve" if "k_solve" in k else None))
         if not short:
             continue
         lst = lst[-50:]
@@ -26,7 +26,8 @@ for k in agg:
     lines.append(f"== {k} (avg per dispatch over the last {max(len(v) for v in agg[k].values())} dispatches)")
     for c in sorted(agg[k]):
         v = agg[k][c]
-        lines.append(f"  {c:45s} {sum(v)/len(v):18.1f}   (min {min(v):.0f} max {max(v):.0f})")
+        early, late = v[:10], v[-10:]
+        lines.append(f"  {c:45s} {sum(v)/len(v):18.1f}   (min {min(v):.0f} max {max(v):.0f}; first 10: {sum(early)/len(early):.0f}, last 10: {sum(late)/len(late):.0f})")
 txt = "\n".join(lines)
 print(txt)
 if out:
