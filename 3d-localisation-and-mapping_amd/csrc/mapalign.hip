@@ -717,11 +717,34 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
 #ifndef MA_XCD_SEG
 #define MA_XCD_SEG 16
 #endif
-__device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t G) {
-  constexpr uint32_t S = MA_XCD_SEG;
-  if (G % (8u * S) != 0u) return b;                     // (the host rounds G up to a multiple of 8 * S)
-  const uint32_t xcd = b % 8u, seg = b / 8u;            // seg: index among this XCD's workgroups
-  return ((seg / S) * 8u + xcd) * S + seg % S;
+constexpr uint32_t kXcdSeg = MA_XCD_SEG;
+#ifndef MA_SCHED
+#define MA_SCHED 1
+#endif
+constexpr int kMaxGroups = 512;   // scheduling groups (of 2^gshift segments) ranked by cost
+
+// Longest-first schedule.  While the clouds are still apart, the workgroups whose points find
+// no gold point inside the gate walk whole gate spheres and run 3-5x longer than the median;
+// dispatched in cloud order they left the second half of a launch at < 30 % occupancy (tail
+// of 50 us in a 100-us launch, tools/wgtimeline.py).  Every workgroup therefore records its
+// duration, k_reduce_solve ranks the segments (in groups) by the previous iteration's cost,
+// and the next launch hands them out most expensive first — dealt over the XCDs in that
+// order, which also evens out the XCDs.  The schedule decides only WHEN a chunk is
+// processed: partials are indexed by chunk, so sums (and results) do not depend on it.
+struct Sched {
+  uint32_t* __restrict__ wg_cost;           // [G] duration of the workgroup that processed chunk g (100 MHz ticks)
+  const uint32_t* __restrict__ order;       // [G / kXcdSeg >> gshift] group ids, most expensive first; null: cloud order
+  uint32_t gshift;
+};
+
+__device__ __forceinline__ uint32_t xcd_chunk(const uint32_t b, const Sched& sc, const bool use_order) {
+  const uint32_t xcd = b % 8u, slot = b / 8u;            // slot: index among this XCD's workgroups
+  uint32_t segpos = (slot / kXcdSeg) * 8u + xcd;         // position of the segment in the schedule
+  if (use_order) {
+    const uint32_t gp = segpos >> sc.gshift;
+    segpos = (sc.order[gp] << sc.gshift) + (segpos - (gp << sc.gshift));
+  }
+  return segpos * kXcdSeg + slot % kXcdSeg;
 }
 
 // a4 + a5 fused.  MODE 0: accumulate only; MODE 1: per-point (idx, d2) only (ma_nn).
@@ -732,16 +755,23 @@ __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t G) {
 #define MA_WAVEQ 1
 #endif
 
+#if MA_WGTIMES   // debug variant only (tools/wgtimeline.py): start/end clock and placement of every workgroup
+__device__ unsigned long long g_wgt[64][4096][2];
+__device__ uint32_t g_wghw[64][4096][2];
+#endif
+
 template <bool COUNT, int MODE>
 __global__ __launch_bounds__(kNNBlock) void k_nn_accum(
     const float4* __restrict__ src, const uint32_t n, const LevelSet S,
     const uint32_t* __restrict__ perm0, const DevState* __restrict__ st, const float best2_init,
     double* __restrict__ partials, uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2) {
+    float* __restrict__ nn_d2, const Sched sched) {
   if (MODE == 0 && st->done) return;
+  const unsigned long long wg_start = wall_clock64();
   constexpr int kNW = kNNBlock / kWave;
   const uint32_t G = gridDim.x;
-  const uint32_t i = xcd_chunk(blockIdx.x, G) * kNNBlock + threadIdx.x;
+  const uint32_t chunk = xcd_chunk(blockIdx.x, sched, sched.order != nullptr && st->iter > 0);
+  const uint32_t i = chunk * kNNBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   // per-wavefront LDS: the work queues during the search, the group sums afterwards
   union WaveShared {
@@ -841,8 +871,17 @@ __global__ __launch_bounds__(kNNBlock) void k_nn_accum(
 #pragma unroll
       for (int t = 0; t < kParts; ++t) v += sh_part[k][t];
     }
-    partials[(size_t)k * G + blockIdx.x] = v;
+    partials[(size_t)k * G + chunk] = v;
   }
+  if (threadIdx.x == 0 && sched.wg_cost) sched.wg_cost[chunk] = (uint32_t)(wall_clock64() - wg_start);
+#if MA_WGTIMES
+  if (threadIdx.x == 0 && MODE == 0 && st->iter < 64 && blockIdx.x < 4096) {
+    g_wgt[st->iter][blockIdx.x][0] = wg_start;
+    g_wgt[st->iter][blockIdx.x][1] = wall_clock64();
+    g_wghw[st->iter][blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+    g_wghw[st->iter][blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+  }
+#endif
 }
 
 // a5 (final sum): one workgroup PER ACCUMULATOR sums that accumulator's G partials — 19
@@ -935,11 +974,37 @@ __global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_
 // stored write-through (agent-scope relaxed atomic store = `sc1`), drained (`vmcnt(0)`),
 // then the same lane takes its ticket with an agent-scope atomic add; the last arriver reads
 // the 19 sums with agent-scope relaxed loads (`sc1`, never L1-served) after its add returned.
+//
+// One more workgroup (blockIdx kNAcc, beside the sums, not part of the hand-off) ranks the
+// scheduling groups by the cost the search kernel just recorded: order[r] = the group with
+// the r-th largest cost, ties by index (rank by counting, <= 512 groups).
 __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restrict__ partials, const int G,
                                                          DevState* __restrict__ st, double* __restrict__ acc_out,
                                                          uint32_t* __restrict__ ticket, double* __restrict__ trace,
-                                                         const int trace_cap, const double tol) {
+                                                         const int trace_cap, const double tol,
+                                                         const uint32_t* __restrict__ wg_cost,
+                                                         uint32_t* __restrict__ order, const uint32_t gshift) {
   if (st->done) return;   // (written only by the last arriver, after every workgroup got past this line)
+  if (blockIdx.x == kNAcc) {
+    __shared__ uint32_t cost[kMaxGroups];
+    const uint32_t per = kXcdSeg << gshift, ngroups = (uint32_t)G / per;   // chunks per group; <= kMaxGroups
+    for (uint32_t g = threadIdx.x; g < ngroups; g += kBlock) {
+      uint32_t c = 0;
+      for (uint32_t t = 0; t < per; ++t) c += wg_cost[g * per + t] >> gshift;   // (no overflow: 2^28 ticks = 2.7 s)
+      cost[g] = c;
+    }
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < ngroups; g += kBlock) {
+      const uint32_t c = cost[g];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < ngroups; ++j) {
+        const uint32_t cj = cost[j];
+        rank += (cj > c || (cj == c && j < g)) ? 1u : 0u;
+      }
+      order[rank] = g;
+    }
+    return;
+  }
   const int k = blockIdx.x;
   const double* __restrict__ p = partials + (size_t)k * G;
   double v = 0.0;
@@ -1195,9 +1260,10 @@ struct ma_ctx {
   DevBuf raw, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
 
   // loop state
-  DevBuf state, partials, trace, acc19, ticket, nn_idx, nn_d2, nn_tmp, prev;
+  DevBuf state, partials, trace, acc19, ticket, wg_cost, seg_order, nn_idx, nn_d2, nn_tmp, prev;
   int trace_cap = 0;
   int last_G = 0;
+  uint32_t last_gshift = 0;
   std::vector<hipEvent_t> kev;   // MA_FLAG_TIME_KERNELS
   double ktimes[4] = {0, 0, 0, 0};
 
@@ -1377,16 +1443,26 @@ int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, 
   return MA_OK;
 }
 
-// one source point per thread; G a multiple of 8 * MA_XCD_SEG so that the XCD remap is a bijection
-uint32_t grid_for(uint32_t n) {
-  const uint32_t G = div_up(n, kNNBlock), q = 8u * MA_XCD_SEG;
-  return std::max<uint32_t>(q, (G + q - 1u) / q * q);
+// One source point per thread.  G is a multiple of 8 * kXcdSeg (the XCD remap is a
+// bijection) and of kXcdSeg << gshift, where 2^gshift segments form one scheduling group
+// and there are at most kMaxGroups groups (the surplus workgroups have no points).
+uint32_t grid_for(uint32_t n, uint32_t* gshift_out = nullptr) {
+  const uint32_t q = 8u * kXcdSeg;
+  uint32_t G = std::max<uint32_t>(q, (div_up(n, kNNBlock) + q - 1u) / q * q);
+  uint32_t gshift = 0;
+  while (((G / kXcdSeg) >> gshift) > (uint32_t)kMaxGroups) ++gshift;
+  const uint32_t unit = std::max<uint32_t>(q, kXcdSeg << gshift);   // both are powers of two
+  G = (G + unit - 1u) / unit * unit;
+  if (gshift_out) *gshift_out = gshift;
+  return G;
 }
 
 int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
   HIPCHK(ctx->state.ensure(sizeof(DevState)));
   HIPCHK(ctx->partials.ensure((size_t)kNAcc * grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(double)));
   HIPCHK(ctx->acc19.ensure(kNAcc * sizeof(double)));
+  HIPCHK(ctx->wg_cost.ensure((size_t)grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(uint32_t)));
+  HIPCHK(ctx->seg_order.ensure((size_t)kMaxGroups * sizeof(uint32_t)));
   if (!ctx->ticket.p) {   // arrival counter of k_reduce_solve: every launch leaves it at 0 again
     HIPCHK(ctx->ticket.ensure(sizeof(uint32_t)));
     HIPCHK(hipMemsetAsync(ctx->ticket.p, 0, sizeof(uint32_t), ctx->stream));
@@ -1416,15 +1492,20 @@ int upload_state(ma_ctx* ctx, const double* T) {
 
 
 
+// `scheduled`: inside the ma_icp loop (costs recorded, longest-first order from iteration 1 on)
 template <int MODE>
-int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2) {
-  const uint32_t G = grid_for(ctx->n);
+int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2, bool scheduled = false) {
+  uint32_t gshift = 0;
+  const uint32_t G = grid_for(ctx->n, &gshift);
   ctx->last_G = (int)G;
+  ctx->last_gshift = gshift;
+  Sched sched{nullptr, nullptr, gshift};
+  if (scheduled) { sched.wg_cost = ctx->wg_cost.as<uint32_t>(); sched.order = ctx->seg_order.as<uint32_t>(); }
   auto args = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(G), dim3(kNNBlock), 0, ctx->stream, ctx->src.as<float4>(), ctx->n,
                        ctx->levels, ctx->perm0.as<uint32_t>(), ctx->state.as<DevState>(), best2_init,
                        ctx->partials.as<double>(),
-                       MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, nn_idx, nn_d2);
+                       MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, nn_idx, nn_d2, sched);
   };
   if (count) args(k_nn_accum<true, MODE>);
   else args(k_nn_accum<false, MODE>);
@@ -1442,9 +1523,10 @@ int launch_reduce(ma_ctx* ctx) {
 
 // the same sum plus the solve by the last-arriving workgroup, one launch
 int launch_reduce_solve(ma_ctx* ctx, double tol) {
-  hipLaunchKernelGGL(k_reduce_solve, dim3(kNAcc), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
+  hipLaunchKernelGGL(k_reduce_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
                      ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>(), ctx->ticket.as<uint32_t>(),
-                     ctx->trace.as<double>(), ctx->trace_cap, tol);
+                     ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(),
+                     ctx->seg_order.as<uint32_t>(), ctx->last_gshift);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
@@ -1540,7 +1622,7 @@ int ma_destroy(ma_ctx* ctx) {
   for (int l = 0; l < kLevels; ++l) { ctx->gold[l].release(); ctx->cstart[l].release(); }
   for (DevBuf* b : {&ctx->map_pts, &ctx->map_keys_a, &ctx->map_keys_b, &ctx->map_flags, &ctx->map_seg, &ctx->perm0, &ctx->inv0, &ctx->occ_a, &ctx->occ_b, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
                     &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc, &ctx->depth_in,
-                    &ctx->state, &ctx->partials, &ctx->trace, &ctx->acc19, &ctx->ticket, &ctx->nn_idx, &ctx->nn_d2,
+                    &ctx->state, &ctx->partials, &ctx->trace, &ctx->acc19, &ctx->ticket, &ctx->wg_cost, &ctx->seg_order, &ctx->nn_idx, &ctx->nn_d2,
                     &ctx->nn_tmp, &ctx->prev})
     b->release();
   for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
@@ -2070,7 +2152,7 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   if (timek) HIPCHK(hipEventRecord(ctx->kev[0], ctx->stream));
   for (int k = 0; k < params->max_iter; ++k) {
-    if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr))) return rc;
+    if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr, MA_SCHED != 0))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
     if ((rc = launch_reduce_solve(ctx, params->tol))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 2], ctx->stream));
@@ -2115,6 +2197,14 @@ int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {
   }
   return rows;
 }
+
+#if MA_WGTIMES
+int ma_debug_wgtimes(ma_ctx* ctx, unsigned long long* times, uint32_t* hw) {
+  HIPCHK(hipMemcpyFromSymbol(times, HIP_SYMBOL(g_wgt), sizeof(g_wgt)));
+  HIPCHK(hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_wghw), sizeof(g_wghw)));
+  return MA_OK;
+}
+#endif
 
 int ma_get_kernel_times(ma_ctx* ctx, double out[4]) {
   if (!ctx || !out) return MA_ERR_INVALID;

@@ -3,7 +3,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 libdir = os.path.join(ROOT, "3d-localisation-and-mapping_amd", "lib")
 cell = sys.argv[1] if len(sys.argv) > 1 else "0.035"
-names = [""] + sorted(f[len("libmapalign_"):-3] for f in os.listdir(libdir) if f.startswith("libmapalign_"))
+names = [""] + sorted(f[len("libmapalign_"):-3] for f in os.listdir(libdir) if f.startswith("libmapalign_") and f != "libmapalign_wgt.so")
 code = r'''
 import sys, os
 sys.path.insert(0, os.path.join(%r, "3d-localisation-and-mapping_amd"))
