@@ -522,6 +522,9 @@ __device__ __forceinline__ void nn_find(const float px, const float py, const fl
 // capacities per wavefront (A/B on MI355X: doubling them costs occupancy, 3.39 vs 3.08 ms;
 // halving 3.12; chunks of 4, 6, 12 candidates: 3.39, 3.28, 3.30 ms against 3.08 for 8)
 constexpr int kRowCap = 128, kChunkCap = 256, kChunkLen = 8;
+#ifndef MA_ROWS_PER_TRIP
+#define MA_ROWS_PER_TRIP 2
+#endif
 
 struct WaveLds {
   float4 pos[kWave];
@@ -577,47 +580,58 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
   const uint32_t* __restrict__ cs0 = S.cs[0];
   const float inv_c = S.inv_c[0];
   const int nx = S.nx[0];
-  for (uint32_t i0 = 0; i0 < nrow; i0 += kWave) {
-    const uint32_t i = i0 + lane;
-    uint32_t a = 0, b = 0, lq = 0;
-    if (i < nrow) {
-      lq = W.row_lane[i];
-      const float d2yz = W.row_d2yz[i];
-      const float4 p = W.pos[lq];
-      const float b2 = __uint_as_float((uint32_t)(W.best[lq] >> 32));
-      if (d2yz < b2) {
-        const float rx = fast_sqrt(b2 - d2yz) + S.delta;
-        const int x0 = (int)fmaxf(floorf((p.x - rx - S.ox) * inv_c), 0.f);
-        const int x1 = (int)fminf(floorf((p.x + rx - S.ox) * inv_c), (float)(nx - 1));
-        if (x0 <= x1) {
-          const uint32_t cell = W.row_cell[i] + (uint32_t)x0;
-          const int span = x1 - x0;
-          if (span <= 2) {
-            const u4_unaligned v = ld_cell4(cs0, cell);
-            a = v.x;
-            b = span == 0 ? v.y : (span == 1 ? v.z : v.w);
-          } else {
-            a = ld_cell(cs0, cell);
-            b = ld_cell(cs0, cell + (uint32_t)span + 1u);
+  // MA_ROWS_PER_TRIP row items per lane and trip: their table reads are in flight together
+  // (a lone wavefront in the tail of a launch has nobody else to hide that latency).
+  // Measured: 1 / 2 / 3 / 4 items -> 2.95 / 2.77 / 2.96 / 3.04 ms (3 and 4 cross 64 VGPRs);
+  // two chunk items per trip in wq_flush_chunks: 118 VGPRs, 3.62 ms.
+  for (uint32_t i0 = 0; i0 < nrow; i0 += MA_ROWS_PER_TRIP * kWave) {
+    uint32_t a[MA_ROWS_PER_TRIP], b[MA_ROWS_PER_TRIP], lq[MA_ROWS_PER_TRIP];
+#pragma unroll
+    for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
+      const uint32_t i = i0 + (uint32_t)u * kWave + lane;
+      a[u] = 0; b[u] = 0; lq[u] = 0;
+      if (i < nrow) {
+        lq[u] = W.row_lane[i];
+        const float d2yz = W.row_d2yz[i];
+        const float4 p = W.pos[lq[u]];
+        const float b2 = __uint_as_float((uint32_t)(W.best[lq[u]] >> 32));
+        if (d2yz < b2) {
+          const float rx = fast_sqrt(b2 - d2yz) + S.delta;
+          const int x0 = (int)fmaxf(floorf((p.x - rx - S.ox) * inv_c), 0.f);
+          const int x1 = (int)fminf(floorf((p.x + rx - S.ox) * inv_c), (float)(nx - 1));
+          if (x0 <= x1) {
+            const uint32_t cell = W.row_cell[i] + (uint32_t)x0;
+            const int span = x1 - x0;
+            if (span <= 2) {
+              const u4_unaligned v = ld_cell4(cs0, cell);
+              a[u] = v.x;
+              b[u] = span == 0 ? v.y : (span == 1 ? v.z : v.w);
+            } else {
+              a[u] = ld_cell(cs0, cell);
+              b[u] = ld_cell(cs0, cell + (uint32_t)span + 1u);
+            }
+            if (COUNT) nrows_cnt += span <= 2 ? 4u : 2u;
           }
-          if (COUNT) nrows_cnt += span <= 2 ? 4u : 2u;
         }
       }
     }
     // cut [a,b) into chunks; trip k pushes chunk k of every lane that still has one
-    for (uint32_t k = 0;; ++k) {
-      const bool has = a + k * kChunkLen < b;
-      const unsigned long long mask = __ballot(has);
-      if (mask == 0ull) break;
-      const uint32_t cnt = (uint32_t)__popcll(mask);
-      if (nchunk + cnt > (uint32_t)kChunkCap) wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
-      if (has) {
-        const uint32_t pos = nchunk + lane_prefix(mask), ca = a + k * kChunkLen;
-        W.chunk_a[pos] = ca;
-        W.chunk_lane[pos] = (uint8_t)lq;
-        W.chunk_cnt[pos] = (uint8_t)min((uint32_t)kChunkLen, b - ca);
+#pragma unroll
+    for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
+      for (uint32_t k = 0;; ++k) {
+        const bool has = a[u] + k * kChunkLen < b[u];
+        const unsigned long long mask = __ballot(has);
+        if (mask == 0ull) break;
+        const uint32_t cnt = (uint32_t)__popcll(mask);
+        if (nchunk + cnt > (uint32_t)kChunkCap) wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
+        if (has) {
+          const uint32_t pos = nchunk + lane_prefix(mask), ca = a[u] + k * kChunkLen;
+          W.chunk_a[pos] = ca;
+          W.chunk_lane[pos] = (uint8_t)lq[u];
+          W.chunk_cnt[pos] = (uint8_t)min((uint32_t)kChunkLen, b[u] - ca);
+        }
+        nchunk += cnt;
       }
-      nchunk += cnt;
     }
   }
   nrow = 0;
