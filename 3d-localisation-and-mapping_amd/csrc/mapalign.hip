@@ -667,23 +667,26 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     }
     nrow += cnt;
   };
-  // geometric test of row (y, z): can the query's current sphere reach it?
-  auto geo = [&](const int y, const int z, float& d2yz) -> bool {
-    if ((unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz) return false;
-    const float ylo = S.oy + (float)y * c, zlo = S.oz + (float)z * c;
-    const float dyq = fmaxf(0.f, fmaxf(ylo - S.delta - py, py - (ylo + c + S.delta)));
-    const float dzq = fmaxf(0.f, fmaxf(zlo - S.delta - pz, pz - (zlo + c + S.delta)));
-    d2yz = dyq * dyq + dzq * dzq;
-    return d2yz < best2;
-  };
 
-  // ---- round 0: the 3 x 3 rows (rings 0 and 1), centre row first
+  // ---- round 0: the 3 x 3 rows (rings 0 and 1), centre row first.  The row test is
+  // separable: squared gap to the slab of cells at offset d along y, and along z (6 values),
+  // then one add and one compare per row (the direct form costs 22 VALU ops per row, a
+  // quarter of a converged iteration).  Same bounds up to rounding, which `delta` covers.
+  const float fy = py - (S.oy + (float)cy * c), fz = pz - (S.oz + (float)cz * c);
+  auto gap2 = [&](const int d, const float f, const int ci, const int n) -> float {
+    const float lo = ((float)d * c - S.delta) - f, hi = f - ((float)(d + 1) * c + S.delta);
+    const float t = fmaxf(0.f, fmaxf(lo, hi));
+    return (unsigned)(ci + d) < (unsigned)n ? t * t : INFINITY;
+  };
+  {
+    const float gy[3] = {gap2(0, fy, cy, ny), gap2(-1, fy, cy, ny), gap2(1, fy, cy, ny)};
+    const float gz[3] = {gap2(0, fz, cz, nz), gap2(-1, fz, cz, nz), gap2(1, fz, cz, nz)};
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const int dy = (k % 3 == 0) ? 0 : (k % 3 == 1 ? -1 : 1), dz = (k / 3 == 0) ? 0 : (k / 3 == 1 ? -1 : 1);
-    float d2yz = 0.f;
-    const bool pred = finite && geo(cy + dy, cz + dz, d2yz);
-    push_row(pred, cy + dy, cz + dz, d2yz);
+    for (int k = 0; k < 9; ++k) {
+      const int dy = (k % 3 == 0) ? 0 : (k % 3 == 1 ? -1 : 1), dz = (k / 3 == 0) ? 0 : (k / 3 == 1 ? -1 : 1);
+      const float d2yz = gy[k % 3] + gz[k / 3];
+      push_row(finite && d2yz < best2, cy + dy, cz + dz, d2yz);
+    }
   }
   wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
   wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
@@ -702,16 +705,20 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     const float lb = (float)(r - 1) * c - S.delta;
     more = more && r <= rmax && lb * lb < best2;
     if (!__any(more)) break;
-    for (int k = 0; k < 8 * r; ++k) {
-      const int side = k / (2 * r), o = k - side * 2 * r;     // wave-uniform
-      int dy, dz;
-      if (side == 0)      { dy = o - r; dz = -r; }
-      else if (side == 1) { dy = r;     dz = o - r; }
-      else if (side == 2) { dy = r - o; dz = r; }
-      else                { dy = -r;    dz = r - o; }
-      float d2yz = 0.f;
-      const bool pred = more && geo(cy + dy, cz + dz, d2yz);
-      push_row(pred, cy + dy, cz + dz, d2yz);
+    // the four sides of the ring; along a side one offset is fixed, so a row costs one gap
+    // evaluation, one add and one compare
+    for (int side = 0; side < 4; ++side) {
+      const bool zfixed = (side & 1) == 0;                    // sides 0, 2: dz = -r, +r; sides 1, 3: dy = +r, -r
+      const int dfix = (side == 0 || side == 3) ? -r : r;
+      const float ffix = zfixed ? fz : fy, fvar = zfixed ? fy : fz;
+      const int cfix = zfixed ? cz : cy, cvar = zfixed ? cy : cz, nfix = zfixed ? nz : ny, nvar = zfixed ? ny : nz;
+      const float gfix = gap2(dfix, ffix, cfix, nfix);
+      for (int o = 0; o < 2 * r; ++o) {
+        const int dvar = side < 2 ? o - r : r - o;
+        const float d2yz = gfix + gap2(dvar, fvar, cvar, nvar);
+        const int dy = zfixed ? dvar : dfix, dz = zfixed ? dfix : dvar;
+        push_row(more && d2yz < best2, cy + dy, cz + dz, d2yz);
+      }
     }
     wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
     wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
@@ -774,8 +781,13 @@ __device__ unsigned long long g_wgt[64][4096][2];
 __device__ uint32_t g_wghw[64][4096][2];
 #endif
 
+#ifdef MA_NN_WAVES
+#define MA_NN_ATTR __attribute__((amdgpu_waves_per_eu(MA_NN_WAVES, MA_NN_WAVES)))
+#else
+#define MA_NN_ATTR
+#endif
 template <bool COUNT, int MODE>
-__global__ __launch_bounds__(kNNBlock) void k_nn_accum(
+__global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     const float4* __restrict__ src, const uint32_t n, const LevelSet S,
     const uint32_t* __restrict__ perm0, const DevState* __restrict__ st, const float best2_init,
     double* __restrict__ partials, uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx,
@@ -795,15 +807,20 @@ __global__ __launch_bounds__(kNNBlock) void k_nn_accum(
   __shared__ WaveShared sh_w[kNW];
 
   const bool has = i < n;
+  // the point and its fp64 image are formed twice, before the search (only the fp32 image
+  // is kept) and again after it: ten registers that the search does not have to carry
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   double Px = 0.0, Py = 0.0, Pz = 0.0;
-  float px = 0.f, py = 0.f, pz = 0.f, best2 = best2_init;
-  uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
-  if (has) {
-    s = src[i];
+  auto image = [&](const uint32_t at) {
+    s = src[at];
     Px = st->R[0] * s.x + st->R[1] * s.y + st->R[2] * s.z + st->t[0];
     Py = st->R[3] * s.x + st->R[4] * s.y + st->R[5] * s.z + st->t[1];
     Pz = st->R[6] * s.x + st->R[7] * s.y + st->R[8] * s.z + st->t[2];
+  };
+  float px = 0.f, py = 0.f, pz = 0.f, best2 = best2_init;
+  uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
+  if (has) {
+    image(i);
     px = (float)Px; py = (float)Py; pz = (float)Pz;
     if (prev) {
       // temporal coherence: last iteration's match bounds the search radius from the start
@@ -828,6 +845,11 @@ __global__ __launch_bounds__(kNNBlock) void k_nn_accum(
   for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
   if (has) {
     if (prev) prev[i] = bestj;
+    if (MODE == 0) {
+      uint32_t again = i;
+      asm volatile("" : "+v"(again));   // opaque copy of the index: the compiler must not keep s, P live instead
+      image(again);
+    }
     if (MODE == 1) {
       nn_idx[i] = bestj != kNoMatch ? perm0[bestj] : kNoMatch;
       nn_d2[i] = bestj != kNoMatch ? best2 : INFINITY;

@@ -14,7 +14,9 @@ eng = mapalign.MapAligner(0); eng.set_gold(g, %s); eng.set_source(c)
 for _ in range(3): r = eng.icp(50, 0.0, 0.1)
 ts = [eng.icp(50, 0.0, 0.1).gpu_ms for _ in range(5)]
 r = eng.icp(50, 0.0, 0.1, time_kernels=True); kt = eng.kernel_times()
-print("%%-14s loop ms min %%.3f med %%.3f | nn avg us %%.1f solve avg us %%.1f | errR %%.3e" %% (os.environ.get("VAR", "default"), min(ts), sorted(ts)[2], kt["nn_ms"]/kt["nn_launches"]*1e3, kt["solve_ms"]/kt["solve_launches"]*1e3, np.linalg.norm(r.R - R0)))
+early = min(eng.icp(10, 0.0, 0.1).gpu_ms for _ in range(5)) / 10 * 1e3
+conv = min(eng.icp(30, 0.0, 0.1, init=r.T).gpu_ms - eng.icp(10, 0.0, 0.1, init=r.T).gpu_ms for _ in range(5)) / 20 * 1e3
+print("%%-14s loop ms min %%.3f med %%.3f | nn avg us %%.1f solve avg us %%.1f | it 0-9: %%.1f us/it, converged: %%.1f us/it | errR %%.3e" %% (os.environ.get("VAR", "default"), min(ts), sorted(ts)[2], kt["nn_ms"]/kt["nn_launches"]*1e3, kt["solve_ms"]/kt["solve_launches"]*1e3, early, conv, np.linalg.norm(r.R - R0)))
 ''' % (ROOT, cell)
 for rep in range(2):
     for n in names:
