@@ -35,14 +35,35 @@ MA_HD inline Col3 cross3(const Col3& a, const Col3& b) {
 }
 MA_HD inline void swap_col(Col3& a, Col3& b) { const Col3 t = a; a = b; b = t; }
 
-// 1/sqrt(x): the device has a hardware seed + refinement (a handful of instructions);
-// an IEEE divide and square root cost ~40 fp64 instructions on one lane, and the solve
-// kernel is exactly one lane of dependent fp64 work.
+// The solve is ONE lane of dependent fp64 work on the device, so its time is its
+// instruction count.  An IEEE divide or square root is ~30 fp64 instructions there (scaling,
+// fix-ups); the hardware seeds (v_rcp_f64, v_rsq_f64: ~26 bits) plus one Newton step are 4-5
+// and accurate to an ulp or two, which is all this needs (the rotation keeps c^2 + s^2 = 1 by
+// construction, see jacobi_rotate).  Operands here are never 0, inf or denormal: every call
+// site is guarded (W >= 3, gamma^2 > 0, singular values checked).  The host build (unit
+// test against numpy) uses the exact operations.
+MA_HD inline double inv_f64(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
+#else
+  return 1.0 / x;
+#endif
+}
 MA_HD inline double rsqrt_f64(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return rsqrt(x);
+  const double y = __builtin_amdgcn_rsq(x);
+  return fma(fma(-x * y, y, 1.0), 0.5 * y, y);
 #else
   return 1.0 / sqrt(x);
+#endif
+}
+MA_HD inline double sqrt_f64(double x) {   // x > 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(x), s = x * y;
+  return fma(fma(-s, s, x), 0.5 * y, s);
+#else
+  return sqrt(x);
 #endif
 }
 
@@ -56,7 +77,7 @@ MA_HD inline double jacobi_rotate(Col3& gp, Col3& gq, Col3& vp, Col3& vq) {
   const double ab = alpha * beta, g2 = gamma * gamma;
   if (g2 <= 1e-300 + 1e-32 * ab) return 0.0;  // already orthogonal
   const double d = beta - alpha;
-  const double t = (d >= 0.0 ? 2.0 : -2.0) * gamma / (fabs(d) + sqrt(d * d + 4.0 * g2));
+  const double t = (d >= 0.0 ? 2.0 : -2.0) * gamma * inv_f64(fabs(d) + sqrt_f64(d * d + 4.0 * g2));
   const double c = rsqrt_f64(1.0 + t * t);
   const double s = c * t;
   const Col3 g0 = gp, g1 = gq, w0 = vp, w1 = vq;
@@ -64,7 +85,7 @@ MA_HD inline double jacobi_rotate(Col3& gp, Col3& gq, Col3& vp, Col3& vq) {
   gq = {s * g0.x + c * g1.x, s * g0.y + c * g1.y, s * g0.z + c * g1.z};
   vp = {c * w0.x - s * w1.x, c * w0.y - s * w1.y, c * w0.z - s * w1.z};
   vq = {s * w0.x + c * w1.x, s * w0.y + c * w1.y, s * w0.z + c * w1.z};
-  return g2 / ab;
+  return g2 * inv_f64(ab);
 }
 
 // A = U Sig V^T for a 3x3 given by its COLUMNS g0,g1,g2 (overwritten by the columns of
@@ -109,25 +130,28 @@ MA_HD inline int kabsch_from_acc(const double* acc, double dR[9], double dt[3]) 
   for (int i = 0; i < kAccLen; ++i) finite = finite && isfinite(acc[i]);
   const double W = acc[0];
   if (!finite || !(W >= kMinCorrespondences)) return 1;
-  const Col3 mp{acc[1] / W, acc[2] / W, acc[3] / W}, mq{acc[4] / W, acc[5] / W, acc[6] / W};
+  const double iW = inv_f64(W);
+  const Col3 mp{acc[1] * iW, acc[2] * iW, acc[3] * iW}, mq{acc[4] * iW, acc[5] * iW, acc[6] * iW};
   // H_ab = S_ab - W mp_a mq_b ; columns of H (index b)
   Col3 g0{acc[7] - W * mp.x * mq.x, acc[10] - W * mp.y * mq.x, acc[13] - W * mp.z * mq.x};
   Col3 g1{acc[8] - W * mp.x * mq.y, acc[11] - W * mp.y * mq.y, acc[14] - W * mp.z * mq.y};
   Col3 g2{acc[9] - W * mp.x * mq.z, acc[12] - W * mp.y * mq.z, acc[15] - W * mp.z * mq.z};
   Col3 v0, v1, v2;
   jacobi_svd3_cols(g0, g1, g2, v0, v1, v2);
-  double s0 = sqrt(dot3(g0, g0)), s1 = sqrt(dot3(g1, g1)), s2 = sqrt(dot3(g2, g2));
+  // squared singular values: their order and the rank test need no square root
+  double s0 = dot3(g0, g0), s1 = dot3(g1, g1), s2 = dot3(g2, g2);
   // order the singular directions (largest first) with conditional swaps
   if (s0 < s1) { swap_col(g0, g1); swap_col(v0, v1); const double t = s0; s0 = s1; s1 = t; }
   if (s1 < s2) { swap_col(g1, g2); swap_col(v1, v2); const double t = s1; s1 = s2; s2 = t; }
   if (s0 < s1) { swap_col(g0, g1); swap_col(v0, v1); const double t = s0; s0 = s1; s1 = t; }
-  if (!(s1 > 1e-12 * s0) || !(s0 > 0.0)) return 1;
+  if (!(s1 > 1e-24 * s0) || !(s0 > 0.0)) return 1;   // sigma_1 <= 1e-12 sigma_0: rank < 2
   // U columns of the two leading directions; the third of BOTH frames is the cross product
   // of the first two.  That covers a vanishing third singular value (planar
   // correspondences) and makes both frames right-handed, so
   //   dR = v0 u0^T + v1 u1^T + (v0 x v1)(u0 x u1)^T
   // has det +1: it IS V diag(1,1,det(V U^T)) U^T with the flip on the smallest direction.
-  const Col3 u0{g0.x / s0, g0.y / s0, g0.z / s0}, u1{g1.x / s1, g1.y / s1, g1.z / s1};
+  const double i0 = rsqrt_f64(s0), i1 = rsqrt_f64(s1);
+  const Col3 u0{g0.x * i0, g0.y * i0, g0.z * i0}, u1{g1.x * i1, g1.y * i1, g1.z * i1};
   const Col3 u2 = cross3(u0, u1), w2 = cross3(v0, v1);
   dR[0] = v0.x * u0.x + v1.x * u1.x + w2.x * u2.x;
   dR[1] = v0.x * u0.y + v1.x * u1.y + w2.x * u2.y;

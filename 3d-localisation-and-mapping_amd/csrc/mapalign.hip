@@ -951,9 +951,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ 
 // a6 + a7 for one thread: Kabsch step from the 19 reduced values, transform composition,
 // convergence test, trace row.  (Kept out of the search kernel: its fp64 Jacobi code needs
 // ~110 VGPRs and would halve the occupancy of the search.)
-__device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState* __restrict__ st,
+__device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0, DevState* __restrict__ st,
                                            double* __restrict__ trace, const int trace_cap, const double tol) {
-  DevState s0 = *st;
   const int it = s0.iter;
   const double W = a[0];
   const double rmse = W > 0.0 ? sqrt(a[16] / W) : NAN;
@@ -967,7 +966,12 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState* _
   s0.last_rmse = rmse;
   s0.last_W = W;
   double dR[9], dt[3];
+#ifdef MA_NOSOLVE
+  dR[0] = dR[4] = dR[8] = 1.0; dR[1] = dR[2] = dR[3] = dR[5] = dR[6] = dR[7] = 0.0; dt[0] = dt[1] = dt[2] = 0.0;
+  if (false) {
+#else
   if (ma::kabsch_from_acc(a, dR, dt)) {
+#endif
     s0.degenerate = 1;
     s0.done = 1;
     *st = s0;
@@ -1001,7 +1005,7 @@ __global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_
   double a[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) a[k] = acc_in[k];
-  solve_step(a, st, trace, trace_cap, tol);
+  solve_step(a, *st, st, trace, trace_cap, tol);
 }
 
 // a5 (final sum) + a6 + a7 in ONE launch: the 19 reducing workgroups of k_reduce19, and the
@@ -1020,40 +1024,57 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
                                                          const int trace_cap, const double tol,
                                                          const uint32_t* __restrict__ wg_cost,
                                                          uint32_t* __restrict__ order, const uint32_t gshift) {
-  if (st->done) return;   // (written only by the last arriver, after every workgroup got past this line)
+  // `done` is written only by the last arriver, after every workgroup has read it.  It is
+  // tested AFTER the first loads have been issued: every dependent memory round trip of
+  // this small kernel is ~1 us of the iteration.
+  const int done = st->done;
   if (blockIdx.x == kNAcc) {
-    __shared__ uint32_t cost[kMaxGroups];
-    const uint32_t per = kXcdSeg << gshift, ngroups = (uint32_t)G / per;   // chunks per group; <= kMaxGroups
+    // key = (cost, reversed index): unique, so the rank is a plain count of larger keys
+    __shared__ __attribute__((aligned(16))) uint32_t key[kMaxGroups];
+    const uint32_t per4 = (kXcdSeg << gshift) / 4u, ngroups = (uint32_t)G / (kXcdSeg << gshift);   // <= kMaxGroups
+    const uint4* __restrict__ cost4 = reinterpret_cast<const uint4*>(wg_cost);
     for (uint32_t g = threadIdx.x; g < ngroups; g += kBlock) {
       uint32_t c = 0;
-      for (uint32_t t = 0; t < per; ++t) c += wg_cost[g * per + t] >> gshift;   // (no overflow: 2^28 ticks = 2.7 s)
-      cost[g] = c;
+      for (uint32_t t = 0; t < per4; t += 4u) {     // per4 is a multiple of 4: four 16-byte reads in flight
+        uint4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = cost4[g * per4 + t + (uint32_t)u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += (q[u].x >> gshift) + (q[u].y >> gshift) + (q[u].z >> gshift) + (q[u].w >> gshift);
+      }
+      key[g] = (min(c, 0x7FFFFFu) << 9) | ((uint32_t)kMaxGroups - 1u - g);
     }
+    if (done) return;
     __syncthreads();
+    const uint4* key4 = reinterpret_cast<const uint4*>(key);   // (ngroups is a multiple of 8)
     for (uint32_t g = threadIdx.x; g < ngroups; g += kBlock) {
-      const uint32_t c = cost[g];
+      const uint32_t mine = key[g];
       uint32_t rank = 0;
-      for (uint32_t j = 0; j < ngroups; ++j) {
-        const uint32_t cj = cost[j];
-        rank += (cj > c || (cj == c && j < g)) ? 1u : 0u;
+#pragma unroll 4
+      for (uint32_t j = 0; j < ngroups / 4u; ++j) {
+        const uint4 kj = key4[j];
+        rank += (kj.x > mine ? 1u : 0u) + (kj.y > mine ? 1u : 0u) + (kj.z > mine ? 1u : 0u) + (kj.w > mine ? 1u : 0u);
       }
       order[rank] = g;
     }
     return;
   }
   const int k = blockIdx.x;
+  DevState s0;
+  if (threadIdx.x == 0) s0 = *st;   // whoever arrives last will need it: read it now, not after the hand-off
   const double* __restrict__ p = partials + (size_t)k * G;
   double v = 0.0;
-  for (int b0 = threadIdx.x; b0 < G; b0 += 8 * kBlock) {
-    double u[8];
+  for (int b0 = threadIdx.x; b0 < G; b0 += 16 * kBlock) {
+    double u[16];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < 16; ++t) {    // sixteen independent loads in flight per thread
       const int b = b0 + t * kBlock;
       u[t] = b < G ? p[b] : 0.0;
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v += u[t];
+    for (int t = 0; t < 16; ++t) v += u[t];
   }
+  if (done) return;
   __shared__ double red[kBlock / kWave];
   v = wave_sum(v);
   if ((threadIdx.x & (kWave - 1)) == kSumLane) red[threadIdx.x / kWave] = v;
@@ -1069,7 +1090,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   double a[kNAcc];
 #pragma unroll
   for (int t = 0; t < kNAcc; ++t) a[t] = __hip_atomic_load(&acc_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  solve_step(a, st, trace, trace_cap, tol);
+  solve_step(a, s0, st, trace, trace_cap, tol);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -46,6 +46,11 @@ for it in (0, 5, 12, 20, 45):
         ov = np.clip(np.minimum(end, b) - np.maximum(start, a), 0, None).sum() / (b - a)
         res.append(ov)
     print("          resident workgroups per decile of the span:", " ".join(f"{r:6.0f}" for r in res))
+    by = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        m = (start >= a) & (start < b)
+        by.append(f"{np.median(dur[m]):6.1f}" if m.any() else "     -")
+    print("          median duration of the workgroups STARTED in that decile:", " ".join(by))
     xcc = hw[it, :G, 1] & 0xF
     per = [end[xcc == x].max() if (xcc == x).any() else 0 for x in range(8)]
     cnt = [int((xcc == x).sum()) for x in range(8)]
