@@ -426,6 +426,29 @@ def test_full_size_1m_known_transform_and_invariances(engine):
     assert np.allclose(res.trace[0, 4:7], gold[idx[m]].astype(np.float64).sum(0), rtol=1e-9)
 
 
+def test_2p5m_cloud_grouped_schedule_known_transform(engine):
+    """BASELINE configs[4] size class (2M+ points per pair): beyond 2M points the longest-first
+    schedule ranks GROUPS of segments (more than 512 segments), and the grid is padded to whole
+    groups.  align(A, T.A) must still recover T, bitwise the same on every run (the schedule
+    follows measured durations, the sums must not), and the accumulators of iteration 0 must
+    equal direct sums over the matched points."""
+    n = 2_500_000
+    gold, comp, R0, t0 = syn.make_pair(3, n, resample=False)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    res = engine.icp(30, 0.0, 0.10, with_trace=True)
+    eR, et = orc.rt_error(res.R, res.t, R0, t0)
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    assert res.inliers == n and res.rmse < 1e-5
+    again = engine.icp(30, 0.0, 0.10, with_trace=True)
+    assert np.array_equal(res.T, again.T) and np.array_equal(res.trace, again.trace)
+    idx, d2 = engine.nn(None, 0.10)
+    m = idx != NO_MATCH
+    assert res.trace[0, 0] == m.sum()
+    assert np.allclose(res.trace[0, 1:4], comp[m].astype(np.float64).sum(0), rtol=1e-9)
+    assert np.allclose(res.trace[0, 4:7], gold[idx[m]].astype(np.float64).sum(0), rtol=1e-9)
+
+
 def test_full_size_1m_resampled_pair_one_step_vs_oracle(engine):
     """One full-size iteration against the KD-tree oracle (a single 1M query is affordable)."""
     gold, comp, R0, t0 = syn.make_pair(0, 1_000_000)
