@@ -641,7 +641,8 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
 template <bool COUNT>
 __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bool has_query, const float px,
                                             const float py, const float pz, const LevelSet& S, float& best2,
-                                            uint32_t& bestj, uint32_t& nrows_cnt, uint32_t& ncand) {
+                                            uint32_t& bestj, uint32_t& nrows_cnt, uint32_t& ncand,
+                                            uint32_t& ndismissed) {
   const float c = S.c[0], inv_c = S.inv_c[0];
   const int nx = S.nx[0], ny = S.ny[0], nz = S.nz[0];
   const float4* __restrict__ gold0 = S.gold[0];
@@ -701,6 +702,22 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
   const float lim = c - S.delta, wide = kWalk * c;
   bool more = finite && best2 > lim * lim && best2 <= wide * wide;
   const bool fallback = finite && best2 > wide * wide;
+  // A sphere that is still wide after the 3 x 3 block (an early iteration: nothing, or only
+  // something far, has been found) asks the distance-to-occupied table before walking rings:
+  // if even the nearest occupied cell is farther than the sphere there is nothing more to
+  // find, for one byte instead of ~40 empty rows.  (Never reached once the clouds are aligned.)
+  ndismissed = 0;
+  if (__any(more)) {
+    const float ux = (px - S.ox) * inv_c;
+    bool dismissed = false;
+    if (more && ux >= 0.f && ux < (float)nx && (unsigned)cy < (unsigned)ny && (unsigned)cz < (unsigned)nz) {
+      const int k = S.occ_dist[(uint32_t)((cz * ny + cy) * nx) + (uint32_t)ux];
+      const float lbk = (float)max(k - 1, 0) * c - S.delta;
+      dismissed = lbk > 0.f && lbk * lbk > best2;   // (strictly: an equal distance may still win on position)
+    }
+    more = more && !dismissed;
+    ndismissed = (uint32_t)__popcll(__ballot(dismissed));
+  }
   for (int r = 2; __any(more); ++r) {
     const float lb = (float)(r - 1) * c - S.delta;
     more = more && r <= rmax && lb * lb < best2;
@@ -835,7 +852,8 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     }
   }
 #if MA_WAVEQ
-  wave_search<COUNT>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand);
+  uint32_t ndismissed = 0;
+  wave_search<COUNT>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand, ndismissed);
 #else
   if (has) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
 #endif
@@ -882,6 +900,9 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   constexpr int kLive = COUNT ? kNAcc : ma::kAccLen;
   constexpr int kVals = kNW * 16, kParts = 8, kPer = kVals / kParts;
   __shared__ double sh_part[kNAcc][kParts];
+  __shared__ uint32_t sh_dismissed[kNW];
+  static_assert(kNW == 4, "the cost line below adds four wavefronts");
+  if (lane == 0) sh_dismissed[wv] = ndismissed;
 #pragma unroll
   for (int k = 0; k < kLive; ++k) {
     double v = dpp_add<0x111>(acc[k]);
@@ -909,7 +930,14 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     }
     partials[(size_t)k * G + chunk] = v;
   }
-  if (threadIdx.x == 0 && sched.wg_cost) sched.wg_cost[chunk] = (uint32_t)(wall_clock64() - wg_start);
+  // Cost for the next launch's schedule: this workgroup's duration, plus what its dismissed
+  // points would have cost had they walked their rings (~0.5 us per point of one wavefront;
+  // four wavefronts run side by side) — as the clouds approach each other such points come
+  // within reach from one iteration to the next, and a segment that was cheap only because
+  // it was dismissed must not be scheduled last.
+  if (threadIdx.x == 0 && sched.wg_cost)
+    sched.wg_cost[chunk] = (uint32_t)(wall_clock64() - wg_start) +
+                           12u * (sh_dismissed[0] + sh_dismissed[1] + sh_dismissed[2] + sh_dismissed[3]);
 #if MA_WGTIMES
   if (threadIdx.x == 0 && MODE == 0 && st->iter < 64 && blockIdx.x < 4096) {
     g_wgt[st->iter][blockIdx.x][0] = wg_start;
