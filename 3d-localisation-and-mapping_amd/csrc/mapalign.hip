@@ -308,6 +308,13 @@ struct u4_unaligned { uint32_t x, y, z, w; } __attribute__((packed, aligned(4)))
 __device__ __forceinline__ float4 ld_point(const float4* __restrict__ base, uint32_t j) {
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (j << 4));
 }
+// Coordinates only (12 of the 16 bytes).  The candidate scan is bound by the L1 return path
+// (a wavefront-wide 16-byte load is 16 cycles of it, a 12-byte one 12: forcing full float4
+// loads cost 10 % of the whole alignment), and in level 0 the fourth word is the point's own
+// position, i.e. the index it was loaded from.
+__device__ __forceinline__ float3 ld_xyz(const float4* __restrict__ base, uint32_t j) {
+  return *reinterpret_cast<const float3*>(reinterpret_cast<const char*>(base) + (j << 4));
+}
 __device__ __forceinline__ uint32_t ld_cell(const uint32_t* __restrict__ base, uint32_t c) {
   return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(base) + (c << 2));
 }
@@ -535,6 +542,9 @@ struct WaveLds {
   uint8_t row_lane[kRowCap];
   uint8_t chunk_lane[kChunkCap];
   uint8_t chunk_cnt[kChunkCap];
+#if MA_WGTIMES
+  unsigned long long dbg_round0;
+#endif
 };
 
 __device__ __forceinline__ unsigned long long pack_best(float d2, uint32_t j) {
@@ -556,14 +566,18 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
       const float b2_in = b2;
       uint32_t bj = kNoMatch;
       for (uint32_t t = 0; t < cnt; t += 4u) {
-        float4 q[4];
+        float3 q[4];
+        uint32_t at[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = ld_point(gold0, a + min(t + (uint32_t)u, cnt - 1u));
+        for (int u = 0; u < 4; ++u) {
+          at[u] = a + min(t + (uint32_t)u, cnt - 1u);
+          q[u] = ld_xyz(gold0, at[u]);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float dx = p.x - q[u].x, dy = p.y - q[u].y, dz = p.z - q[u].z;
           const float d = dx * dx + dy * dy + dz * dz;
-          if (d < b2) { b2 = d; bj = __float_as_uint(q[u].w); }
+          if (d < b2) { b2 = d; bj = at[u]; }   // level 0: position == index
         }
       }
       if (COUNT) ncand += cnt;
@@ -691,6 +705,9 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
   }
   wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
   wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
+#if MA_WGTIMES
+  if (lane == 0) W.dbg_round0 = wall_clock64();
+#endif
   {
     const unsigned long long key = W.best[lane];
     best2 = __uint_as_float((uint32_t)(key >> 32));
@@ -796,6 +813,7 @@ __device__ __forceinline__ uint32_t xcd_chunk(const uint32_t b, const Sched& sc,
 #if MA_WGTIMES   // debug variant only (tools/wgtimeline.py): start/end clock and placement of every workgroup
 __device__ unsigned long long g_wgt[64][4096][2];
 __device__ uint32_t g_wghw[64][4096][2];
+__device__ uint32_t g_wgph[64][4096][4];   // wave 0: ticks from the start to: search begins, 3x3 block done, search done, sums formed
 #endif
 
 #ifdef MA_NN_WAVES
@@ -843,7 +861,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       // temporal coherence: last iteration's match bounds the search radius from the start
       const uint32_t pj = prev[i];
       if (pj != kNoMatch) {
-        const float4 c = ld_point(S.gold[0], pj);
+        const float3 c = ld_xyz(S.gold[0], pj);
         const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
         if (COUNT) ncand += 1u;
@@ -853,7 +871,14 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   }
 #if MA_WAVEQ
   uint32_t ndismissed = 0;
+#if MA_WGTIMES
+  const unsigned long long dbg_t1 = wall_clock64();
+#endif
   wave_search<COUNT>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand, ndismissed);
+#if MA_WGTIMES
+  const unsigned long long dbg_t3 = wall_clock64(), dbg_t2 = sh_w[wv].q.dbg_round0;
+  unsigned long long dbg_t4 = 0;
+#endif
 #else
   if (has) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
 #endif
@@ -873,7 +898,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       nn_d2[i] = bestj != kNoMatch ? best2 : INFINITY;
     }
     if (MODE == 0 && bestj != kNoMatch) {
-      const float4 q = ld_point(S.gold[0], bestj);   // the winner's coordinates (level 0 holds every point)
+      const float3 q = ld_xyz(S.gold[0], bestj);   // the winner's coordinates (level 0 holds every point)
       const double w = (double)s.w;
       const double qx = q.x, qy = q.y, qz = q.z;
       const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
@@ -889,6 +914,10 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
   }
   if (MODE == 1) return;  // ma_nn: per-point outputs only
+#if MA_WGTIMES
+  asm volatile("" :: "v"(acc[16]), "v"(acc[0]));
+  dbg_t4 = wall_clock64();
+#endif
 
   // Workgroup reduction of the live accumulators, fixed order (deterministic):
   //   1. two DPP steps fold each group of 4 lanes (6 VALU ops per value; a full wavefront
@@ -944,6 +973,10 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     g_wgt[st->iter][blockIdx.x][1] = wall_clock64();
     g_wghw[st->iter][blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
     g_wghw[st->iter][blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    g_wgph[st->iter][blockIdx.x][0] = (uint32_t)(dbg_t1 - wg_start);
+    g_wgph[st->iter][blockIdx.x][1] = (uint32_t)(dbg_t2 - wg_start);
+    g_wgph[st->iter][blockIdx.x][2] = (uint32_t)(dbg_t3 - wg_start);
+    g_wgph[st->iter][blockIdx.x][3] = (uint32_t)(dbg_t4 - wg_start);
   }
 #endif
 }
@@ -2284,6 +2317,10 @@ int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {
 }
 
 #if MA_WGTIMES
+int ma_debug_wgphases(ma_ctx* ctx, uint32_t* ph) {
+  HIPCHK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_wgph), sizeof(g_wgph)));
+  return MA_OK;
+}
 int ma_debug_wgtimes(ma_ctx* ctx, unsigned long long* times, uint32_t* hw) {
   HIPCHK(hipMemcpyFromSymbol(times, HIP_SYMBOL(g_wgt), sizeof(g_wgt)));
   HIPCHK(hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_wghw), sizeof(g_wghw)));

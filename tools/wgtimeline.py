@@ -27,6 +27,9 @@ hw = np.zeros((64, 4096, 2), dtype=np.uint32)
 lib.ma_debug_wgtimes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 rc = lib.ma_debug_wgtimes(eng._ctx, times.ctypes.data, hw.ctypes.data)
 assert rc == 0, rc
+ph = np.zeros((64, 4096, 4), dtype=np.uint32)
+lib.ma_debug_wgphases.argtypes = [C.c_void_p, C.c_void_p]
+assert lib.ma_debug_wgphases(eng._ctx, ph.ctypes.data) == 0
 G = int((times[0, :, 1] > 0).sum())
 print("workgroups", G)
 for it in (0, 5, 12, 20, 45):
@@ -46,6 +49,11 @@ for it in (0, 5, 12, 20, 45):
         ov = np.clip(np.minimum(end, b) - np.maximum(start, a), 0, None).sum() / (b - a)
         res.append(ov)
     print("          resident workgroups per decile of the span:", " ".join(f"{r:6.0f}" for r in res))
+    p = ph[it, :G].astype(np.float64) * tick_us
+    seg = np.stack([p[:, 0], p[:, 1] - p[:, 0], p[:, 2] - p[:, 1], p[:, 3] - p[:, 2], dur - p[:, 3]], axis=1)
+    late = start > 0.5 * span if (start > 0.5 * span).sum() > 50 else start >= 0
+    print("          wave 0 phases, median us (all | started in the 2nd half): head loads %.1f|%.1f  3x3 block %.1f|%.1f  rings %.1f|%.1f  winner+sums %.1f|%.1f  reduction+write %.1f|%.1f"
+          % tuple(v for k in range(5) for v in (np.median(seg[:, k]), np.median(seg[late, k]))))
     by = []
     for a, b in zip(edges[:-1], edges[1:]):
         m = (start >= a) & (start < b)
