@@ -61,11 +61,12 @@ def algorithmic_bytes(trace, n_src, n_blocks):
     """bytes one k_nn_accum launch must move, from the exact work counters.
 
     16 B per source point (float4) + 8 B per point for the remembered match (4 B read +
-    4 B write) + 4 B per grid-table word read + 16 B per candidate gold point examined
-    (float4, the remembered match included) + 16 B per matched point (re-read of the
-    winner) + 19 fp64 partials per workgroup.  Averaged over the launches of one step."""
+    4 B write) + 4 B per grid-table word read + 12 B per candidate gold point examined
+    (coordinates only, the remembered match included: SURVEY.md §8d's 12*C) + 12 B per
+    matched point (re-read of the winner) + 19 fp64 partials per workgroup.  Averaged over
+    the launches of one step."""
     words, cands, matched = trace[:, 18], trace[:, 19], trace[:, 0]
-    per_launch = 24.0 * n_src + 4.0 * words + 16.0 * cands + 16.0 * matched + 19 * 8.0 * n_blocks
+    per_launch = 24.0 * n_src + 4.0 * words + 12.0 * cands + 12.0 * matched + 19 * 8.0 * n_blocks
     return float(per_launch.mean()), float(words.mean() / n_src), float(cands.mean() / n_src)
 
 
