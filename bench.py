@@ -187,7 +187,7 @@ def main():
             achieved = b_launch / t_launch_s / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and args.points == N_POINTS and args.cell == 0.0:   # measured for this workload only
                 try:
                     traffic = json.load(open(tpath)).get("k_nn_accum_hbm_bytes_per_launch")
                 except Exception:
@@ -215,7 +215,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32 (f64 accumulate/solve)",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 1M-point synthetic cloud pair, 50 ICP iterations, 1xMI355X"
+            "config": {"workload": ("configs[1]: 1M-point synthetic cloud pair, 50 ICP iterations, 1xMI355X"
+                                    if args.points == N_POINTS else
+                                    f"{args.points}-point synthetic cloud pair (configs[1] at another size), 50 ICP iterations")
                        + ("" if world == 1 else f" - one pair per GPU x{world}" if not sharded
                           else f" - one pair sharded over {world} GPUs, RCCL all-reduce of 17 doubles/iteration"),
                        "points_gold": len(gold), "points_comparison": len(comp), "iterations_per_step": ITERS,
