@@ -19,13 +19,16 @@
 // gather + reduction (<0.5 flop/B), and no CPU fallback.
 //
 // Memory layout in HBM (all owned by the ctx):
-//   gold   float4[M]   cell-sorted (x fastest), coordinates relative to the centring
-//                      origin, .w = original index (bit pattern)
-//   cstart u32[ncells+1] exclusive prefix of points per cell: the points of the x-run
+//   gold[l] float4[M]  four levels (cell edge c, 2c, 4c, 8c), each cell-sorted (x fastest),
+//                      coordinates relative to the centring origin, .w = the point's
+//                      position in level 0 (bit pattern); perm0 maps that to the caller's index
+//   cstart[l] u32[ncells+1] exclusive prefix of points per cell: the points of the x-run
 //                      [x0,x1] of row (y,z) are gold[cstart[row+x0] .. cstart[row+x1+1])
-//   src    float4[N]   cell-sorted in its own frame for spatial coherence of a wavefront,
-//                      .w = per-point weight
-//   partials f64[19][G], state (R,t,flags), trace f64[iters][20]
+//   occ_dist u8[ncells] level 0: Chebyshev distance (cells, capped) to the nearest occupied cell
+//   src    float4[N]   brick-major sorted in its own frame (256 consecutive points = a compact
+//                      patch), .w = per-point weight; prev u32[N] = last iteration's match
+//   partials f64[19][G] one per 256-point chunk, state (R,t,flags), trace f64[iters][20],
+//   wg_cost u32[G] + seg_order u32[<=512]  workgroup durations and the longest-first schedule
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -930,7 +933,6 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   constexpr int kVals = kNW * 16, kParts = 8, kPer = kVals / kParts;
   __shared__ double sh_part[kNAcc][kParts];
   __shared__ uint32_t sh_dismissed[kNW];
-  static_assert(kNW == 4, "the cost line below adds four wavefronts");
   if (lane == 0) sh_dismissed[wv] = ndismissed;
 #pragma unroll
   for (int k = 0; k < kLive; ++k) {
@@ -964,9 +966,12 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   // four wavefronts run side by side) — as the clouds approach each other such points come
   // within reach from one iteration to the next, and a segment that was cheap only because
   // it was dismissed must not be scheduled last.
-  if (threadIdx.x == 0 && sched.wg_cost)
-    sched.wg_cost[chunk] = (uint32_t)(wall_clock64() - wg_start) +
-                           12u * (sh_dismissed[0] + sh_dismissed[1] + sh_dismissed[2] + sh_dismissed[3]);
+  if (threadIdx.x == 0 && sched.wg_cost) {
+    uint32_t dismissed = 0;
+#pragma unroll
+    for (int w = 0; w < kNW; ++w) dismissed += sh_dismissed[w];
+    sched.wg_cost[chunk] = (uint32_t)(wall_clock64() - wg_start) + (48u / kNW) * dismissed;
+  }
 #if MA_WGTIMES
   if (threadIdx.x == 0 && MODE == 0 && st->iter < 64 && blockIdx.x < 4096) {
     g_wgt[st->iter][blockIdx.x][0] = wg_start;

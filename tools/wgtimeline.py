@@ -32,7 +32,7 @@ lib.ma_debug_wgphases.argtypes = [C.c_void_p, C.c_void_p]
 assert lib.ma_debug_wgphases(eng._ctx, ph.ctypes.data) == 0
 G = int((times[0, :, 1] > 0).sum())
 print("workgroups", G)
-for it in (0, 5, 12, 20, 45):
+for it in (0, 1, 2, 5, 12, 20, 45):
     t = times[it, :G].astype(np.int64)
     t0_, t1_ = t[:, 0].min(), t[:, 1].max()
     tick_us = 0.01  # wall_clock64: 100 MHz
