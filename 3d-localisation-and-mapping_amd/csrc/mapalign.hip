@@ -977,7 +977,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     g_wgt[st->iter][blockIdx.x][0] = wg_start;
     g_wgt[st->iter][blockIdx.x][1] = wall_clock64();
     g_wghw[st->iter][blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
-    g_wghw[st->iter][blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    g_wghw[st->iter][blockIdx.x][1] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) | (chunk << 4);   // XCC_ID, chunk
     g_wgph[st->iter][blockIdx.x][0] = (uint32_t)(dbg_t1 - wg_start);
     g_wgph[st->iter][blockIdx.x][1] = (uint32_t)(dbg_t2 - wg_start);
     g_wgph[st->iter][blockIdx.x][2] = (uint32_t)(dbg_t3 - wg_start);

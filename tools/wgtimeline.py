@@ -63,6 +63,18 @@ for it in (0, 1, 2, 5, 12, 20, 45):
     per = [end[xcc == x].max() if (xcc == x).any() else 0 for x in range(8)]
     cnt = [int((xcc == x).sum()) for x in range(8)]
     print("          per-XCD finish us:", " ".join(f"{p:5.1f}" for p in per), "| wgs per XCD:", cnt)
+    if it > 0:
+        # how well did the previous iteration's segment costs predict this one's? (the schedule uses them)
+        def seg_cost(k):
+            tk = times[k, :G].astype(np.int64)
+            ch = (hw[k, :G, 1] >> 4).astype(np.int64)
+            c = np.zeros(G); c[ch] = (tk[:, 1] - tk[:, 0])
+            return c.reshape(-1, 16).sum(1)
+        a, b = seg_cost(it - 1), seg_cost(it)
+        ra, rb = np.argsort(np.argsort(-a)), np.argsort(np.argsort(-b))
+        top = rb < len(b) // 4
+        print("          segment cost vs previous iteration: Pearson %.3f, rank %.3f; of this iteration's top-quarter segments %.0f %% were predicted in the top quarter, worst predicted rank %d of %d"
+              % (np.corrcoef(a, b)[0, 1], np.corrcoef(ra, rb)[0, 1], 100.0 * (ra[top] < len(b) // 4).mean(), ra[top].max(), len(b)))
     hwid = hw[it, :G, 0]
     cu = (hwid >> 8) & 0xF
     se = (hwid >> 13) & 0x7
