@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "3d-localisation-and-mapping_amd"))
 import mapalign, numpy as np
 from mapalign import synthetic as syn
-g, c, R0, t0 = syn.make_pair(0, 1_000_000)
+g, c, R0, t0 = syn.make_pair(0, int(os.environ.get("N", "1000000")))
 eng = mapalign.MapAligner(0)
 for cell in [float(a) for a in sys.argv[1:]]:
     gi = eng.set_gold(g, cell); eng.set_source(c)
