@@ -809,9 +809,6 @@ __device__ __forceinline__ uint32_t xcd_chunk(const uint32_t b, const Sched& sc,
 // One source point per thread: many short-lived wavefronts hide the search's memory latency
 // best (2 and 4 points per thread measured 25-70 % slower), and the 17 fp64 accumulator terms
 // are formed only after the search, so they hold no registers during it.
-#ifndef MA_WAVEQ
-#define MA_WAVEQ 1
-#endif
 
 #if MA_WGTIMES   // debug variant only (tools/wgtimeline.py): start/end clock and placement of every workgroup
 __device__ unsigned long long g_wgt[64][4096][2];
@@ -872,7 +869,6 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       }
     }
   }
-#if MA_WAVEQ
   uint32_t ndismissed = 0;
 #if MA_WGTIMES
   const unsigned long long dbg_t1 = wall_clock64();
@@ -881,9 +877,6 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
 #if MA_WGTIMES
   const unsigned long long dbg_t3 = wall_clock64(), dbg_t2 = sh_w[wv].q.dbg_round0;
   unsigned long long dbg_t4 = 0;
-#endif
-#else
-  if (has) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
 #endif
 
   double acc[kNAcc];
@@ -1032,12 +1025,7 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
   s0.last_rmse = rmse;
   s0.last_W = W;
   double dR[9], dt[3];
-#ifdef MA_NOSOLVE
-  dR[0] = dR[4] = dR[8] = 1.0; dR[1] = dR[2] = dR[3] = dR[5] = dR[6] = dR[7] = 0.0; dt[0] = dt[1] = dt[2] = 0.0;
-  if (false) {
-#else
   if (ma::kabsch_from_acc(a, dR, dt)) {
-#endif
     s0.degenerate = 1;
     s0.done = 1;
     *st = s0;
