@@ -1951,6 +1951,9 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
   HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
   const float* d_w = nullptr;
   if (weights) {
+    for (uint64_t k = 0; k < n64; ++k)
+      if (!(weights[k] >= 0.f) || !std::isfinite(weights[k]))
+        return ctx->fail(MA_ERR_INVALID, "weights must be finite and >= 0");
     HIPCHK(ctx->wts.ensure((size_t)n * 4));
     HIPCHK(hipMemcpyAsync(ctx->wts.p, weights, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     d_w = ctx->wts.as<float>();

@@ -100,7 +100,8 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell);
 int ma_grid_info_get(const ma_ctx* ctx, ma_grid_info* out);
 
 /* Comparison ("maintenance") cloud: N x 3 fp32 points, optional per-point weights
- * (NULL = 1).  Needs the gold map first (points are stored relative to its origin). */
+ * (NULL = 1; each finite and >= 0, else MA_ERR_INVALID).  Needs the gold map first (points
+ * are stored relative to its origin). */
 int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t n);
 
 /* Row a8: fused depth -> 3-D unprojection written straight into the source-cloud device

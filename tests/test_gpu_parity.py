@@ -335,6 +335,12 @@ def test_error_paths(engine):
     bad[0, 0] = np.inf
     with pytest.raises(E):
         engine.set_source(bad)
+    for w_bad in (-1.0, np.nan, np.inf):                     # weights: finite and >= 0
+        w = np.ones(len(comp), np.float32)
+        w[7] = w_bad
+        with pytest.raises(E) as e:
+            engine.set_source(comp, w)
+        assert e.value.status == -1
     with pytest.raises(ValueError):
         engine.set_source(np.zeros((5, 2), np.float32))
     engine.set_source(comp)
