@@ -1,0 +1,165 @@
+// host_math.h — host-side arithmetic of libmapalign that needs no HIP: frame conversions
+// between the caller's world frame and the context's centred frame, grid geometry, launch
+// geometry of the search kernel.  Plain C++17, so that tests/test_host_math.py can build it
+// with g++ -fsanitize=address,undefined on a CPU box (sanitizer row) and check
+// it against NumPy; mapalign.hip includes the same header for the product build.
+//
+// Conventions (reference: src/map_alignment/visualise.py:94-96,128-130): a rigid transform
+// is a 4x4 row-major matrix applied as p' = T @ [p,1].  The device keeps coordinates
+// relative to a centring origin o (the gold map's bounding-box centre): p_c = p - o.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+
+namespace ma {
+
+struct GridP {
+  float ox, oy, oz;  // min corner of the grid in the centred frame
+  float c, inv_c;    // cell edge and its reciprocal
+  float delta;       // boundary slack (a few ulp of the largest coordinate)
+  int nx, ny, nz;
+};
+
+struct DevState {
+  double R[9];
+  double t[3];       // centred frame: p'_c = R p_c + t
+  double prev_rmse;
+  double last_rmse;
+  double last_W;
+  int iter;
+  int done;
+  int converged;
+  int degenerate;
+};
+
+// A/B knobs of the product build (csrc/Makefile `variant`); the defaults are the measured optimum.
+#ifndef MA_NN_BLOCK
+#define MA_NN_BLOCK 256
+#endif
+#ifndef MA_XCD_SEG
+#define MA_XCD_SEG 16
+#endif
+
+constexpr uint64_t kMaxCells = 1ull << 27;
+constexpr int kSearchBlock = MA_NN_BLOCK;     // points per workgroup of the search kernel
+constexpr uint32_t kXcdSegment = MA_XCD_SEG;  // chunks per XCD segment
+constexpr int kMaxSchedGroups = 512;  // scheduling groups ranked by cost
+
+inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// world 4x4 (row-major; nullptr = identity) -> centred-frame state
+inline void world_to_centred(const double* T, const double o[3], DevState& s) {
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+  if (T) {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) R[3 * r + c] = T[4 * r + c];
+      t[r] = T[4 * r + 3];
+    }
+  }
+  for (int i = 0; i < 9; ++i) s.R[i] = R[i];
+  for (int r = 0; r < 3; ++r)
+    s.t[r] = R[3 * r] * o[0] + R[3 * r + 1] * o[1] + R[3 * r + 2] * o[2] + t[r] - o[r];
+}
+
+inline void centred_to_world(const DevState& s, const double o[3], double* T) {
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) T[4 * r + c] = s.R[3 * r + c];
+    T[4 * r + 3] = s.t[r] - (s.R[3 * r] * o[0] + s.R[3 * r + 1] * o[1] + s.R[3 * r + 2] * o[2]) + o[r];
+  }
+  T[12] = T[13] = T[14] = 0.0;
+  T[15] = 1.0;
+}
+
+// centred-frame accumulators -> world-frame accumulators (p = p_c + o, q = q_c + o)
+inline void acc_to_world(const double* a, const double o[3], double* out) {
+  const double W = a[0];
+  out[0] = W;
+  for (int i = 0; i < 3; ++i) {
+    out[1 + i] = a[1 + i] + W * o[i];
+    out[4 + i] = a[4 + i] + W * o[i];
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      out[7 + 3 * r + c] = a[7 + 3 * r + c] + a[1 + r] * o[c] + o[r] * a[4 + c] + W * o[r] * o[c];
+  out[16] = a[16];
+}
+
+// strict '<' acceptance against this value implements the inclusive gate d^2 <= gate^2
+inline float open_gate2(double gate) {
+  if (!std::isfinite(gate)) return std::numeric_limits<float>::infinity();
+  const float g2 = (float)(gate * gate);
+  return std::nextafterf(g2, std::numeric_limits<float>::infinity());
+}
+
+inline GridP make_grid(const float lo[3], const float hi[3], const double o[3], float c) {
+  GridP g{};
+  g.ox = (float)((double)lo[0] - o[0]);
+  g.oy = (float)((double)lo[1] - o[1]);
+  g.oz = (float)((double)lo[2] - o[2]);
+  g.c = c;
+  g.inv_c = 1.0f / c;
+  const double ex = (double)hi[0] - lo[0], ey = (double)hi[1] - lo[1], ez = (double)hi[2] - lo[2];
+  g.nx = (int)std::floor(ex / c) + 1;
+  g.ny = (int)std::floor(ey / c) + 1;
+  g.nz = (int)std::floor(ez / c) + 1;
+  double maxabs = 0;
+  for (int a = 0; a < 3; ++a) maxabs = std::max({maxabs, std::fabs((double)lo[a] - o[a]), std::fabs((double)hi[a] - o[a])});
+  const float ulp = std::nextafterf((float)maxabs, INFINITY) - (float)maxabs;
+  g.delta = 8.0f * ulp + 1e-6f * c;
+  return g;
+}
+
+inline float clamp_cell_to_budget(const float lo[3], const float hi[3], float c, uint64_t max_cells) {
+  for (int it = 0; it < 64; ++it) {
+    const double nx = std::floor(((double)hi[0] - lo[0]) / c) + 1, ny = std::floor(((double)hi[1] - lo[1]) / c) + 1,
+                 nz = std::floor(((double)hi[2] - lo[2]) / c) + 1;
+    const double cells = nx * ny * nz;
+    if (cells <= (double)max_cells && nx < 2e9 && ny < 2e9 && nz < 2e9) return c;
+    // grow the edge by what the count calls for (not by a fixed factor: the result should sit
+    // just under the budget, not up to 2x below it)
+    c *= (float)std::min(2.0, std::max(1.004, std::cbrt(cells / (double)max_cells) * 1.002));
+  }
+  return c;
+}
+
+// Launch geometry of the search kernel: one source point per thread, kSearchBlock points per
+// chunk.  G (chunks, = workgroups) is a multiple of 8 * kXcdSegment (the XCD remap is a
+// bijection) and of kXcdSegment << gshift, where 2^gshift segments form one scheduling group
+// and there are at most kMaxSchedGroups groups (the surplus workgroups have no points).
+inline uint32_t grid_for(uint32_t n, uint32_t* gshift_out = nullptr) {
+  const uint32_t q = 8u * kXcdSegment;
+  const uint32_t G0 = std::max<uint32_t>(q, (div_up(n, kSearchBlock) + q - 1u) / q * q);
+  uint32_t gshift = 0, G = G0;
+  for (;;) {
+    const uint32_t unit = std::max<uint32_t>(q, kXcdSegment << gshift);   // both are powers of two
+    G = (G0 + unit - 1u) / unit * unit;
+    // rounding G up to the unit can add a group (67.1M points: 512 -> 513), so test AFTER it
+    if (G / (kXcdSegment << gshift) <= (uint32_t)kMaxSchedGroups) break;
+    ++gshift;
+  }
+  if (gshift_out) *gshift_out = gshift;
+  return G;
+}
+
+// Number of scheduling groups the ranking workgroup of k_reduce_solve orders.
+inline uint32_t sched_groups(uint32_t G, uint32_t gshift) { return G / (kXcdSegment << gshift); }
+
+// Host model of the ranking workgroup: order[r] = the group with the r-th largest cost
+// (ties: smaller index first).  Keys are padded with 0 up to a multiple of 4, exactly as the
+// kernel pads its LDS array, so that the 16-byte compare loop sees every key.
+inline void rank_groups_model(const uint32_t* cost, uint32_t ngroups, uint32_t* order) {
+  uint32_t key[kMaxSchedGroups + 4] = {0};
+  for (uint32_t g = 0; g < ngroups; ++g)
+    key[g] = (std::min(cost[g], 0x7FFFFFu) << 9) | ((uint32_t)kMaxSchedGroups - 1u - g);
+  const uint32_t n4 = (ngroups + 3u) / 4u;
+  for (uint32_t g = 0; g < ngroups; ++g) {
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < 4u * n4; ++j) rank += key[j] > key[g] ? 1u : 0u;
+    order[rank] = g;
+  }
+}
+
+}  // namespace ma

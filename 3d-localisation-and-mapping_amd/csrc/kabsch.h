@@ -25,7 +25,6 @@
 namespace ma {
 
 constexpr int kAccLen = 17;
-constexpr double kMinCorrespondences = 3.0;
 
 struct Col3 { double x, y, z; };
 
@@ -40,7 +39,7 @@ MA_HD inline void swap_col(Col3& a, Col3& b) { const Col3 t = a; a = b; b = t; }
 // fix-ups); the hardware seeds (v_rcp_f64, v_rsq_f64: ~26 bits) plus one Newton step are 4-5
 // and accurate to an ulp or two, which is all this needs (the rotation keeps c^2 + s^2 = 1 by
 // construction, see jacobi_rotate).  Operands here are never 0, inf or denormal: every call
-// site is guarded (W >= 3, gamma^2 > 0, singular values checked).  The host build (unit
+// site is guarded (W > 0, gamma^2 > 0, singular values checked).  The host build (unit
 // test against numpy) uses the exact operations.
 MA_HD inline double inv_f64(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -120,8 +119,11 @@ MA_HD inline double det3(const double M[9]) {
 }
 
 // acc = {W, s_p[3], s_q[3], S[9] (S_ab = sum w p_a q_b), E}.  Writes dR (row-major) and dt.
-// Returns 0 on success, 1 if degenerate (W < 3, non-finite input, or rank(H) < 2), in
-// which case dR = I, dt = 0.
+// Returns 0 on success, 1 if degenerate, in which case dR = I, dt = 0.  Degenerate means: a
+// non-finite sum, no weight at all (W <= 0), or rank(H) < 2 — which is what fewer than three
+// non-collinear correspondences produce (0, 1 or 2 pairs, or any number on one line, give
+// rank <= 1).  W is a sum of WEIGHTS, not a count: normalised or confidence weights may sum
+// to less than 3 with millions of matches, so the test is on the rank, not on W >= 3.
 MA_HD inline int kabsch_from_acc(const double* acc, double dR[9], double dt[3]) {
   dR[0] = 1.0; dR[1] = 0.0; dR[2] = 0.0; dR[3] = 0.0; dR[4] = 1.0; dR[5] = 0.0;
   dR[6] = 0.0; dR[7] = 0.0; dR[8] = 1.0;
@@ -129,7 +131,7 @@ MA_HD inline int kabsch_from_acc(const double* acc, double dR[9], double dt[3]) 
   bool finite = true;
   for (int i = 0; i < kAccLen; ++i) finite = finite && isfinite(acc[i]);
   const double W = acc[0];
-  if (!finite || !(W >= kMinCorrespondences)) return 1;
+  if (!finite || !(W > 0.0)) return 1;
   const double iW = inv_f64(W);
   const Col3 mp{acc[1] * iW, acc[2] * iW, acc[3] * iW}, mq{acc[4] * iW, acc[5] * iW, acc[6] * iW};
   // H_ab = S_ab - W mp_a mq_b ; columns of H (index b)
@@ -145,6 +147,11 @@ MA_HD inline int kabsch_from_acc(const double* acc, double dR[9], double dt[3]) 
   if (s1 < s2) { swap_col(g1, g2); swap_col(v1, v2); const double t = s1; s1 = s2; s2 = t; }
   if (s0 < s1) { swap_col(g0, g1); swap_col(v0, v1); const double t = s0; s0 = s1; s1 = t; }
   if (!(s1 > 1e-24 * s0) || !(s0 > 0.0)) return 1;   // sigma_1 <= 1e-12 sigma_0: rank < 2
+  // H = S - W mu_p mu_q^T is a difference of terms of size W |mu_p| |mu_q|; a result below
+  // 1e-12 of that is rounding noise (a single correspondence gives H = 0 up to rounding, and
+  // noise has no small singular value for the rank test to see)
+  const double noise2 = W * W * dot3(mp, mp) * dot3(mq, mq);
+  if (!(s0 > 1e-24 * noise2)) return 1;
   // U columns of the two leading directions; the third of BOTH frames is the cross product
   // of the first two.  That covers a vanishing third singular value (planar
   // correspondences) and makes both frames right-handed, so

@@ -31,6 +31,9 @@
 //   wg_cost u32[G] + seg_order u32[<=512]  workgroup durations and the longest-first schedule
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is loaded with dlopen at ma_comm_init
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -42,39 +45,30 @@
 #include <string>
 #include <vector>
 
+#include "host_math.h"
 #include "kabsch.h"
 #include "mapalign.h"
 
 namespace {
 
 constexpr int kBlock = 256;           // 4 wavefronts
-#ifndef MA_NN_BLOCK
-#define MA_NN_BLOCK 256
-#endif
-constexpr int kNNBlock = MA_NN_BLOCK;  // workgroup of the search kernel
+constexpr int kNNBlock = ma::kSearchBlock;  // workgroup of the search kernel (MA_NN_BLOCK)
 constexpr int kWave = 64;
 constexpr int kNAcc = 19;             // 17 accumulators + rows visited + candidates
-constexpr uint64_t kMaxCells = 1ull << 27;
 constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
 
-struct GridP {
-  float ox, oy, oz;  // min corner of the grid in the centred frame
-  float c, inv_c;    // cell edge and its reciprocal
-  float delta;       // boundary slack (a few ulp of the largest coordinate)
-  int nx, ny, nz;
-};
-
-struct DevState {
-  double R[9];
-  double t[3];       // centred frame: p'_c = R p_c + t
-  double prev_rmse;
-  double last_rmse;
-  double last_W;
-  int iter;
-  int done;
-  int converged;
-  int degenerate;
-};
+// plain structs and host arithmetic shared with the CPU-side sanitizer test (host_math.h)
+using ma::DevState;
+using ma::GridP;
+using ma::kMaxCells;
+using ma::div_up;
+using ma::world_to_centred;
+using ma::centred_to_world;
+using ma::acc_to_world;
+using ma::open_gate2;
+using ma::make_grid;
+using ma::clamp_cell_to_budget;
+using ma::grid_for;
 
 // ---------------------------------------------------------------------------------------
 // small device helpers
@@ -211,6 +205,29 @@ __global__ __launch_bounds__(kBlock) void k_count_occupied(const uint32_t* __res
 #pragma unroll
     for (int w = 0; w < kBlock / kWave; ++w) t += part[w];
     if (t > 0.0) atomicAdd(out, (unsigned long long)t);
+  }
+}
+
+// number of weights that are not finite and >= 0 (one integer atomic per workgroup)
+__global__ __launch_bounds__(kBlock) void k_count_bad_weights(const float* __restrict__ w, uint32_t n,
+                                                              unsigned long long* __restrict__ out) {
+  uint32_t c = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float v = w[i];
+    c += !(v >= 0.f) || !isfinite(v);
+  }
+  const unsigned long long any = __ballot(c != 0u);
+  __shared__ uint32_t part[kBlock / kWave];
+  uint32_t tot = c;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) tot += __shfl_down(tot, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = any ? tot : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; ++k) t += part[k];
+    if (t) atomicAdd(out, (unsigned long long)t);
   }
 }
 
@@ -781,14 +798,11 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
 // (neighbouring workgroups share gold cells in its private L2) but gets pieces from all
 // over the cloud, so that an expensive region (e.g. a part of the scan the gold map does
 // not cover) is not one XCD's problem alone.
-#ifndef MA_XCD_SEG
-#define MA_XCD_SEG 16
-#endif
-constexpr uint32_t kXcdSeg = MA_XCD_SEG;
+constexpr uint32_t kXcdSeg = ma::kXcdSegment;   // MA_XCD_SEG
 #ifndef MA_SCHED
 #define MA_SCHED 1
 #endif
-constexpr int kMaxGroups = 512;   // scheduling groups (of 2^gshift segments) ranked by cost
+constexpr int kMaxGroups = ma::kMaxSchedGroups;   // scheduling groups (of 2^gshift segments) ranked by cost
 
 // Longest-first schedule.  While the clouds are still apart, the workgroups whose points find
 // no gold point inside the gate walk whole gate spheres and run 3-5x longer than the median;
@@ -988,13 +1002,60 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
 #endif
 }
 
+// Longest-first schedule, ranking step (one workgroup): order[r] = the scheduling group with
+// the r-th largest cost recorded by the search kernel, ties by index (rank by counting).
+__device__ __forceinline__ void rank_groups(const int G, const uint32_t* __restrict__ wg_cost,
+                                            uint32_t* __restrict__ order, const uint32_t gshift, const int done) {
+  // key = (cost, reversed index): unique, so the rank is a plain count of larger keys.
+  // ngroups = G / (16 << gshift) is ANY integer <= kMaxGroups once gshift >= 2 (sources above
+  // ~4.2M points: 306 groups at 5M), so the array is padded with zeros (smaller than or equal
+  // to every real key, and only strictly larger keys are counted) up to the next multiple of
+  // 4 and the 16-byte compare loop runs over the padded length: every key is compared.
+  __shared__ __attribute__((aligned(16))) uint32_t key[kMaxGroups + 4];
+  const uint32_t per4 = (kXcdSeg << gshift) / 4u, ngroups = (uint32_t)G / (kXcdSeg << gshift);   // <= kMaxGroups
+  const uint32_t n4 = (ngroups + 3u) / 4u;
+  const uint4* __restrict__ cost4 = reinterpret_cast<const uint4*>(wg_cost);
+  for (uint32_t g = threadIdx.x; g < 4u * n4; g += kBlock) {
+    uint32_t c = 0;
+    if (g < ngroups) {
+      for (uint32_t t = 0; t < per4; t += 4u) {     // per4 is a multiple of 4: four 16-byte reads in flight
+        uint4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = cost4[g * per4 + t + (uint32_t)u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += (q[u].x >> gshift) + (q[u].y >> gshift) + (q[u].z >> gshift) + (q[u].w >> gshift);
+      }
+    }
+    key[g] = g < ngroups ? (min(c, 0x7FFFFFu) << 9) | ((uint32_t)kMaxGroups - 1u - g) : 0u;
+  }
+  if (done) return;
+  __syncthreads();
+  const uint4* key4 = reinterpret_cast<const uint4*>(key);
+  for (uint32_t g = threadIdx.x; g < ngroups; g += kBlock) {
+    const uint32_t mine = key[g];
+    uint32_t rank = 0;
+#pragma unroll 4
+    for (uint32_t j = 0; j < n4; ++j) {
+      const uint4 kj = key4[j];
+      rank += (kj.x > mine ? 1u : 0u) + (kj.y > mine ? 1u : 0u) + (kj.z > mine ? 1u : 0u) + (kj.w > mine ? 1u : 0u);
+    }
+    order[rank] = g;
+  }
+}
+
 // a5 (final sum): one workgroup PER ACCUMULATOR sums that accumulator's G partials — 19
 // CUs pull 31 KB each instead of one CU pulling 0.6 MB (one CU's load bandwidth, not the
 // arithmetic, is what a single-workgroup reduction waits for).  Fixed assignment partial ->
 // thread, fixed order within a thread, DPP + LDS tree: deterministic.
 __global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ partials, const int G,
                                                      const DevState* __restrict__ st,
-                                                     double* __restrict__ acc_out) {
+                                                     double* __restrict__ acc_out,
+                                                     const uint32_t* __restrict__ wg_cost,
+                                                     uint32_t* __restrict__ order, const uint32_t gshift) {
+  if (blockIdx.x == kNAcc) {   // launched only with a schedule (ma_icp_sharded): rank the groups for the next search
+    rank_groups(G, wg_cost, order, gshift, st->done);
+    return;
+  }
   if (st->done) return;
   const int k = blockIdx.x;
   const double* __restrict__ p = partials + (size_t)k * G;
@@ -1020,7 +1081,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ 
 // convergence test, trace row.  (Kept out of the search kernel: its fp64 Jacobi code needs
 // ~110 VGPRs and would halve the occupancy of the search.)
 __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0, DevState* __restrict__ st,
-                                           double* __restrict__ trace, const int trace_cap, const double tol) {
+                                           double* __restrict__ trace, const int trace_cap, const double tol,
+                                           int* __restrict__ host_done) {
   const int it = s0.iter;
   const double W = a[0];
   const double rmse = W > 0.0 ? sqrt(a[16] / W) : NAN;
@@ -1038,6 +1100,7 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
     s0.degenerate = 1;
     s0.done = 1;
     *st = s0;
+    if (host_done) *host_done = 1;
     return;
   }
   double Rn[9], tn[3];
@@ -1055,6 +1118,8 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
   if (it >= 1 && fabs(rmse - s0.prev_rmse) < tol) {
     s0.converged = 1;
     s0.done = 1;
+    // pinned host word: lets ma_icp stop enqueueing launches that would only find `done` set
+    if (host_done) *host_done = 1;
   }
   s0.prev_rmse = rmse;
   *st = s0;
@@ -1063,12 +1128,12 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
 // The solve alone (sharded-source stepping: the 17 sums come back from the all-reduce).
 __global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_in, DevState* __restrict__ st,
                                                  double* __restrict__ trace, const int trace_cap,
-                                                 const double tol) {
+                                                 const double tol, int* __restrict__ host_done) {
   if (st->done || threadIdx.x != 0) return;
   double a[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) a[k] = acc_in[k];
-  solve_step(a, *st, st, trace, trace_cap, tol);
+  solve_step(a, *st, st, trace, trace_cap, tol, host_done);
 }
 
 // a5 (final sum) + a6 + a7 in ONE launch: the 19 reducing workgroups of k_reduce19, and the
@@ -1086,40 +1151,14 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
                                                          uint32_t* __restrict__ ticket, double* __restrict__ trace,
                                                          const int trace_cap, const double tol,
                                                          const uint32_t* __restrict__ wg_cost,
-                                                         uint32_t* __restrict__ order, const uint32_t gshift) {
+                                                         uint32_t* __restrict__ order, const uint32_t gshift,
+                                                         int* __restrict__ host_done) {
   // `done` is written only by the last arriver, after every workgroup has read it.  It is
   // tested AFTER the first loads have been issued: every dependent memory round trip of
   // this small kernel is ~1 us of the iteration.
   const int done = st->done;
   if (blockIdx.x == kNAcc) {
-    // key = (cost, reversed index): unique, so the rank is a plain count of larger keys
-    __shared__ __attribute__((aligned(16))) uint32_t key[kMaxGroups];
-    const uint32_t per4 = (kXcdSeg << gshift) / 4u, ngroups = (uint32_t)G / (kXcdSeg << gshift);   // <= kMaxGroups
-    const uint4* __restrict__ cost4 = reinterpret_cast<const uint4*>(wg_cost);
-    for (uint32_t g = threadIdx.x; g < ngroups; g += kBlock) {
-      uint32_t c = 0;
-      for (uint32_t t = 0; t < per4; t += 4u) {     // per4 is a multiple of 4: four 16-byte reads in flight
-        uint4 q[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = cost4[g * per4 + t + (uint32_t)u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) c += (q[u].x >> gshift) + (q[u].y >> gshift) + (q[u].z >> gshift) + (q[u].w >> gshift);
-      }
-      key[g] = (min(c, 0x7FFFFFu) << 9) | ((uint32_t)kMaxGroups - 1u - g);
-    }
-    if (done) return;
-    __syncthreads();
-    const uint4* key4 = reinterpret_cast<const uint4*>(key);   // (ngroups is a multiple of 8)
-    for (uint32_t g = threadIdx.x; g < ngroups; g += kBlock) {
-      const uint32_t mine = key[g];
-      uint32_t rank = 0;
-#pragma unroll 4
-      for (uint32_t j = 0; j < ngroups / 4u; ++j) {
-        const uint4 kj = key4[j];
-        rank += (kj.x > mine ? 1u : 0u) + (kj.y > mine ? 1u : 0u) + (kj.z > mine ? 1u : 0u) + (kj.w > mine ? 1u : 0u);
-      }
-      order[rank] = g;
-    }
+    rank_groups(G, wg_cost, order, gshift, done);
     return;
   }
   const int k = blockIdx.x;
@@ -1153,7 +1192,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   double a[kNAcc];
 #pragma unroll
   for (int t = 0; t < kNAcc; ++t) a[t] = __hip_atomic_load(&acc_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  solve_step(a, s0, st, trace, trace_cap, tol);
+  solve_step(a, s0, st, trace, trace_cap, tol, host_done);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1294,6 +1333,37 @@ __global__ __launch_bounds__(kBlock) void k_lift_boxes(const T* __restrict__ dep
   if (valid) valid[i] = ok ? 1 : 0;
 }
 
+// a10 over a batch of frames: corner i belongs to box i/4 of frame box_frame[i/4]; frames are
+// stored back to back, poses as 12 doubles per frame (rows 0..2 of camera->world).  One
+// launch lifts the boxes of all frames of a detector batch (configs[3]).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_lift_boxes_batch(const T* __restrict__ depth, const int width,
+                                                             const int height, const uint32_t n_frames,
+                                                             const double fx_inv, const double fy_inv,
+                                                             const double cx, const double cy, const double inv_scale,
+                                                             const double* __restrict__ poses,
+                                                             const float* __restrict__ boxes,
+                                                             const uint32_t* __restrict__ box_frame,
+                                                             const uint32_t ncorners, double* __restrict__ out,
+                                                             uint8_t* __restrict__ valid) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= ncorners) return;
+  const uint32_t b = i >> 2, k = i & 3u;
+  const uint32_t f = min(box_frame[b], n_frames - 1u);   // (validated on the host; clamp keeps the read in bounds)
+  const float bx = boxes[4 * b + ((k == 1u || k == 2u) ? 2 : 0)];   // x1 x2 x2 x1
+  const float by = boxes[4 * b + ((k >= 2u) ? 3 : 1)];               // y1 y1 y2 y2
+  const int u = min(max((int)bx, 0), width - 1), v = min(max((int)by, 0), height - 1);  // int(x), int(y)
+  double z = (double)depth[(size_t)f * width * height + (size_t)v * width + u] * inv_scale;
+  const bool ok = isfinite(z) && z > 0.0;
+  if (!ok) z = NAN;
+  const double* __restrict__ T12 = poses + 12 * (size_t)f;
+  const double X = ((double)u - cx) * z * fx_inv, Y = ((double)v - cy) * z * fy_inv;
+  out[3 * (size_t)i] = T12[0] * X + T12[1] * Y + T12[2] * z + T12[3];
+  out[3 * (size_t)i + 1] = T12[4] * X + T12[5] * Y + T12[6] * z + T12[7];
+  out[3 * (size_t)i + 2] = T12[8] * X + T12[9] * Y + T12[10] * z + T12[11];
+  if (valid) valid[i] = ok ? 1 : 0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_uncentre(const float4* __restrict__ src, uint32_t n,
                                                      double o0, double o1, double o2,
                                                      float* __restrict__ xyz) {
@@ -1318,19 +1388,41 @@ __global__ __launch_bounds__(kBlock) void k_unpermute(const T* __restrict__ in,
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
+// Device allocations of one context: counted so that callers (and the tests) can check that a
+// warm context — the second and later alignments through the cached engine of mapalign.api —
+// allocates nothing (ma_mem_info_get).
+struct MemStats {
+  uint64_t allocs = 0, frees = 0, bytes_live = 0, bytes_peak = 0;
+};
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  MemStats* stats = nullptr;
+  // Grows only; 12.5 % headroom so that clouds of slightly different sizes (successive scans of
+  // the same vehicle) reuse the allocation.
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    release();
     const size_t want = bytes + bytes / 8 + 256;
     hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
+    if (e == hipSuccess) {
+      cap = want;
+      if (stats) {
+        ++stats->allocs;
+        stats->bytes_live += want;
+        stats->bytes_peak = std::max(stats->bytes_peak, stats->bytes_live);
+      }
+    } else {
+      p = nullptr;
+    }
     return e;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      (void)hipFree(p);
+      if (stats) { ++stats->frees; stats->bytes_live -= cap; }
+    }
     p = nullptr;
     cap = 0;
   }
@@ -1338,8 +1430,6 @@ struct DevBuf {
 };
 
 thread_local std::string g_create_error;
-
-inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 }  // namespace
 
@@ -1379,8 +1469,22 @@ struct ma_ctx {
   // scratch for builds
   DevBuf raw, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
 
+  // batched box lifting (a10 over many frames)
+  DevBuf lift_poses, lift_frames;
+
   // loop state
   DevBuf state, partials, trace, acc19, ticket, wg_cost, seg_order, nn_idx, nn_d2, nn_tmp, prev;
+  // The stepping state (DevState, prev[], partials, ...) is sized for the clouds that were set
+  // when it was uploaded; installing another gold map or source cloud invalidates it
+  // (ma_step_accumulate / ma_step_solve then return MA_ERR_STATE until ma_state_set).
+  bool state_valid = false;
+  int* host_done = nullptr;      // pinned host word the solve sets when the loop stops (tol > 0 runs)
+  std::vector<hipEvent_t> batch_ev;
+  MemStats mem;
+  bool oom = false;              // a C++ allocation failed inside the last call (no message storage)
+  // RCCL communicator of the sharded-source mode (ma_comm_init); opaque here
+  void* comm = nullptr;
+  int comm_ranks = 0, comm_rank = 0;
   int trace_cap = 0;
   int last_G = 0;
   uint32_t last_gshift = 0;
@@ -1390,6 +1494,14 @@ struct ma_ctx {
   int fail(int code, const std::string& msg) {
     err = msg;
     return code;
+  }
+  std::vector<DevBuf*> all_bufs() {
+    std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &perm0, &inv0, &occ_a, &occ_b,
+                              &src, &src_perm, &raw, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
+                              &depth_in, &lift_poses, &lift_frames, &state, &partials, &trace, &acc19, &ticket,
+                              &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
+    for (int l = 0; l < kLevels; ++l) { v.push_back(&gold[l]); v.push_back(&cstart[l]); }
+    return v;
   }
 };
 
@@ -1402,6 +1514,68 @@ struct ma_ctx {
 
 namespace {
 
+// ---------------------------------------------------------------------------------------
+// RCCL (sharded-source mode): loaded on first use so that single-GPU users
+// need no librccl at load time, and so that a process that already holds an RCCL (PyTorch
+// bundles one under the same soname) shares it instead of getting a second copy.
+// ---------------------------------------------------------------------------------------
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;
+};
+
+RcclApi g_rccl;
+
+RcclApi* rccl_api() {
+  static const bool ok = [] {   // C++11 static initialisation is thread-safe
+    RcclApi& api = g_rccl;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (api.handle) break;
+    }
+    if (!api.handle) {
+      const char* e = dlerror();
+      api.error = std::string("cannot load librccl.so.1: ") + (e ? e : "unknown error");
+      return false;
+    }
+    auto sym = [&](const char* name) -> void* {
+      void* f = dlsym(api.handle, name);
+      if (!f && api.error.empty()) api.error = std::string("librccl lacks ") + name;
+      return f;
+    };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    return api.error.empty();
+  }();
+  return ok ? &g_rccl : nullptr;
+}
+
+#define NCCLCHK(expr)                                                                              \
+  do {                                                                                             \
+    ncclResult_t r_ = (expr);                                                                      \
+    if (r_ != ncclSuccess)                                                                         \
+      return ctx->fail(MA_ERR_COMM, std::string(#expr) + ": " + rccl_api()->GetErrorString(r_));   \
+  } while (0)
+
+void comm_destroy(ma_ctx* ctx) {
+  RcclApi* api = rccl_api();
+  if (api && ctx->comm) (void)api->CommDestroy(static_cast<ncclComm_t>(ctx->comm));
+  ctx->comm = nullptr;
+  ctx->comm_ranks = 0;
+  ctx->comm_rank = 0;
+}
+
 int check_params(ma_ctx* ctx, const ma_params* p) {
   if (!p) return ctx->fail(MA_ERR_INVALID, "params is NULL");
   if (p->max_iter < 1) return ctx->fail(MA_ERR_INVALID, "max_iter must be >= 1");
@@ -1410,54 +1584,10 @@ int check_params(ma_ctx* ctx, const ma_params* p) {
   return MA_OK;
 }
 
-// strict '<' acceptance against this value implements the inclusive gate d^2 <= gate^2
-float open_gate2(double gate) {
-  if (!std::isfinite(gate)) return std::numeric_limits<float>::infinity();
-  const float g2 = (float)(gate * gate);
-  return std::nextafterf(g2, std::numeric_limits<float>::infinity());
-}
-
 int need_ready(ma_ctx* ctx) {
   if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "gold map not set (ma_set_gold)");
   if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set (ma_set_source)");
   return MA_OK;
-}
-
-// world 4x4 (row-major) -> centred-frame state
-void world_to_centred(const double* T, const double o[3], DevState& s) {
-  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
-  if (T) {
-    for (int r = 0; r < 3; ++r) {
-      for (int c = 0; c < 3; ++c) R[3 * r + c] = T[4 * r + c];
-      t[r] = T[4 * r + 3];
-    }
-  }
-  for (int i = 0; i < 9; ++i) s.R[i] = R[i];
-  for (int r = 0; r < 3; ++r)
-    s.t[r] = R[3 * r] * o[0] + R[3 * r + 1] * o[1] + R[3 * r + 2] * o[2] + t[r] - o[r];
-}
-
-void centred_to_world(const DevState& s, const double o[3], double* T) {
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) T[4 * r + c] = s.R[3 * r + c];
-    T[4 * r + 3] = s.t[r] - (s.R[3 * r] * o[0] + s.R[3 * r + 1] * o[1] + s.R[3 * r + 2] * o[2]) + o[r];
-  }
-  T[12] = T[13] = T[14] = 0.0;
-  T[15] = 1.0;
-}
-
-// centred-frame accumulators -> world-frame accumulators (p = p_c + o, q = q_c + o)
-void acc_to_world(const double* a, const double o[3], double* out) {
-  const double W = a[0];
-  out[0] = W;
-  for (int i = 0; i < 3; ++i) {
-    out[1 + i] = a[1 + i] + W * o[i];
-    out[4 + i] = a[4 + i] + W * o[i];
-  }
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c)
-      out[7 + 3 * r + c] = a[7 + 3 * r + c] + a[1 + r] * o[c] + o[r] * a[4 + c] + W * o[r] * o[c];
-  out[16] = a[16];
 }
 
 // bounding box (and finiteness check) of a device-resident n x 3 cloud
@@ -1480,37 +1610,6 @@ int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float
   }
   if (bad > 0) return ctx->fail(MA_ERR_INVALID, "cloud has non-finite coordinates (filter them first, as the reference's read_point_cloud(remove_nan_points=True, remove_infinite_points=True) does)");
   return MA_OK;
-}
-
-GridP make_grid(const float lo[3], const float hi[3], const double o[3], float c) {
-  GridP g{};
-  g.ox = (float)((double)lo[0] - o[0]);
-  g.oy = (float)((double)lo[1] - o[1]);
-  g.oz = (float)((double)lo[2] - o[2]);
-  g.c = c;
-  g.inv_c = 1.0f / c;
-  const double ex = (double)hi[0] - lo[0], ey = (double)hi[1] - lo[1], ez = (double)hi[2] - lo[2];
-  g.nx = (int)std::floor(ex / c) + 1;
-  g.ny = (int)std::floor(ey / c) + 1;
-  g.nz = (int)std::floor(ez / c) + 1;
-  double maxabs = 0;
-  for (int a = 0; a < 3; ++a) maxabs = std::max({maxabs, std::fabs((double)lo[a] - o[a]), std::fabs((double)hi[a] - o[a])});
-  const float ulp = std::nextafterf((float)maxabs, INFINITY) - (float)maxabs;
-  g.delta = 8.0f * ulp + 1e-6f * c;
-  return g;
-}
-
-float clamp_cell_to_budget(const float lo[3], const float hi[3], float c, uint64_t max_cells) {
-  for (int it = 0; it < 64; ++it) {
-    const double nx = std::floor(((double)hi[0] - lo[0]) / c) + 1, ny = std::floor(((double)hi[1] - lo[1]) / c) + 1,
-                 nz = std::floor(((double)hi[2] - lo[2]) / c) + 1;
-    const double cells = nx * ny * nz;
-    if (cells <= (double)max_cells && nx < 2e9 && ny < 2e9 && nz < 2e9) return c;
-    // grow the edge by what the count calls for (not by a fixed factor: the result should sit
-    // just under the budget, not up to 2x below it)
-    c *= (float)std::min(2.0, std::max(1.004, std::cbrt(cells / (double)max_cells) * 1.002));
-  }
-  return c;
 }
 
 // keys/vals for `n` raw points + optional histogram; then a stable radix sort by cell id.
@@ -1566,26 +1665,15 @@ int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, 
   return MA_OK;
 }
 
-// One source point per thread.  G is a multiple of 8 * kXcdSeg (the XCD remap is a
-// bijection) and of kXcdSeg << gshift, where 2^gshift segments form one scheduling group
-// and there are at most kMaxGroups groups (the surplus workgroups have no points).
-uint32_t grid_for(uint32_t n, uint32_t* gshift_out = nullptr) {
-  const uint32_t q = 8u * kXcdSeg;
-  uint32_t G = std::max<uint32_t>(q, (div_up(n, kNNBlock) + q - 1u) / q * q);
-  uint32_t gshift = 0;
-  while (((G / kXcdSeg) >> gshift) > (uint32_t)kMaxGroups) ++gshift;
-  const uint32_t unit = std::max<uint32_t>(q, kXcdSeg << gshift);   // both are powers of two
-  G = (G + unit - 1u) / unit * unit;
-  if (gshift_out) *gshift_out = gshift;
-  return G;
-}
-
 int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
   HIPCHK(ctx->state.ensure(sizeof(DevState)));
   HIPCHK(ctx->partials.ensure((size_t)kNAcc * grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(double)));
   HIPCHK(ctx->acc19.ensure(kNAcc * sizeof(double)));
   HIPCHK(ctx->wg_cost.ensure((size_t)grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(uint32_t)));
-  HIPCHK(ctx->seg_order.ensure((size_t)kMaxGroups * sizeof(uint32_t)));
+  if (!ctx->seg_order.p) {  // never read before the first ranking wrote it (order is used from iteration 1 on); zeroed anyway
+    HIPCHK(ctx->seg_order.ensure((size_t)kMaxGroups * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(ctx->seg_order.p, 0, (size_t)kMaxGroups * sizeof(uint32_t), ctx->stream));
+  }
   if (!ctx->ticket.p) {   // arrival counter of k_reduce_solve: every launch leaves it at 0 again
     HIPCHK(ctx->ticket.ensure(sizeof(uint32_t)));
     HIPCHK(hipMemsetAsync(ctx->ticket.p, 0, sizeof(uint32_t), ctx->stream));
@@ -1610,6 +1698,8 @@ int upload_state(ma_ctx* ctx, const double* T) {
     HIPCHK(ctx->prev.ensure((size_t)ctx->n * 4));
     HIPCHK(hipMemsetAsync(ctx->prev.p, 0xFF, (size_t)ctx->n * 4, ctx->stream));
   }
+  *ctx->host_done = 0;   // every earlier launch has completed: each entry point that runs the loop ends with a sync
+  ctx->state_valid = ctx->have_src;
   return MA_OK;
 }
 
@@ -1637,9 +1727,11 @@ int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float
 }
 
 // partials -> ctx->acc19 (19 workgroups), then optionally the solve (one wavefront)
-int launch_reduce(ma_ctx* ctx) {
-  hipLaunchKernelGGL(k_reduce19, dim3(kNAcc), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
-                     ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>());
+// with_rank: one more workgroup orders the scheduling groups for the next search launch
+int launch_reduce(ma_ctx* ctx, bool with_rank = false) {
+  hipLaunchKernelGGL(k_reduce19, dim3(kNAcc + (with_rank ? 1 : 0)), dim3(kBlock), 0, ctx->stream,
+                     ctx->partials.as<double>(), ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>(),
+                     ctx->wg_cost.as<uint32_t>(), ctx->seg_order.as<uint32_t>(), ctx->last_gshift);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
@@ -1649,14 +1741,14 @@ int launch_reduce_solve(ma_ctx* ctx, double tol) {
   hipLaunchKernelGGL(k_reduce_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
                      ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>(), ctx->ticket.as<uint32_t>(),
                      ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(),
-                     ctx->seg_order.as<uint32_t>(), ctx->last_gshift);
+                     ctx->seg_order.as<uint32_t>(), ctx->last_gshift, tol > 0.0 ? ctx->host_done : (int*)nullptr);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
 
 int launch_solve(ma_ctx* ctx, double tol) {
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(kWave), 0, ctx->stream, ctx->acc19.as<double>(),
-                     ctx->state.as<DevState>(), ctx->trace.as<double>(), ctx->trace_cap, tol);
+                     ctx->state.as<DevState>(), ctx->trace.as<double>(), ctx->trace_cap, tol, (int*)nullptr);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
@@ -1676,6 +1768,21 @@ void fill_stats(const DevState& s, double gpu_ms, ma_stats* st) {
   st->rmse = s.last_rmse;
   st->inliers = s.last_W;
   st->gpu_ms = gpu_ms;
+}
+
+// No C++ exception crosses the C ABI: std::vector / std::string allocations inside the entry
+// points can throw std::bad_alloc, which is turned into a status here.
+template <typename F>
+int guarded(ma_ctx* ctx, F&& body) noexcept {
+  try {
+    if (ctx) ctx->oom = false;
+    return body();
+  } catch (const std::bad_alloc&) {
+    if (ctx) ctx->oom = true;
+    return MA_ERR_NO_MEMORY;
+  } catch (...) {
+    return MA_ERR_INVALID;
+  }
 }
 
 }  // namespace
@@ -1701,13 +1808,19 @@ const char* ma_status_string(int status) {
     case MA_ERR_STATE: return "call-order error";
     case MA_ERR_DEGENERATE: return "degenerate correspondences";
     case MA_ERR_TOO_LARGE: return "cloud too large";
+    case MA_ERR_COMM: return "RCCL error";
+    case MA_ERR_NO_MEMORY: return "out of host memory";
     default: return "unknown status";
   }
 }
 
-const char* ma_last_error(const ma_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char* ma_last_error(const ma_ctx* ctx) {
+  if (ctx && ctx->oom) return "out of host memory inside the library";
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
 
 int ma_create(int device, ma_ctx** out) {
+  return guarded(nullptr, [&]() -> int {
   if (!out) { g_create_error = "out is NULL"; return MA_ERR_INVALID; }
   *out = nullptr;
   int count = 0;
@@ -1734,20 +1847,22 @@ int ma_create(int device, ma_ctx** out) {
   ctx->stream = ctx->own_stream;
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_done), 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+  *ctx->host_done = 0;
+  for (DevBuf* b : ctx->all_bufs()) b->stats = &ctx->mem;
   *out = ctx;
   return MA_OK;
+  });
 }
 
 int ma_destroy(ma_ctx* ctx) {
   if (!ctx) return MA_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  for (int l = 0; l < kLevels; ++l) { ctx->gold[l].release(); ctx->cstart[l].release(); }
-  for (DevBuf* b : {&ctx->map_pts, &ctx->map_keys_a, &ctx->map_keys_b, &ctx->map_flags, &ctx->map_seg, &ctx->perm0, &ctx->inv0, &ctx->occ_a, &ctx->occ_b, &ctx->src, &ctx->src_perm, &ctx->raw, &ctx->wts, &ctx->keys_a,
-                    &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc, &ctx->depth_in,
-                    &ctx->state, &ctx->partials, &ctx->trace, &ctx->acc19, &ctx->ticket, &ctx->wg_cost, &ctx->seg_order, &ctx->nn_idx, &ctx->nn_d2,
-                    &ctx->nn_tmp, &ctx->prev})
-    b->release();
+  if (ctx->comm) comm_destroy(ctx);
+  for (DevBuf* b : ctx->all_bufs()) b->release();
+  if (ctx->host_done) (void)hipHostFree(ctx->host_done);
+  for (hipEvent_t e : ctx->batch_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1757,21 +1872,26 @@ int ma_destroy(ma_ctx* ctx) {
 }
 
 int ma_set_stream(ma_ctx* ctx, void* hip_stream, int external) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->stream = external ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
   return MA_OK;
+  });
 }
 
 int ma_sync(ma_ctx* ctx) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return MA_OK;
+  });
 }
 
 int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   if (!xyz && m) return ctx->fail(MA_ERR_INVALID, "xyz is NULL");
   if (m == 0) return ctx->fail(MA_ERR_EMPTY, "gold cloud is empty");
@@ -1780,11 +1900,13 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
   HIPCHK(hipSetDevice(ctx->device));
   ctx->have_gold = false;
   ctx->have_src = false;
+  ctx->state_valid = false;
   const uint32_t n = (uint32_t)m;
   HIPCHK(ctx->raw.ensure((size_t)n * 12));
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
   return build_gold_from_raw(ctx, n, cell);
+  });
 }
 
 static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
@@ -1948,24 +2070,32 @@ int ma_grid_info_get(const ma_ctx* ctx, ma_grid_info* out) {
 }
 
 int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t n64) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "set the gold map before the source cloud");
   if (!xyz && n64) return ctx->fail(MA_ERR_INVALID, "xyz is NULL");
   if (n64 == 0) return ctx->fail(MA_ERR_EMPTY, "source cloud is empty");
-  if (n64 >= 0xFFFFFFFEull) return ctx->fail(MA_ERR_TOO_LARGE, "source cloud has more than 2^32-2 points");
+  if (n64 >= (1ull << 31)) return ctx->fail(MA_ERR_TOO_LARGE, "source cloud has 2^31 or more points (32-bit item counts of the sort)");
   HIPCHK(hipSetDevice(ctx->device));
   ctx->have_src = false;
+  ctx->state_valid = false;
   const uint32_t n = (uint32_t)n64;
   HIPCHK(ctx->raw.ensure((size_t)n * 12));
   HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
   const float* d_w = nullptr;
   if (weights) {
-    for (uint64_t k = 0; k < n64; ++k)
-      if (!(weights[k] >= 0.f) || !std::isfinite(weights[k]))
-        return ctx->fail(MA_ERR_INVALID, "weights must be finite and >= 0");
     HIPCHK(ctx->wts.ensure((size_t)n * 4));
     HIPCHK(hipMemcpyAsync(ctx->wts.p, weights, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     d_w = ctx->wts.as<float>();
+    HIPCHK(ctx->misc.ensure(64));
+    HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_count_bad_weights, dim3(std::min<uint32_t>(div_up(n, kBlock), 1024)), dim3(kBlock), 0,
+                       ctx->stream, d_w, n, ctx->misc.as<unsigned long long>());
+    HIPCHK(hipGetLastError());
+    unsigned long long bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, ctx->misc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (bad) return ctx->fail(MA_ERR_INVALID, "weights must be finite and >= 0");
   }
   float lo[3], hi[3];
   int rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, lo, hi);
@@ -1988,19 +2118,22 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
   ctx->src_sorted = true;
   ctx->have_src = true;
   return MA_OK;
+  });
 }
 
 int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height,
                              const float K[4], const double T[16], float depth_scale, uint64_t* n_valid) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "set the gold map before the source cloud");
   if (!depth || !K || !T) return ctx->fail(MA_ERR_INVALID, "NULL argument");
   if (dtype != 0 && dtype != 1) return ctx->fail(MA_ERR_INVALID, "dtype must be 0 (float32) or 1 (uint16)");
-  if (width <= 0 || height <= 0 || (uint64_t)width * height >= 0xFFFFFFFEull) return ctx->fail(MA_ERR_INVALID, "bad image size");
+  if (width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 31)) return ctx->fail(MA_ERR_INVALID, "bad image size");
   if (!(K[0] != 0.f) || !(K[1] != 0.f) || !(depth_scale > 0.f) || !std::isfinite(depth_scale)) return ctx->fail(MA_ERR_INVALID, "bad intrinsics / depth_scale");
   for (int i = 0; i < 16; ++i) if (!std::isfinite(T[i])) return ctx->fail(MA_ERR_INVALID, "non-finite camera pose");
   HIPCHK(hipSetDevice(ctx->device));
   ctx->have_src = false;
+  ctx->state_valid = false;
   const uint32_t npx = (uint32_t)((uint64_t)width * height);
   const size_t esz = dtype == 0 ? 4 : 2;
   HIPCHK(ctx->depth_in.ensure((size_t)npx * esz));
@@ -2054,9 +2187,11 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   ctx->src_sorted = false;
   ctx->have_src = true;
   return MA_OK;
+  });
 }
 
 int ma_map_begin(ma_ctx* ctx, float voxel, uint64_t capacity_points) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   if (!(voxel > 0.f) || !std::isfinite(voxel)) return ctx->fail(MA_ERR_INVALID, "voxel must be > 0");
   if (capacity_points == 0 || capacity_points >= (1ull << 31)) return ctx->fail(MA_ERR_INVALID, "capacity must be in [1, 2^31)");
@@ -2067,10 +2202,12 @@ int ma_map_begin(ma_ctx* ctx, float voxel, uint64_t capacity_points) {
   ctx->map_voxel = voxel;
   ctx->map_has_origin = false;
   return MA_OK;
+  });
 }
 
 int ma_map_add_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height, const float K[4],
                      const double T[16], float depth_scale, uint64_t* n_added) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   if (ctx->map_cap == 0) return ctx->fail(MA_ERR_STATE, "ma_map_begin first");
   if (!depth || !K || !T) return ctx->fail(MA_ERR_INVALID, "NULL argument");
@@ -2134,9 +2271,11 @@ int ma_map_add_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int h
   ctx->map_n += total;
   if (n_added) *n_added = total;
   return MA_OK;
+  });
 }
 
 int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t* n_io) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx || !n_io) return MA_ERR_INVALID;
   if (ctx->map_cap == 0) return ctx->fail(MA_ERR_STATE, "ma_map_begin first");
   if (ctx->map_n == 0) return ctx->fail(MA_ERR_EMPTY, "the map holds no point");
@@ -2188,15 +2327,18 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
     if (nvox >= (1u << 28)) return ctx->fail(MA_ERR_TOO_LARGE, "map has 2^28 or more voxels");
     ctx->have_gold = false;
     ctx->have_src = false;
+    ctx->state_valid = false;
     return build_gold_from_raw(ctx, nvox, cell);   // ctx->raw already holds the voxel centroids
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return MA_OK;
+  });
 }
 
 int ma_lift_boxes(ma_ctx* ctx, const void* depth, int dtype, int width, int height, const float K[4],
                   const double T[16], float depth_scale, const float* boxes_xyxy, uint64_t n_boxes,
                   double* corners_out, uint8_t* valid_out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   if (!K || !T || (!boxes_xyxy && n_boxes) || (!corners_out && n_boxes)) return ctx->fail(MA_ERR_INVALID, "NULL argument");
   if (n_boxes == 0) return MA_OK;
@@ -2240,9 +2382,11 @@ int ma_lift_boxes(ma_ctx* ctx, const void* depth, int dtype, int width, int heig
   if (valid_out) HIPCHK(hipMemcpyAsync(valid_out, d_valid, nc, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return MA_OK;
+  });
 }
 
 int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx || !n) return MA_ERR_INVALID;
   if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set");
   if (!xyz_out) { *n = ctx->n; return MA_OK; }
@@ -2256,9 +2400,11 @@ int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   *n = ctx->n;
   return MA_OK;
+  });
 }
 
 int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16], ma_stats* stats) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   int rc;
   if ((rc = check_params(ctx, params))) return rc;
@@ -2277,13 +2423,33 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
       ctx->kev.push_back(e);
     }
   }
+  // With a convergence test (tol > 0) the loop usually stops long before max_iter, and every
+  // launch after that only finds `done` set (3-6 us each).  The host therefore enqueues in
+  // batches of kBatch iterations and, before batch b, waits for the end of batch b-2 and reads
+  // the pinned word the solve sets when it stops: one batch always stays queued behind the one
+  // being waited for, so the device never idles.  tol = 0 (the benchmark) takes no part in this.
+  constexpr int kBatch = 8;
+  const bool early_exit = params->tol > 0.0 && !timek;
+  if (early_exit) {
+    const int need = (params->max_iter + kBatch - 1) / kBatch;
+    while ((int)ctx->batch_ev.size() < need) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ctx->batch_ev.push_back(e);
+    }
+  }
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   if (timek) HIPCHK(hipEventRecord(ctx->kev[0], ctx->stream));
   for (int k = 0; k < params->max_iter; ++k) {
+    if (early_exit && k % kBatch == 0 && k >= 2 * kBatch) {
+      HIPCHK(hipEventSynchronize(ctx->batch_ev[k / kBatch - 2]));
+      if (*static_cast<volatile int*>(ctx->host_done)) break;
+    }
     if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr, MA_SCHED != 0))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
     if ((rc = launch_reduce_solve(ctx, params->tol))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 2], ctx->stream));
+    if (early_exit && (k + 1) % kBatch == 0) HIPCHK(hipEventRecord(ctx->batch_ev[k / kBatch], ctx->stream));
   }
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   DevState s;
@@ -2302,11 +2468,13 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   }
   centred_to_world(s, ctx->origin, T_out);
   fill_stats(s, ms, stats);
-  if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "fewer than 3 correspondences inside max_corr_dist, or rank-deficient covariance");
+  if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "no correspondence inside max_corr_dist, or rank-deficient covariance (fewer than 3 non-collinear pairs)");
   return MA_OK;
+  });
 }
 
 int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx || !out || max_rows < 0) return MA_ERR_INVALID;
   if (!ctx->state.p || !ctx->trace.p) return ctx->fail(MA_ERR_STATE, "no iteration has run");
   HIPCHK(hipSetDevice(ctx->device));
@@ -2324,6 +2492,7 @@ int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {
     o[17] = in[17]; o[18] = in[18]; o[19] = in[19];
   }
   return rows;
+  });
 }
 
 #if MA_WGTIMES
@@ -2346,6 +2515,7 @@ int ma_get_kernel_times(ma_ctx* ctx, double out[4]) {
 
 int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16], double acc_out[MA_ACC_LEN],
                 double T_out[16]) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   int rc;
   if ((rc = check_params(ctx, params))) return rc;
@@ -2361,11 +2531,13 @@ int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16], dou
   if ((rc = fetch_state(ctx, &s))) return rc;
   if (acc_out) acc_to_world(a, ctx->origin, acc_out);
   if (T_out) centred_to_world(s, ctx->origin, T_out);
-  if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "fewer than 3 correspondences inside max_corr_dist, or rank-deficient covariance");
+  if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "no correspondence inside max_corr_dist, or rank-deficient covariance (fewer than 3 non-collinear pairs)");
   return MA_OK;
+  });
 }
 
 int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_out, float* d2_out) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   int rc;
   if ((rc = need_ready(ctx))) return rc;
@@ -2394,17 +2566,21 @@ int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_o
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   return MA_OK;
+  });
 }
 
 int ma_state_set(ma_ctx* ctx, const double T[16]) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "gold map not set");
   if (T) for (int i = 0; i < 16; ++i) if (!std::isfinite(T[i])) return ctx->fail(MA_ERR_INVALID, "non-finite transform");
   HIPCHK(hipSetDevice(ctx->device));
   return upload_state(ctx, T);
+  });
 }
 
 int ma_state_get(ma_ctx* ctx, double T_out[16], ma_stats* stats) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   if (!ctx->state.p) return ctx->fail(MA_ERR_STATE, "no state (ma_state_set / ma_icp first)");
   HIPCHK(hipSetDevice(ctx->device));
@@ -2414,32 +2590,217 @@ int ma_state_get(ma_ctx* ctx, double T_out[16], ma_stats* stats) {
   if (T_out) centred_to_world(s, ctx->origin, T_out);
   fill_stats(s, 0.0, stats);
   return MA_OK;
+  });
 }
 
 int ma_step_accumulate(ma_ctx* ctx, const ma_params* params, void* acc_dev) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   int rc;
   if ((rc = check_params(ctx, params))) return rc;
   if ((rc = need_ready(ctx))) return rc;
-  if (!ctx->state.p) return ctx->fail(MA_ERR_STATE, "ma_state_set first");
+  if (!ctx->state_valid) return ctx->fail(MA_ERR_STATE, "no valid stepping state: call ma_state_set after the clouds are set (a new gold map or source cloud invalidates it)");
   if (!acc_dev) return ctx->fail(MA_ERR_INVALID, "acc_dev is NULL");
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
   if ((rc = launch_reduce(ctx))) return rc;
   HIPCHK(hipMemcpyAsync(acc_dev, ctx->acc19.p, MA_ACC_LEN * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return MA_OK;
+  });
 }
 
 int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
   int rc;
   if ((rc = check_params(ctx, params))) return rc;
-  if (!ctx->state.p) return ctx->fail(MA_ERR_STATE, "ma_state_set first");
+  if (!ctx->state_valid) return ctx->fail(MA_ERR_STATE, "no valid stepping state: call ma_state_set after the clouds are set (a new gold map or source cloud invalidates it)");
   if (!acc_dev) return ctx->fail(MA_ERR_INVALID, "acc_dev is NULL");
   HIPCHK(hipSetDevice(ctx->device));
   // rows 17,18 (work counters) keep the local values of the accumulate step
   HIPCHK(hipMemcpyAsync(ctx->acc19.p, acc_dev, MA_ACC_LEN * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return launch_solve(ctx, params->tol);
+  });
+}
+
+int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out) {
+  if (!ctx || !out) return MA_ERR_INVALID;
+  out->device_allocs = ctx->mem.allocs;
+  out->device_frees = ctx->mem.frees;
+  out->bytes_live = ctx->mem.bytes_live;
+  out->bytes_peak = ctx->mem.bytes_peak;
+  return MA_OK;
+}
+
+int ma_lift_boxes_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int width, int height, uint32_t n_frames,
+                        const float K[4], const double* T_cam_to_world, float depth_scale, const float* boxes_xyxy,
+                        const uint32_t* box_frame, uint64_t n_boxes, double* corners_out, uint8_t* valid_out) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!depth_frames || !K || !T_cam_to_world || (!boxes_xyxy && n_boxes) || (!box_frame && n_boxes) || (!corners_out && n_boxes))
+    return ctx->fail(MA_ERR_INVALID, "NULL argument");
+  if (dtype != 0 && dtype != 1) return ctx->fail(MA_ERR_INVALID, "dtype must be 0 (float32) or 1 (uint16)");
+  if (width <= 0 || height <= 0 || n_frames == 0 || (uint64_t)width * height * n_frames >= (1ull << 40)) return ctx->fail(MA_ERR_INVALID, "bad image size / frame count");
+  if (n_boxes > (1ull << 28)) return ctx->fail(MA_ERR_TOO_LARGE, "too many boxes");
+  if (!(K[0] != 0.f) || !(K[1] != 0.f) || !(depth_scale > 0.f) || !std::isfinite(depth_scale)) return ctx->fail(MA_ERR_INVALID, "bad intrinsics / depth_scale");
+  for (uint64_t i = 0; i < 16ull * n_frames; ++i) if (!std::isfinite(T_cam_to_world[i])) return ctx->fail(MA_ERR_INVALID, "non-finite camera pose");
+  for (uint64_t b = 0; b < n_boxes; ++b) if (box_frame[b] >= n_frames) return ctx->fail(MA_ERR_INVALID, "box_frame entry out of range");
+  if (n_boxes == 0) return MA_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t esz = dtype == 0 ? 4 : 2, frame_bytes = (size_t)width * height * esz;
+  std::vector<double> poses((size_t)n_frames * 12);
+  for (uint32_t f = 0; f < n_frames; ++f)
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) poses[(size_t)f * 12 + 4 * r + c] = T_cam_to_world[(size_t)f * 16 + 4 * r + c];
+  const uint32_t nc = (uint32_t)n_boxes * 4u;
+  HIPCHK(ctx->lift_frames.ensure(frame_bytes * n_frames));
+  HIPCHK(ctx->lift_poses.ensure(poses.size() * 8 + n_boxes * 4));
+  HIPCHK(ctx->raw.ensure((size_t)n_boxes * 16));
+  HIPCHK(ctx->misc.ensure((size_t)nc * 24 + nc));
+  // ONE upload of the whole batch of frames, one of the poses + frame indices, one of the boxes
+  HIPCHK(hipMemcpyAsync(ctx->lift_frames.p, depth_frames, frame_bytes * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->lift_poses.p, poses.data(), poses.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  uint32_t* d_frame = reinterpret_cast<uint32_t*>(ctx->lift_poses.as<double>() + poses.size());
+  HIPCHK(hipMemcpyAsync(d_frame, box_frame, n_boxes * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->raw.p, boxes_xyxy, (size_t)n_boxes * 16, hipMemcpyHostToDevice, ctx->stream));
+  double* d_out = ctx->misc.as<double>();
+  uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_out + (size_t)nc * 3);
+  const double fx_inv = 1.0 / (double)K[0], fy_inv = 1.0 / (double)K[1], inv_scale = 1.0 / (double)depth_scale;
+  if (dtype == 0) {
+    hipLaunchKernelGGL(k_lift_boxes_batch<float>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       ctx->lift_frames.as<float>(), width, height, n_frames, fx_inv, fy_inv, (double)K[2], (double)K[3],
+                       inv_scale, ctx->lift_poses.as<double>(), ctx->raw.as<float>(), d_frame, nc, d_out, d_valid);
+  } else {
+    hipLaunchKernelGGL(k_lift_boxes_batch<uint16_t>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       ctx->lift_frames.as<uint16_t>(), width, height, n_frames, fx_inv, fy_inv, (double)K[2], (double)K[3],
+                       inv_scale, ctx->lift_poses.as<double>(), ctx->raw.as<float>(), d_frame, nc, d_out, d_valid);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(corners_out, d_out, (size_t)nc * 24, hipMemcpyDeviceToHost, ctx->stream));
+  if (valid_out) HIPCHK(hipMemcpyAsync(valid_out, d_valid, nc, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // the one synchronisation of the batch
+  return MA_OK;
+  });
+}
+
+// ---- RCCL: communicator bootstrap + the sharded-source loop --------------------------------
+int ma_comm_unique_id(void* id_out) {
+  return guarded(nullptr, [&]() -> int {
+  if (!id_out) return MA_ERR_INVALID;
+  RcclApi* api = rccl_api();
+  if (!api) { g_create_error = g_rccl.error; return MA_ERR_COMM; }
+  ncclUniqueId id;
+  const ncclResult_t r = api->GetUniqueId(&id);
+  if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + api->GetErrorString(r); return MA_ERR_COMM; }
+  static_assert(sizeof(ncclUniqueId) == MA_COMM_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id_out, &id, sizeof(id));
+  return MA_OK;
+  });
+}
+
+int ma_comm_init(ma_ctx* ctx, const void* id, int n_ranks, int rank) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return ctx->fail(MA_ERR_INVALID, "bad communicator arguments");
+  RcclApi* api = rccl_api();
+  if (!api) return ctx->fail(MA_ERR_COMM, g_rccl.error);
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->comm) comm_destroy(ctx);
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  ncclComm_t comm = nullptr;
+  NCCLCHK(api->CommInitRank(&comm, n_ranks, uid, rank));
+  ctx->comm = comm;
+  ctx->comm_ranks = n_ranks;
+  ctx->comm_rank = rank;
+  return MA_OK;
+  });
+}
+
+int ma_comm_destroy(ma_ctx* ctx) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  comm_destroy(ctx);
+  return MA_OK;
+  });
+}
+
+int ma_comm_allgather_f64(ma_ctx* ctx, const double* in, uint64_t count, double* out) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!ctx->comm) return ctx->fail(MA_ERR_STATE, "no communicator (ma_comm_init)");
+  if (!in || !out || count == 0 || count > (1ull << 24)) return ctx->fail(MA_ERR_INVALID, "bad gather arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t bytes = count * sizeof(double), total = bytes * (size_t)ctx->comm_ranks;
+  HIPCHK(ctx->nn_tmp.ensure(bytes + total));
+  char* base = static_cast<char*>(ctx->nn_tmp.p);
+  HIPCHK(hipMemcpyAsync(base, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  NCCLCHK(rccl_api()->AllGather(base, base + bytes, count, ncclDouble, static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+  HIPCHK(hipMemcpyAsync(out, base + bytes, total, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+  });
+}
+
+int ma_comm_allreduce_f64(ma_ctx* ctx, double* inout, uint64_t count, int op) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!ctx->comm) return ctx->fail(MA_ERR_STATE, "no communicator (ma_comm_init)");
+  if (!inout || count == 0 || count > (1ull << 24) || op < 0 || op > 1) return ctx->fail(MA_ERR_INVALID, "bad reduce arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t bytes = count * sizeof(double);
+  HIPCHK(ctx->nn_tmp.ensure(bytes));
+  HIPCHK(hipMemcpyAsync(ctx->nn_tmp.p, inout, bytes, hipMemcpyHostToDevice, ctx->stream));
+  NCCLCHK(rccl_api()->AllReduce(ctx->nn_tmp.p, ctx->nn_tmp.p, count, ncclDouble, op == 0 ? ncclSum : ncclMax,
+                                static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+  HIPCHK(hipMemcpyAsync(inout, ctx->nn_tmp.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+  });
+}
+
+// One pair over the ranks of the communicator: gold map + grids replicated (every rank called
+// ma_set_gold with the same cloud), this rank's shard of the comparison cloud in ma_set_source.
+// Per iteration, all on the ctx stream and with the loop here in C (no host code between the
+// iterations, no host sync):
+//   k_nn_accum (a4+a5, local shard) -> k_reduce19 (+ schedule ranking) ->
+//   ncclAllReduce(sum, 17 x f64, in place) -> k_solve (a6+a7, redundantly on every rank).
+// Identical inputs give identical states on all ranks, so nothing is broadcast.
+int ma_icp_sharded(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16], ma_stats* stats) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  int rc;
+  if ((rc = check_params(ctx, params))) return rc;
+  if ((rc = need_ready(ctx))) return rc;
+  if (!ctx->comm) return ctx->fail(MA_ERR_STATE, "no communicator (ma_comm_init)");
+  if (!T_out) return ctx->fail(MA_ERR_INVALID, "T_out is NULL");
+  if (init) for (int i = 0; i < 16; ++i) if (!std::isfinite(init[i])) return ctx->fail(MA_ERR_INVALID, "non-finite init");
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ensure_loop_buffers(ctx, params->max_iter))) return rc;
+  if ((rc = upload_state(ctx, init))) return rc;
+  const float best2 = open_gate2(params->max_corr_dist);
+  const bool count = (params->flags & MA_FLAG_COUNT_WORK) != 0;
+  RcclApi* api = rccl_api();
+  ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int k = 0; k < params->max_iter; ++k) {
+    if ((rc = launch_nn<0>(ctx, count, best2, nullptr, nullptr, MA_SCHED != 0))) return rc;
+    if ((rc = launch_reduce(ctx, MA_SCHED != 0))) return rc;
+    NCCLCHK(api->AllReduce(ctx->acc19.p, ctx->acc19.p, MA_ACC_LEN, ncclDouble, ncclSum, comm, ctx->stream));
+    if ((rc = launch_solve(ctx, params->tol))) return rc;
+  }
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  DevState s;
+  if ((rc = fetch_state(ctx, &s))) return rc;
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  centred_to_world(s, ctx->origin, T_out);
+  fill_stats(s, ms, stats);
+  if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "no correspondence inside max_corr_dist, or rank-deficient covariance");
+  return MA_OK;
+  });
 }
 
 }  // extern "C"

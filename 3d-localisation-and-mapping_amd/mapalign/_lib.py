@@ -28,6 +28,9 @@ MA_ERR_EMPTY = -4
 MA_ERR_STATE = -5
 MA_ERR_DEGENERATE = -6
 MA_ERR_TOO_LARGE = -7
+MA_ERR_COMM = -8
+MA_ERR_NO_MEMORY = -9
+MA_COMM_ID_BYTES = 128
 
 
 class MapAlignError(RuntimeError):
@@ -57,6 +60,11 @@ class ma_grid_info(C.Structure):
     _fields_ = [("cell", C.c_float), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
                 ("n_cells", C.c_uint64), ("n_occupied", C.c_uint64), ("origin", C.c_double * 3),
                 ("build_ms", C.c_double)]
+
+
+class ma_mem_info(C.Structure):
+    _fields_ = [("device_allocs", C.c_uint64), ("device_frees", C.c_uint64), ("bytes_live", C.c_uint64),
+                ("bytes_peak", C.c_uint64)]
 
 
 _ctx_p = C.c_void_p
@@ -94,6 +102,15 @@ ABI = {
     "ma_state_get": (C.c_int, [_ctx_p, _f64p, C.POINTER(ma_stats)]),
     "ma_step_accumulate": (C.c_int, [_ctx_p, C.POINTER(ma_params), C.c_void_p]),
     "ma_step_solve": (C.c_int, [_ctx_p, C.POINTER(ma_params), C.c_void_p]),
+    "ma_mem_info_get": (C.c_int, [_ctx_p, C.POINTER(ma_mem_info)]),
+    "ma_lift_boxes_batch": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, _f32p, _f64p,
+                                      C.c_float, _f32p, _u32p, C.c_uint64, _f64p, C.POINTER(C.c_uint8)]),
+    "ma_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "ma_comm_init": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int]),
+    "ma_comm_destroy": (C.c_int, [_ctx_p]),
+    "ma_icp_sharded": (C.c_int, [_ctx_p, C.POINTER(ma_params), _f64p, _f64p, C.POINTER(ma_stats)]),
+    "ma_comm_allgather_f64": (C.c_int, [_ctx_p, _f64p, C.c_uint64, _f64p]),
+    "ma_comm_allreduce_f64": (C.c_int, [_ctx_p, _f64p, C.c_uint64, C.c_int]),
 }
 
 _lib = None

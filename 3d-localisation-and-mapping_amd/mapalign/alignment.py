@@ -25,7 +25,7 @@ import pickle
 import numpy as np
 
 from . import boxes, coarse, ply, transforms
-from .engine import MapAligner
+from .api import cached_engine
 
 DATA_ROOT = os.path.join("src", "common", "data")     # visualise.py:241
 GOLD_FOLDER = "gold_std"                               # visualise.py:224-225
@@ -62,11 +62,14 @@ class Alignment:
 
     def align_clouds(self, gold_cloud, comparison_cloud):
         """Staged alignment of two point arrays -> (transformations list, composed 4x4, info)."""
-        with MapAligner(self.device) as eng:
+        eng, lock = cached_engine(self.device)     # one context per device for the process: warm buffers
+        with lock:
             eng.set_gold(gold_cloud)
             stages, T0, info = [], np.eye(4), {}
             if self.coarse_stage:
-                stages, T0, info = coarse.coarse_align(eng, gold_cloud, comparison_cloud)
+                stages, T0, info = coarse.coarse_align(eng, gold_cloud, comparison_cloud,
+                                                       base_pose_df=self.base_pose_df,
+                                                       comparison_pose_df=self.comparison_pose_df)
             eng.set_source(comparison_cloud)
             res = eng.icp(self.max_iter, self.tol, self.max_corr_dist, init=T0)
         T_icp = res.T @ np.linalg.inv(T0)          # refinement applied AFTER the coarse stages

@@ -98,3 +98,33 @@ def match_bboxes(gold_bboxes, aligned_bboxes, max_dist=0.5, csv_output_file=None
             for g in missing:
                 w.writerow([g, lab(grows[g]), "missing", "", "", *gc[g]])
     return {"matches": matches, "missing": missing, "unexpected": unexpected, "damaged": damaged}
+
+
+class BBoxComparison:
+    """The reference's call shape for the step the alignment feeds
+    (``/root/reference/task_def.py:190-197``)::
+
+        compare_bboxes = BBoxComparison(goldstd_bboxes, aligned_maintenance_bboxes, goldstd_mesh,
+                                        visualise=cfg.comparison_vis, csv_output_file=cfg.csv_output)
+        compare_bboxes.match_bboxes()
+
+    ``src/map_alignment/comparison.py`` is absent from the snapshot; the matching is
+    :func:`match_bboxes` (bipartite on centre distance, ``README.md:67``).  ``goldstd_mesh`` is
+    only shown by the reference's viewer (out of scope) and is kept for signature parity, as is
+    ``visualise``.  The result dict is returned and kept in ``self.result``.
+    """
+
+    def __init__(self, gold_bboxes, aligned_bboxes, goldstd_mesh=None, visualise=False, csv_output_file=None,
+                 max_dist=0.5):
+        self.gold_bboxes = gold_bboxes or {}
+        self.aligned_bboxes = aligned_bboxes or {}
+        self.goldstd_mesh = goldstd_mesh
+        self.visualise = visualise
+        self.csv_output_file = csv_output_file
+        self.max_dist = float(max_dist)
+        self.result = None
+
+    def match_bboxes(self):
+        self.result = match_bboxes(self.gold_bboxes, self.aligned_bboxes, max_dist=self.max_dist,
+                                   csv_output_file=self.csv_output_file)
+        return self.result

@@ -10,6 +10,16 @@ Stage 1  rotation about the comparison centroid that maps its principal axes ont
 Stage 2  translation of the rotated centroid onto the gold centroid           -> 4x4
 Stage 3  ICP refinement (mapalign.align)                                       -> 4x4
 
+The camera trajectories the reference hands to ``Alignment`` (``base_pose_df`` /
+``comparison_pose_df``, ``/root/reference/task_def.py:176-177``; columns ``timestamp tx ty tz qx
+qy qz qw``, ``src/mapper/database_query.py:20-25``) decide what geometry alone cannot: a
+carriage shell is nearly symmetric under a half turn about its vertical axis, so the PCA
+candidates that differ by 180 degrees can score almost equally on the clouds.  Both scans
+are walked through the vehicle along a trajectory lying INSIDE the cloud, so the candidate
+must also map the comparison trajectory onto the gold one (direction of travel, which side
+of the centre line the camera was carried on); the trajectory residual is added to the
+cloud score.
+
 The reference's own coarse stage (inside the absent align.py) is unknown; only its
 output format is pinned.  This is host-side glue (3x3 eigen-decompositions); all cloud
 work goes through the HIP engine.
@@ -42,10 +52,53 @@ def candidate_rotations(axes_gold, axes_comp):
     return out
 
 
-def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0):
+def trajectory_xyz(pose_df):
+    """``[K,3]`` camera positions from a pose table: a DataFrame / mapping with ``tx ty tz``
+    columns (``src/mapper/database_query.py:22``) or an array whose first three columns —
+    after an optional leading timestamp column, as the reference slices ``row[1:]``
+    (``pose_processor.py:109``) — are the position.  ``None`` -> ``None``."""
+    if pose_df is None:
+        return None
+    if hasattr(pose_df, "columns") or isinstance(pose_df, dict):
+        cols = [np.asarray(pose_df[k], dtype=np.float64) for k in ("tx", "ty", "tz")]
+        xyz = np.stack(cols, axis=1)
+    else:
+        a = np.asarray(pose_df, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] < 3:
+            raise ValueError("pose array must be [K, >=3]")
+        xyz = a[:, 1:4] if a.shape[1] in (8, 9) else a[:, :3]
+    xyz = xyz[np.all(np.isfinite(xyz), axis=1)]
+    return xyz if len(xyz) >= 2 else None
+
+
+def resample_polyline(xyz, n=64):
+    """``n`` points equally spaced in arc length along a trajectory (scans are recorded at
+    different speeds, so samples are compared by the fraction of the path walked)."""
+    seg = np.linalg.norm(np.diff(xyz, axis=0), axis=1)
+    s = np.concatenate([[0.0], np.cumsum(seg)])
+    if s[-1] <= 0.0:
+        return np.repeat(xyz[:1], n, axis=0)
+    u = np.linspace(0.0, s[-1], n)
+    return np.stack([np.interp(u, s, xyz[:, a]) for a in range(3)], axis=1)
+
+
+def trajectory_residual(T, base_traj, comp_traj, n=64):
+    """rms distance between the gold trajectory and the transformed comparison trajectory,
+    both resampled by arc length; the better of the two walking directions counts (a scan
+    may be recorded from either end of the vehicle)."""
+    a = resample_polyline(base_traj, n)
+    b = resample_polyline(transforms.apply(T, comp_traj), n)
+    fwd = np.sqrt(np.mean(np.sum((a - b) ** 2, axis=1)))
+    rev = np.sqrt(np.mean(np.sum((a - b[::-1]) ** 2, axis=1)))
+    return float(min(fwd, rev))
+
+
+def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0, base_pose_df=None,
+                 comparison_pose_df=None):
     """Returns (stages, T_coarse, info); ``engine`` is a MapAligner with the gold map set.
 
-    ``stages`` = [(R, centre), T_translate] in the reference's mixed format.
+    ``stages`` = [(R, centre), T_translate] in the reference's mixed format.  With both
+    trajectories given, each candidate's score is ``sqrt(cloud_rmse^2 + trajectory_rms^2)``.
     """
     gold = np.asarray(gold_cloud, dtype=np.float64)
     comp = np.asarray(comparison_cloud, dtype=np.float64)
@@ -54,13 +107,21 @@ def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0):
     rng = np.random.default_rng(seed)
     sub = comp if len(comp) <= sample else comp[rng.choice(len(comp), sample, replace=False)]
     engine.set_source(sub.astype(np.float32))
-    scores = []
+    base_traj, comp_traj = trajectory_xyz(base_pose_df), trajectory_xyz(comparison_pose_df)
+    use_traj = base_traj is not None and comp_traj is not None
+    scores, cloud_scores, traj_scores = [], [], []
     cands = candidate_rotations(ag, ac)
     for R in cands:
         T = transforms.rt_to_matrix(np.eye(3), cg - cc) @ transforms.rotation_about_centre(R, cc)
         acc, _ = engine.icp_step(T, max_corr_dist=np.inf)
-        scores.append(float(np.sqrt(acc[16] / max(acc[0], 1.0))))
+        cloud = float(np.sqrt(acc[16] / max(acc[0], 1.0)))
+        traj = trajectory_residual(T, base_traj, comp_traj) if use_traj else 0.0
+        cloud_scores.append(cloud)
+        traj_scores.append(traj)
+        scores.append(float(np.hypot(cloud, traj)))
     best = int(np.argmin(scores))
     R = cands[best]
     stages = [(R, cc), transforms.rt_to_matrix(np.eye(3), cg - cc)]
-    return stages, transforms.compose(stages), {"scores": scores, "chosen": best}
+    return stages, transforms.compose(stages), {"scores": scores, "cloud_scores": cloud_scores,
+                                                "trajectory_scores": traj_scores if use_traj else None,
+                                                "chosen": best}

@@ -1,19 +1,24 @@
-"""Multi-GPU scheduling of the alignment path: one process per GPU,
-``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
+"""Multi-GPU scheduling of the alignment path: one process per GPU.
 
 Two modes, both without any per-point traffic between GPUs:
 
 * **pair-per-GPU** (:func:`align_pairs`) — scan pairs are independent; rank r runs the
-  whole ICP loop for pairs r, r+W, ... with zero communication inside the loop and one
-  small gather of the 4x4 results at the end.  This is the node-level (weak-scaling) mode.
-* **sharded source** (:func:`sharded_icp`) — one pair spread over the ranks of a group:
-  the gold map and its grid are replicated, the comparison cloud is block-partitioned,
-  and per iteration the ONLY exchange is one all-reduce(sum) of the 17-double
-  centroid / cross-covariance accumulator (136 B, latency-bound; RCCL's LL protocol),
-  after which every rank runs the identical 3x3 solve — no broadcast needed.
+  whole ICP loop for pairs r, r+W, ... with zero communication inside the loop and ONE
+  tensor all-gather of the 4x4 results at the end.  This is the node-level (weak-scaling)
+  mode and what ``bench.py --gpus N`` measures.
+* **sharded source** (:func:`sharded_align`) — one pair spread over the ranks of a group:
+  the gold map and its grid are replicated, the comparison cloud is block-partitioned, and
+  per iteration the ONLY exchange is one all-reduce(sum) of the 17-double centroid /
+  cross-covariance accumulator (136 B, latency-bound).  The collective lives INSIDE
+  ``libmapalign.so`` (``ma_icp_sharded``: search -> 19-way sum -> ``ncclAllReduce`` ->
+  solve, enqueued from C on the context's stream, no Python between iterations); Python
+  only bootstraps the ``ncclUniqueId`` (:func:`bootstrap_comm`) over whatever
+  ``torch.distributed`` group the job already has.
 
-The engines are duck-typed so the CPU tests can drive the same scheduling code with a
-stand-in engine over ``gloo``; the product engine is :class:`HipShardEngine`.
+``sharded_icp`` is the same loop spelled out in Python over a duck-typed engine.  It exists
+for the CPU tests (world-size-2 ``gloo`` with an oracle-backed stand-in engine) and for
+callers that want their own collective between :meth:`MapAligner.step_accumulate` and
+:meth:`MapAligner.step_solve`; the product path on GPUs is ``ma_icp_sharded``.
 """
 from __future__ import annotations
 
@@ -34,8 +39,31 @@ def pairs_for_rank(n_pairs, world, rank):
     return list(range(rank, int(n_pairs), int(world)))
 
 
+def _world(group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def bootstrap_comm(aligner, group=None):
+    """Give ``aligner`` (a :class:`mapalign.MapAligner`) an RCCL communicator spanning the
+    ranks of ``group``: rank 0 draws the ``ncclUniqueId`` in the library, the 128 bytes travel
+    through ``torch.distributed`` (any backend), every rank joins with ``ma_comm_init``.
+    Without an initialised process group this makes a 1-rank communicator."""
+    import torch.distributed as dist
+
+    world, rank = _world(group)
+    payload = [aligner.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(payload, src=src, group=group)
+    aligner.comm_init(payload[0], world, rank)
+    return world, rank
+
+
 class HipShardEngine:
-    """Sharded-source engine over one :class:`mapalign.MapAligner` (one GPU)."""
+    """Python-stepping view of one :class:`mapalign.MapAligner` (see ``sharded_icp``)."""
 
     def __init__(self, aligner, max_corr_dist=0.10, tol=0.0):
         self.aligner = aligner
@@ -47,7 +75,7 @@ class HipShardEngine:
         return torch.zeros(ACC_LEN, dtype=torch.float64, device=f"cuda:{self.aligner.device}")
 
     def bind_current_stream(self):
-        """Launch on torch's current stream so kernels and the RCCL all-reduce are ordered without host syncs."""
+        """Launch on torch's current stream so kernels and a torch collective are ordered without host syncs."""
         import torch
         self.aligner.set_stream(torch.cuda.current_stream(self.aligner.device).cuda_stream)
 
@@ -65,8 +93,8 @@ class HipShardEngine:
 
 
 def sharded_icp(engine, acc, max_iter=50, init=None, group=None, all_reduce=None):
-    """Run the sharded-source loop on this rank.  ``acc`` is the 17-double exchange buffer
-    (a tensor on the engine's device); ``all_reduce(acc)`` defaults to
+    """The sharded-source loop in Python over a duck-typed engine (tests / custom collectives).
+    ``acc`` is the 17-double exchange buffer; ``all_reduce(acc)`` defaults to
     ``torch.distributed.all_reduce(acc, SUM, group)``.  Returns ``(T 4x4, info dict)``;
     identical on every rank of the group."""
     if all_reduce is None:
@@ -85,15 +113,14 @@ def sharded_icp(engine, acc, max_iter=50, init=None, group=None, all_reduce=None
 
 
 def sharded_align(gold_cloud, comparison_cloud, *, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None,
-                  cell=0.0, device=None, group=None):
-    """One pair over all ranks of ``group`` (every rank passes the same full clouds)."""
+                  cell=0.0, device=None, group=None, return_info=False):
+    """One pair over all ranks of ``group`` (every rank passes the same full clouds).  The
+    loop, including the RCCL all-reduce, runs inside the library (``ma_icp_sharded``)."""
     import torch
-    import torch.distributed as dist
 
     from .engine import MapAligner
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank = _world(group)
     device = torch.cuda.current_device() if device is None else device
     comp = np.asarray(comparison_cloud)
     lo, hi = shard_bounds(len(comp), world, rank)
@@ -102,29 +129,47 @@ def sharded_align(gold_cloud, comparison_cloud, *, max_iter=50, tol=0.0, max_cor
     with MapAligner(device) as eng:
         eng.set_gold(gold_cloud, cell)
         eng.set_source(comp[lo:hi])
-        he = HipShardEngine(eng, max_corr_dist, tol)
-        he.bind_current_stream()
-        acc = he.new_acc()
-        T, info = sharded_icp(he, acc, max_iter=max_iter, init=init, group=group)
-        eng.use_own_stream()
-    return T[:3, :3].copy(), T[:3, 3].copy(), info
+        bootstrap_comm(eng, group)
+        res = eng.icp_sharded(max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist, init=init)
+        eng.comm_destroy()
+    if return_info:
+        return res.R, res.t, {"iterations": res.iterations, "rmse": res.rmse, "inliers": res.inliers,
+                              "converged": res.converged, "gpu_ms": res.gpu_ms, "ranks": world}
+    return res.R, res.t
+
+
+def _gather_rows(rows, n_cols, world, group, device):
+    """All-gather of a [k, n_cols] float64 block per rank (k <= k_max, padded) as ONE tensor collective."""
+    import torch
+    import torch.distributed as dist
+
+    k_max = max(1, -(-int(rows[1]) // world))
+    block = torch.full((k_max, n_cols), float("nan"), dtype=torch.float64, device=device)
+    if len(rows[0]):
+        block[:len(rows[0])] = torch.as_tensor(np.asarray(rows[0], dtype=np.float64), device=device)
+    out = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(out, block, group=group)
+    return torch.cat(out).cpu().numpy()
 
 
 def align_pairs(pairs, *, max_iter=50, tol=0.0, max_corr_dist=0.10, cell=0.0, device=None, group=None,
                 align_fn=None):
     """Pair-per-GPU: ``pairs`` is the same list of (gold, comparison) on every rank (or a
     callable ``i -> (gold, comparison)`` with ``len`` given by ``pairs.n``).  Rank r aligns
-    pairs r, r+W, ...; the 4x4 results are gathered so every rank returns the full list."""
+    pairs r, r+W, ...; the 4x4 results travel in one tensor all-gather (17 doubles per pair:
+    the pair index and the matrix) so every rank returns the full list."""
     import torch.distributed as dist
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world, rank = _world(group)
     n_pairs = pairs.n if hasattr(pairs, "n") else len(pairs)
+    gather_device = "cpu"
     if align_fn is None:
         import torch
 
         from .api import align
         dev = torch.cuda.current_device() if device is None else device
+        if world > 1 and dist.get_backend(group) == "nccl":
+            gather_device = f"cuda:{dev}"
 
         def align_fn(g, c):
             R, t = align(g, c, max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist, cell=cell, device=dev)
@@ -132,15 +177,16 @@ def align_pairs(pairs, *, max_iter=50, tol=0.0, max_corr_dist=0.10, cell=0.0, de
             T[:3, :3], T[:3, 3] = R, t
             return T
 
-    mine = {}
+    mine = []
     for i in pairs_for_rank(n_pairs, world, rank):
         g, c = pairs(i) if callable(pairs) else pairs[i]
-        mine[i] = align_fn(g, c)
+        mine.append(np.concatenate([[float(i)], np.asarray(align_fn(g, c), dtype=np.float64).reshape(16)]))
     if world == 1:
-        return [mine[i] for i in range(n_pairs)]
-    gathered = [None] * world
-    dist.all_gather_object(gathered, mine, group=group)
-    merged = {}
-    for d in gathered:
-        merged.update(d)
-    return [merged[i] for i in range(n_pairs)]
+        table = np.asarray(mine, dtype=np.float64).reshape(-1, 17)
+    else:
+        table = _gather_rows((mine, n_pairs), 17, world, group, gather_device)
+    out = [None] * n_pairs
+    for row in table:
+        if np.isfinite(row[0]):
+            out[int(row[0])] = row[1:].reshape(4, 4).copy()
+    return out

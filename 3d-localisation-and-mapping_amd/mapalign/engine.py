@@ -11,7 +11,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
-from ._lib import MA_ACC_LEN, MA_TRACE_STRIDE, MapAlignError, ma_grid_info, ma_params, ma_stats
+from ._lib import (MA_ACC_LEN, MA_COMM_ID_BYTES, MA_TRACE_STRIDE, MapAlignError, ma_grid_info, ma_mem_info,
+                   ma_params, ma_stats)
 
 
 def _as_T(init):
@@ -113,6 +114,7 @@ class MapAligner:
         self.n_source = 0
         self._shift = np.zeros(3)
         self._map_shift = None
+        self._comm_ranks = 0
 
     # -- lifetime -------------------------------------------------------------------
     def close(self):
@@ -278,6 +280,39 @@ class MapAligner:
                                           b.shape[0], _f64p(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out + self._shift, valid.astype(bool)
 
+    def lift_boxes_batch(self, boxes_xyxy, box_frame, depth_frames, K, T_cam_to_world, depth_scale=1000.0):
+        """Row a10 for a whole detector batch in ONE device call: ``depth_frames`` [F,H,W]
+        (float32 or uint16), ``T_cam_to_world`` [F,4,4], ``boxes_xyxy`` [B,4] in depth-resolution
+        pixels, ``box_frame`` [B] = frame index of each box.  Returns (corners f64 [B,4,3], valid bool [B,4])."""
+        d = np.asarray(depth_frames)
+        if d.ndim != 3:
+            raise ValueError("depth_frames must have shape [F,H,W]")
+        dtype = 1 if d.dtype == np.uint16 else 0
+        d = np.ascontiguousarray(d if dtype == 1 else d.astype(np.float32, copy=False))
+        F, h, w = d.shape
+        b = np.ascontiguousarray(boxes_xyxy, dtype=np.float32).reshape(-1, 4)
+        bf = np.ascontiguousarray(box_frame, dtype=np.uint32).reshape(-1)
+        if bf.shape[0] != b.shape[0]:
+            raise ValueError("box_frame must have one entry per box")
+        T = np.array(T_cam_to_world, dtype=np.float64).reshape(F, 4, 4)
+        T[:, :3, 3] -= self._shift
+        T = np.ascontiguousarray(T)
+        Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
+        out = np.empty((b.shape[0], 4, 3), dtype=np.float64)
+        valid = np.zeros((b.shape[0], 4), dtype=np.uint8)
+        self._chk(self._lib.ma_lift_boxes_batch(
+            self._ctx, d.ctypes.data_as(C.c_void_p), dtype, w, h, F, Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T),
+            float(depth_scale), b.ctypes.data_as(C.POINTER(C.c_float)), bf.ctypes.data_as(C.POINTER(C.c_uint32)),
+            b.shape[0], _f64p(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out + self._shift, valid.astype(bool)
+
+    def mem_info(self):
+        """Device allocations of this context since it was created (hipMalloc / hipFree counts, bytes)."""
+        mi = ma_mem_info()
+        self._chk(self._lib.ma_mem_info_get(self._ctx, C.byref(mi)))
+        return {"device_allocs": int(mi.device_allocs), "device_frees": int(mi.device_frees),
+                "bytes_live": int(mi.bytes_live), "bytes_peak": int(mi.bytes_peak)}
+
     def get_source(self):
         n = C.c_uint64(0)
         self._chk(self._lib.ma_get_source(self._ctx, None, C.byref(n)))
@@ -350,3 +385,48 @@ class MapAligner:
     def step_solve(self, acc_dev_ptr, tol=0.0, max_corr_dist=0.10):
         p = self._params(1, tol, max_corr_dist)
         self._chk(self._lib.ma_step_solve(self._ctx, C.byref(p), C.c_void_p(int(acc_dev_ptr))))
+
+    # -- RCCL inside the library (sharded-source mode) ----------------------
+    def comm_unique_id(self):
+        """Rank 0: the MA_COMM_ID_BYTES bootstrap id to hand to the other ranks (any channel)."""
+        buf = (C.c_ubyte * MA_COMM_ID_BYTES)()
+        st = self._lib.ma_comm_unique_id(buf)
+        if st < 0:
+            raise MapAlignError(st, (self._lib.ma_last_error(None) or b"").decode("utf-8", "replace"))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        """Collective: join the RCCL communicator described by ``unique_id`` as ``rank`` of ``n_ranks``."""
+        if len(unique_id) != MA_COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {MA_COMM_ID_BYTES} bytes")
+        buf = (C.c_ubyte * MA_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._chk(self._lib.ma_comm_init(self._ctx, buf, int(n_ranks), int(rank)))
+        self._comm_ranks = int(n_ranks)
+
+    def comm_destroy(self):
+        self._chk(self._lib.ma_comm_destroy(self._ctx))
+
+    def icp_sharded(self, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None, count_work=False, with_trace=False):
+        """The whole sharded-source loop in the library: per iteration search -> 19-way sum ->
+        ncclAllReduce(17 doubles) -> solve, all enqueued from C on the context stream."""
+        p = self._params(max_iter, tol, max_corr_dist, count_work)
+        Tin = _conj_shift(_as_T(init), self._shift, inverse=True)
+        Tout = np.empty((4, 4), dtype=np.float64)
+        st = ma_stats()
+        self._chk(self._lib.ma_icp_sharded(self._ctx, C.byref(p), _f64p(Tin), _f64p(Tout), C.byref(st)))
+        Tout = _conj_shift(Tout, self._shift)
+        tr = self.trace(st.iterations) if with_trace else None
+        return AlignResult(Tout, int(st.iterations), float(st.rmse), float(st.inliers), bool(st.converged),
+                           float(st.gpu_ms), tr)
+
+    def comm_allgather(self, vec):
+        """Gather a small float64 host vector from every rank -> [n_ranks, len(vec)] (RCCL all-gather)."""
+        v = np.ascontiguousarray(vec, dtype=np.float64).reshape(-1)
+        out = np.empty((self._comm_ranks, v.shape[0]), dtype=np.float64)
+        self._chk(self._lib.ma_comm_allgather_f64(self._ctx, _f64p(v), v.shape[0], _f64p(out)))
+        return out
+
+    def comm_allreduce(self, vec, op="sum"):
+        v = np.array(vec, dtype=np.float64).reshape(-1)
+        self._chk(self._lib.ma_comm_allreduce_f64(self._ctx, _f64p(v), v.shape[0], {"sum": 0, "max": 1}[op]))
+        return v

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MA_VERSION 100 /* 0.1.0 */
+#define MA_VERSION 200 /* 0.2.0 */
 #define MA_ACC_LEN 17  /* W, s_p[3], s_q[3], S[9] row-major (S_ab = sum w p'_a q_b), E */
 #define MA_TRACE_STRIDE 20 /* per-iteration trace row: acc[17], rmse, table_words_read, candidates */
 #define MA_NO_MATCH 0xFFFFFFFFu
@@ -46,8 +46,10 @@ typedef enum ma_status {
   MA_ERR_HIP = -3,       /* a HIP runtime call failed; see ma_last_error */
   MA_ERR_EMPTY = -4,     /* empty cloud / no valid depth pixel */
   MA_ERR_STATE = -5,     /* call order: gold map or source cloud not set */
-  MA_ERR_DEGENERATE = -6,/* < 3 correspondences or rank-deficient covariance */
-  MA_ERR_TOO_LARGE = -7  /* more than 2^32-2 points */
+  MA_ERR_DEGENERATE = -6,/* no correspondence inside the gate (W = 0) or rank-deficient covariance (< 3 non-collinear pairs) */
+  MA_ERR_TOO_LARGE = -7, /* gold map >= 2^28 points, source cloud / depth image >= 2^31 points */
+  MA_ERR_COMM = -8,      /* RCCL: librccl could not be loaded, or a collective failed; see ma_last_error */
+  MA_ERR_NO_MEMORY = -9  /* a host allocation failed inside the call */
 } ma_status;
 
 /* Loop parameters (rows a4-a7).  The reference exposes no alignment hyper-parameters
@@ -78,6 +80,18 @@ typedef struct ma_grid_info {
   double build_ms;      /* device time of the last grid build */
 } ma_grid_info;
 
+/* Device allocations made by one context since ma_create (hipMalloc / hipFree calls and bytes).
+ * Buffers only grow, so a context that has seen clouds of a given size aligns further clouds
+ * of that size without allocating: mapalign.api keeps one context per device for that reason. */
+typedef struct ma_mem_info {
+  uint64_t device_allocs;
+  uint64_t device_frees;
+  uint64_t bytes_live;
+  uint64_t bytes_peak;
+} ma_mem_info;
+
+#define MA_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+
 int ma_version(void);
 const char* ma_status_string(int status);
 /* Message of the last failure on ctx (or of the last failed ma_create when ctx == NULL). */
@@ -101,8 +115,10 @@ int ma_grid_info_get(const ma_ctx* ctx, ma_grid_info* out);
 
 /* Comparison ("maintenance") cloud: N x 3 fp32 points, optional per-point weights
  * (NULL = 1; each finite and >= 0, else MA_ERR_INVALID).  Needs the gold map first (points
- * are stored relative to its origin). */
+ * are stored relative to its origin).  Weights scale a correspondence's contribution to the
+ * sums (w = 1 is one plain correspondence); they need not sum to anything in particular. */
 int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t n);
+int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out);
 
 /* Row a8: fused depth -> 3-D unprojection written straight into the source-cloud device
  * buffer.  Pinhole model of pose_processor.py:133-137,184-196,242-260:
@@ -141,6 +157,17 @@ int ma_lift_boxes(ma_ctx* ctx, const void* depth, int dtype, int width, int heig
                   const double T_cam_to_world[16], float depth_scale, const float* boxes_xyxy,
                   uint64_t n_boxes, double* corners_out, uint8_t* valid_out);
 
+/* Row a10 for a whole detector batch (BASELINE configs[3]: batch-32 inference, detector.py:82-90,
+ * then pose_processor.py:172-208 per frame): n_frames depth images of the same size stored back
+ * to back, one pose per frame (n_frames x 16 doubles), one intrinsics set, and n_boxes boxes
+ * [x1,y1,x2,y2] (depth-resolution pixels) with box_frame[b] = index of the frame box b was
+ * detected in.  One upload, ONE kernel launch and one synchronisation for the whole batch;
+ * same corner order, truncation, clamping and validity rule as ma_lift_boxes. */
+int ma_lift_boxes_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int width, int height,
+                        uint32_t n_frames, const float K[4], const double* T_cam_to_world,
+                        float depth_scale, const float* boxes_xyxy, const uint32_t* box_frame,
+                        uint64_t n_boxes, double* corners_out, uint8_t* valid_out);
+
 /* Copy the current source cloud back (world frame, storage order); *n in = capacity in
  * points, out = points written.  For parity tests of the unprojection kernel. */
 int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n);
@@ -175,11 +202,34 @@ int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_o
  * acc_dev is a DEVICE pointer to MA_ACC_LEN doubles owned by the caller (e.g. a torch
  * tensor's data_ptr); accumulators are in the ctx's centred frame, which is identical
  * on all ranks because it derives from the gold map alone.  Nothing here synchronises
- * with the host. */
+ * with the host.
+ * Call order: ma_set_gold, ma_set_source (this rank's shard), ma_state_set, then the
+ * accumulate / solve pairs.  Installing another gold map or source cloud (ma_set_gold,
+ * ma_set_source, ma_set_source_from_depth, ma_map_finish(as_gold)) invalidates the stepping
+ * state — its buffers are sized for the clouds it was set for — and ma_step_accumulate /
+ * ma_step_solve then return MA_ERR_STATE until ma_state_set is called again. */
 int ma_state_set(ma_ctx* ctx, const double T[16]);
 int ma_state_get(ma_ctx* ctx, double T_out[16], ma_stats* stats);
 int ma_step_accumulate(ma_ctx* ctx, const ma_params* params, void* acc_dev);
 int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev);
+
+/* The same sharded-source loop with the collective INSIDE the library (SURVEY.md §8e,
+ * north_star "RCCL-over-xGMI all-reduce only of the per-pair accumulators"): librccl is
+ * loaded with dlopen on first use and, per iteration, the library enqueues on the ctx stream
+ *   search+accumulate (local shard) -> 19-way sum -> ncclAllReduce(sum, 17 doubles) -> solve
+ * with the loop in C and no host synchronisation.  Bootstrap: rank 0 obtains an id with
+ * ma_comm_unique_id and hands the MA_COMM_ID_BYTES bytes to the other ranks by any channel
+ * (torch.distributed broadcast, a file, MPI ...); every rank then calls ma_comm_init
+ * (collective).  A 1-rank communicator is valid and makes ma_icp_sharded equal ma_icp bit
+ * for bit.  ma_comm_allgather_f64 / ma_comm_allreduce_f64 (op 0 = sum, 1 = max) move small
+ * HOST vectors through the same communicator (pair-per-GPU result gather, fleet statistics). */
+int ma_comm_unique_id(void* id_out /* MA_COMM_ID_BYTES */);
+int ma_comm_init(ma_ctx* ctx, const void* id, int n_ranks, int rank);
+int ma_comm_destroy(ma_ctx* ctx);
+int ma_icp_sharded(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16],
+                   ma_stats* stats);
+int ma_comm_allgather_f64(ma_ctx* ctx, const double* in, uint64_t count, double* out /* count * n_ranks */);
+int ma_comm_allreduce_f64(ma_ctx* ctx, double* inout, uint64_t count, int op);
 
 #ifdef __cplusplus
 }

@@ -37,20 +37,25 @@ from __future__ import annotations
 import numpy as np
 
 ACC_LEN = 17
-MIN_CORRESPONDENCES = 3.0
 
 
 def kabsch_from_acc(acc):
-    """Rows a6: 17-double accumulator -> (dR, dt, ok).  ok=False if W < 3 or rank(H) < 2."""
+    """Rows a6: 17-double accumulator -> (dR, dt, ok).
+
+    ok=False when a sum is not finite, when there is no weight (W <= 0) or when rank(H) < 2 —
+    what fewer than three non-collinear correspondences give.  W is a sum of weights, not a
+    count, so there is no "W >= 3" test; H below 1e-12 of the size of the terms it is the
+    difference of (W |mu_p| |mu_q|) is rounding noise and counts as rank 0."""
     acc = np.asarray(acc, dtype=np.float64)
     W = acc[0]
-    if not np.isfinite(acc).all() or W < MIN_CORRESPONDENCES:
+    if not np.isfinite(acc).all() or not W > 0.0:
         return np.eye(3), np.zeros(3), False
     mu_p = acc[1:4] / W
     mu_q = acc[4:7] / W
     H = acc[7:16].reshape(3, 3) - W * np.outer(mu_p, mu_q)
     U, S, Vt = np.linalg.svd(H)
-    if S[1] <= 1e-12 * max(S[0], 1e-300):
+    noise = W * np.linalg.norm(mu_p) * np.linalg.norm(mu_q)
+    if S[1] <= 1e-12 * max(S[0], 1e-300) or S[0] <= 1e-12 * noise:
         return np.eye(3), mu_q - mu_p, False
     V = Vt.T
     D = np.diag([1.0, 1.0, np.sign(np.linalg.det(V @ U.T)) or 1.0])

@@ -472,7 +472,7 @@ def test_split_stepping_two_shards_equals_one_context(lib_built):
 def test_sharded_icp_driver_single_rank(lib_built):
     from mapalign import dist as mdist
     gold, comp, R0, t0 = syn.make_pair(16, 8000, resample=False)
-    R, t, info = mdist.sharded_align(gold, comp, max_iter=50, device=0)
+    R, t, info = mdist.sharded_align(gold, comp, max_iter=50, device=0, return_info=True)
     eR, et = orc.rt_error(R, t, R0, t0)
     assert eR <= R_TOL_FRO and et <= T_TOL_M and info["iterations"] == 50
 

@@ -1,0 +1,331 @@
+"""GPU parity tests added in round 2 (run with -m gpu on an MI355X), all through the C ABI:
+
+* the headline configuration (BASELINE configs[1]: 1M-point pair, 50 iterations) against the
+  CPU oracle at EQUAL iteration count, per-iteration inlier counts included, seeds 0-2;
+* the schedule ranking with more than 4.2M source points (group count not a multiple of 4);
+* invalidation of the stepping state, warm contexts allocate nothing, RCCL inside the library
+  with a 1-rank communicator, the batched box lift and the batch-32 detector leg (configs[3]),
+  trajectory-aided coarse stage, weights that do not sum to a count.
+"""
+import time
+
+import numpy as np
+import pytest
+
+import mapalign
+from mapalign import _lib, coarse, synthetic as syn, transforms
+from oracle import icp_oracle as orc
+
+from conftest import R_TOL_FRO, T_TOL_M
+
+pytestmark = pytest.mark.gpu
+
+NO_MATCH = 0xFFFFFFFF
+
+
+# ----------------------------------------------------------------------------- headline parity
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_config2_1m_50_iterations_vs_oracle(engine, seed):
+    """north_star: "(R,t) must match the reference CPU path to <= 1e-4 Frobenius on R and
+    <= 1 mm on t for identical inputs" — the 1M-point pair, all 50 iterations, tol = 0, gate
+    0.10 m.  The oracle runs its 50 KD-tree iterations on the host cores
+    (~1.9 s each on the 256-core GPU box); if this host is much slower, seeds 1 and 2 stop
+    after 20 iterations (still compared at equal iteration count) so the suite stays in budget."""
+    gold, comp, R0, t0 = syn.make_pair(seed, 1_000_000)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    index = orc.GoldIndex(gold, n_jobs=-1)
+    R, t = np.eye(3), np.zeros(3)
+    inliers, rmse = [], []
+    iters = 50
+    t_start = time.perf_counter()
+    k = 0
+    while k < iters:
+        acc, _, _, R, t, ok = orc.icp_step(index, comp, R, t, 0.10)
+        assert ok
+        inliers.append(acc[0])
+        rmse.append(np.sqrt(acc[16] / acc[0]))
+        k += 1
+        if seed > 0 and k == 5 and (time.perf_counter() - t_start) / 5 > 3.5:
+            iters = 20
+    res = engine.icp(iters, 0.0, 0.10, with_trace=True)
+    assert res.iterations == iters
+    eR, et = orc.rt_error(res.R, res.t, R, t)
+    assert eR <= R_TOL_FRO and et <= T_TOL_M, (eR, et)
+    # measured: 1e-7 / 1e-6 m; keep a tighter regression bar than the contract
+    assert eR <= 1e-5 and et <= 1e-4, (eR, et)
+    # the same correspondences every iteration: inlier counts agree to a handful of points
+    # whose distance sits within the fp32 storage error (~1 um) of the gate (2e-5 of the cloud)
+    gpu_inl = res.trace[:, 0]
+    assert np.abs(gpu_inl - np.array(inliers)).max() <= 20, np.abs(gpu_inl - np.array(inliers)).max()
+    assert np.allclose(res.trace[:, 17], rmse, rtol=1e-5, atol=1e-8)
+    if iters == 50:   # and the result is the ground truth of the synthetic pair
+        eR0, et0 = orc.rt_error(res.R, res.t, R0, t0)
+        assert eR0 <= R_TOL_FRO and et0 <= T_TOL_M
+
+
+# ----------------------------------------------------------------------------- schedule, gshift >= 2
+def test_5m_source_points_group_count_not_multiple_of_4(engine):
+    """above ~4.19M source points the ranking workgroup orders 2^gshift-segment
+    groups whose number is any integer (306 at 5M); the trailing count % 4 keys were never
+    compared, two groups dropped out of the schedule and their chunks kept stale partials.
+    The scheduled loop (ma_icp) must equal the unscheduled single steps (ma_icp_step) bit for
+    bit, and iteration 0's sums must equal direct sums over the matched points."""
+    n = 5_000_000
+    gold, comp, R0, t0 = syn.make_pair(9, 600_000, n)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    iters = 6
+    res = engine.icp(iters, 0.0, 0.10, with_trace=True)
+    T = np.eye(4)
+    for k in range(iters):
+        acc, T = engine.icp_step(T, 0.10)
+        assert np.array_equal(acc, res.trace[k, :17]), f"iteration {k}: scheduled and unscheduled sums differ"
+    assert np.array_equal(T, res.T)
+    again = engine.icp(iters, 0.0, 0.10, with_trace=True)
+    assert np.array_equal(again.trace, res.trace)
+    idx, d2 = engine.nn(None, 0.10)
+    m = idx != NO_MATCH
+    assert res.trace[0, 0] == m.sum()
+    assert np.allclose(res.trace[0, 1:4], comp[m].astype(np.float64).sum(0), rtol=1e-9)
+    assert np.allclose(res.trace[0, 4:7], gold[idx[m]].astype(np.float64).sum(0), rtol=1e-9)
+    # 60 iterations from the truth stay at the truth (every chunk contributes every iteration)
+    T0 = np.eye(4)
+    T0[:3, :3], T0[:3, 3] = R0, t0
+    far = engine.icp(20, 0.0, 0.10, init=T0)
+    eR, et = orc.rt_error(far.R, far.t, R0, t0)
+    assert eR <= R_TOL_FRO and et <= T_TOL_M and far.inliers > 0.99 * n
+
+
+# ----------------------------------------------------------------------------- stepping state
+def test_stepping_state_is_invalidated_by_new_clouds(lib_built):
+    import torch
+    gold, comp, _, _ = syn.make_pair(4, 20_000, 30_000)
+    acc = torch.zeros(17, dtype=torch.float64, device="cuda:0")
+    with mapalign.MapAligner(0) as eng:
+        eng.set_gold(gold)
+        eng.set_source(comp[:5000])
+        eng.state_set(None)
+        eng.step_accumulate(acc.data_ptr(), 0.10)
+        eng.step_solve(acc.data_ptr(), 0.0, 0.10)
+        eng.sync()
+        w_small = float(acc[0])
+        # a LARGER cloud after ma_state_set: partials / prev were sized for 5000 points
+        eng.set_source(comp)
+        with pytest.raises(mapalign.MapAlignError) as e:
+            eng.step_accumulate(acc.data_ptr(), 0.10)
+        assert e.value.status == _lib.MA_ERR_STATE
+        with pytest.raises(mapalign.MapAlignError):
+            eng.step_solve(acc.data_ptr(), 0.0, 0.10)
+        eng.state_set(None)
+        eng.step_accumulate(acc.data_ptr(), 0.10)
+        eng.sync()
+        assert float(acc[0]) > w_small
+        # a new gold map invalidates as well (prev[] holds positions in the old map)
+        eng.set_gold(gold[:7000])
+        with pytest.raises(mapalign.MapAlignError) as e:
+            eng.step_accumulate(acc.data_ptr(), 0.10)
+        assert e.value.status == _lib.MA_ERR_STATE
+        # the one-shot entry points are unaffected
+        eng.set_source(comp)
+        assert eng.icp(5, 0.0, 0.10).iterations == 5
+
+
+def test_warm_context_allocates_nothing():
+    """align() keeps one context per device: the second call of the same size must perform zero
+    device allocations, and GoldMap keeps the indexed gold map resident."""
+    gold, comp, R0, t0 = syn.make_pair(6, 200_000)
+    mapalign.release_cached_engines()
+    R1, t1, i1 = mapalign.align(gold, comp, max_iter=30, return_info=True)
+    R2, t2, i2 = mapalign.align(gold, comp, max_iter=30, return_info=True)
+    assert i1["mem"]["device_allocs"] > 0
+    assert i2["mem"]["device_allocs"] == i1["mem"]["device_allocs"] and i2["mem"]["device_frees"] == i1["mem"]["device_frees"]
+    assert np.array_equal(R1, R2) and np.array_equal(t1, t2)
+    # a smaller scan against the same gold map reuses the buffers as well
+    _, _, i3 = mapalign.align(gold, comp[:150_000], max_iter=5, return_info=True)
+    assert i3["mem"]["device_allocs"] == i1["mem"]["device_allocs"]
+    with mapalign.GoldMap(gold) as gm:
+        Ra, ta = mapalign.align(gm, comp, max_iter=30)
+        before = gm.engine.mem_info()["device_allocs"]
+        Rb, tb = mapalign.align(gm, comp[::-1].copy(), max_iter=30)
+        assert gm.engine.mem_info()["device_allocs"] == before
+        assert np.array_equal(Ra, R1) and np.allclose(Rb, R1, atol=1e-9) and np.allclose(tb, t1, atol=1e-9)
+    mapalign.release_cached_engines()
+
+
+def test_tol_early_exit_batches_match_the_oracle(engine):
+    """tol > 0 with a large max_iter: the host stops enqueueing once the device reports `done`
+    (batches of 8 iterations); the result is the oracle's early stop, not max_iter iterations."""
+    gold, comp, _, _ = syn.make_pair(8, 30_000)
+    ref = orc.icp_oracle(gold, comp, max_iter=400, tol=1e-7, max_corr_dist=0.10, n_jobs=1)
+    assert ref["converged"] and ref["iterations"] < 200
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    res = engine.icp(400, 1e-7, 0.10, with_trace=True)
+    assert res.converged and abs(res.iterations - ref["iterations"]) <= 2
+    eR, et = orc.rt_error(res.R, res.t, ref["R"], ref["t"])
+    assert eR <= 1e-6 and et <= 1e-6
+    # and the context is immediately reusable
+    assert engine.icp(3, 0.0, 0.10).iterations == 3
+
+
+def test_weights_that_do_not_sum_to_a_count(engine):
+    """W is a sum of weights, not a correspondence count.  Normalised weights
+    (sum = 1) over 50k matches must align, exactly like unit weights."""
+    gold, comp, R0, t0 = syn.make_pair(12, 50_000, resample=False)
+    engine.set_gold(gold)
+    engine.set_source(comp, np.full(len(comp), 1.0 / len(comp), np.float32))
+    res = engine.icp(40, 0.0, 0.10)
+    eR, et = orc.rt_error(res.R, res.t, R0, t0)
+    assert eR <= R_TOL_FRO and et <= T_TOL_M and abs(res.inliers - 1.0) < 1e-3
+    # two matches only (weights zero elsewhere): rank-deficient -> MA_ERR_DEGENERATE
+    w = np.zeros(len(comp), np.float32)
+    w[:2] = 1.0
+    engine.set_source(comp, w)
+    with pytest.raises(mapalign.MapAlignError) as e:
+        engine.icp(5, 0.0, np.inf)
+    assert e.value.status == _lib.MA_ERR_DEGENERATE
+
+
+# ----------------------------------------------------------------------------- RCCL inside the library
+def test_icp_sharded_one_rank_communicator_equals_icp_bitwise(lib_built):
+    """ma_icp_sharded with a 1-rank RCCL communicator: librccl is loaded (dlopen), every
+    iteration runs search -> 19-way sum -> ncclAllReduce -> solve from C on the ctx stream, and the
+    result equals ma_icp bit for bit (same sums, same order)."""
+    gold, comp, R0, t0 = syn.make_pair(17, 120_000, 100_003)
+    with mapalign.MapAligner(0) as eng:
+        eng.set_gold(gold)
+        eng.set_source(comp)
+        ref = eng.icp(25, 0.0, 0.10, with_trace=True)
+        with pytest.raises(mapalign.MapAlignError) as e:     # no communicator yet
+            eng.icp_sharded(5)
+        assert e.value.status == _lib.MA_ERR_STATE
+        uid = eng.comm_unique_id()
+        assert len(uid) == _lib.MA_COMM_ID_BYTES and any(uid)
+        eng.comm_init(uid, 1, 0)
+        res = eng.icp_sharded(25, 0.0, 0.10, with_trace=True)
+        assert np.array_equal(res.T, ref.T) and np.array_equal(res.trace[:, :18], ref.trace[:, :18])
+        assert res.iterations == 25 and res.inliers == ref.inliers
+        # small host vectors through the same communicator (pair-mode gather, fleet statistics)
+        g = eng.comm_allgather(np.arange(5.0))
+        assert g.shape == (1, 5) and np.array_equal(g[0], np.arange(5.0))
+        assert np.array_equal(eng.comm_allreduce([1.5, -2.0], "sum"), [1.5, -2.0])
+        assert np.array_equal(eng.comm_allreduce([1.5, -2.0], "max"), [1.5, -2.0])
+        eng.comm_destroy()
+    from mapalign import dist as mdist
+    R, t, info = mdist.sharded_align(gold, comp, max_iter=25, device=0, return_info=True)
+    assert np.array_equal(R, ref.R) and np.array_equal(t, ref.t) and info["ranks"] == 1
+
+
+# ----------------------------------------------------------------------------- configs[3]
+def _frames(n_frames, w, h, seed):
+    rng = np.random.default_rng(seed)
+    depth = rng.uniform(500.0, 9000.0, size=(n_frames, h, w)).astype(np.float32)       # millimetres, dataset.py:77
+    depth[rng.random(depth.shape) < 0.05] = 0.0                                         # holes
+    depth[0, 3, 4] = np.nan
+    poses = np.zeros((n_frames, 7))
+    poses[:, :3] = rng.uniform(-5, 5, size=(n_frames, 3))
+    q = rng.normal(size=(n_frames, 4))
+    poses[:, 3:] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    return depth, poses
+
+
+def test_lift_boxes_batch_vs_oracle_and_per_frame_call(engine):
+    n_frames, w, h = 7, 160, 120
+    depth, poses = _frames(n_frames, w, h, 0)
+    K = (140.0, 141.0, 80.5, 59.5)
+    rng = np.random.default_rng(1)
+    nb = 300
+    x1, y1 = rng.uniform(-5, w - 2, nb), rng.uniform(-5, h - 2, nb)
+    boxes = np.stack([x1, y1, x1 + rng.uniform(1, 40, nb), y1 + rng.uniform(1, 40, nb)], axis=1).astype(np.float32)
+    frame = rng.integers(0, n_frames, nb).astype(np.uint32)
+    T = np.stack([syn.pose_to_matrix(p) for p in poses])
+    corners, valid = engine.lift_boxes_batch(boxes, frame, depth, K, T)
+    for f in range(n_frames):
+        sel = frame == f
+        oc, ov = orc.lift_boxes_oracle(boxes[sel], depth[f], K, T[f])
+        assert np.array_equal(valid[sel], ov)
+        assert np.allclose(corners[sel][ov], oc[ov], rtol=0, atol=1e-9)
+        assert np.isnan(corners[sel][~ov]).all()
+        pc, pv = engine.lift_boxes(boxes[sel], K, T[f], depth[f])
+        assert np.array_equal(pv, ov) and np.array_equal(pc[pv], corners[sel][ov])
+    # uint16 frames, empty batch, bad frame index
+    d16 = np.clip(depth, 0, 65535).astype(np.uint16)
+    c16, v16 = engine.lift_boxes_batch(boxes, frame, d16, K, T)
+    oc, ov = orc.lift_boxes_oracle(boxes[frame == 2], d16[2], K, T[2])
+    assert np.array_equal(v16[frame == 2], ov) and np.allclose(c16[frame == 2][ov], oc[ov], atol=1e-9)
+    ce, ve = engine.lift_boxes_batch(np.zeros((0, 4), np.float32), np.zeros(0, np.uint32), depth, K, T)
+    assert ce.shape == (0, 4, 3) and ve.shape == (0, 4)
+    with pytest.raises(mapalign.MapAlignError):
+        engine.lift_boxes_batch(boxes[:2], np.array([0, n_frames], np.uint32), depth, K, T)
+
+
+def test_config4_batch32_detector_and_one_call_lift(engine):
+    """BASELINE configs[3]: batch-32 detector inference on PyTorch-ROCm (random-init
+    YOLOv10-shaped stand-in: SURVEY.md 8d allows it, weights do not exist here) at 3x640x640,
+    rows in the detector.py:155 / :126-127 schema, and the boxes of all 32 frames lifted by ONE
+    ma_lift_boxes_batch call, checked against the oracle frame by frame."""
+    import torch
+    from mapalign import detect
+
+    torch.manual_seed(0)
+    n_frames = 32
+    model = detect.build_yolov10_like()
+    det = detect.Detector(model, None, batch_size=32, conf_thresh=0.0, device="cuda:0", half=True)
+    imgs = torch.randint(0, 256, (n_frames, 640, 640, 3), dtype=torch.uint8)
+    raw, _ = det.infer(imgs)
+    assert raw.shape == (n_frames, detect.MAX_DET, 6) and raw.is_cuda and torch.isfinite(raw).all()
+    det.conf_thresh = float(torch.quantile(raw[:, :, 4].flatten().float(), 0.9))
+    preds = det(imgs)
+    n_rows = sum(len(v) for v in preds.values())
+    assert 0 < n_rows < n_frames * detect.MAX_DET
+    row = next(r for v in preds.values() for r in v)
+    assert len(row) == 7 and isinstance(row[6], int) and row[4] == 0           # [x1,y1,x2,y2,damage,conf,label]
+    depth, poses = _frames(n_frames, 256, 192, 5)                               # the reference's depth size, dataset.py:19-20
+    intr = {"fx": 1500.0, "fy": 1500.0, "cx": 320.0, "cy": 320.0, "image_width": 640, "image_height": 640}
+    before = engine.mem_info()["device_allocs"]
+    out = detect.lift_batch(engine, preds, depth, intr, poses)
+    assert sum(len(v) for v in out.values()) == n_rows
+    from mapalign import lifting
+    K = lifting.rescaled_intrinsics(intr, 256)
+    for f in (0, 7, 31):
+        if not preds[f]:
+            continue
+        scaled = np.array([lifting.scale_bounding_box(r[:4], (640, 640), (256, 192)) for r in preds[f]], np.float32)
+        oc, ov = orc.lift_boxes_oracle(scaled, depth[f], K, syn.pose_to_matrix(poses[f]))
+        got = np.array([[c for c in r[:4]] for r in out[f]])
+        assert np.allclose(got[ov], oc[ov], atol=1e-9) and np.isnan(got[~ov]).all()
+        assert [r[4:] for r in out[f]] == [r[-3:] for r in preds[f]]
+    # a second batch of the same shape reuses the device buffers
+    mid = engine.mem_info()["device_allocs"]
+    detect.lift_batch(engine, preds, depth, intr, poses)
+    assert engine.mem_info()["device_allocs"] == mid and mid >= before
+
+
+# ----------------------------------------------------------------------------- N1 with trajectories
+def test_coarse_stage_uses_trajectories_on_a_half_turn_symmetric_shell(lib_built):
+    """A plain box shell is symmetric under a half turn about its vertical axis: the PCA
+    candidates that differ by it score the same on the clouds.  The camera trajectories
+    (task_def.py:176-177) — walked 0.45 m off the centre line and 0.4 m above mid-height — decide."""
+    rng = np.random.default_rng(3)
+    rects = syn.carriage_rectangles(rng, n_panels=0)
+    gold = syn.sample_rectangles(rects, 60_000, rng).astype(np.float32)
+    s = np.linspace(1.0, 19.0, 60)
+    base_traj = np.stack([s, np.full_like(s, 1.95), np.full_like(s, 1.65)], axis=1)
+    T_true = transforms.rt_to_matrix(syn.rotation_about_axis([0.05, -0.03, 1.0], np.deg2rad(131.0)), [6.0, -3.0, 0.8])
+    inv = np.linalg.inv(T_true)
+    comp = transforms.apply(inv, syn.sample_rectangles(rects, 50_000, rng)).astype(np.float32)
+    comp_traj = transforms.apply(inv, base_traj)
+    pose = lambda xyz: np.concatenate([np.arange(len(xyz))[:, None] * 0.1, xyz, np.tile([0, 0, 0, 1.0], (len(xyz), 1))], axis=1)  # noqa: E731
+    al = mapalign.Alignment(base_pose_df=pose(base_traj), comparison_pose_df=pose(comp_traj), max_iter=60)
+    stages, T, info = al.align_clouds(gold, comp)
+    assert info["trajectory_scores"] is not None
+    assert coarse.trajectory_residual(T, base_traj, comp_traj) < 0.02
+    eR, et = orc.rt_error(T[:3, :3], T[:3, 3], T_true[:3, :3], T_true[:3, 3])
+    assert eR <= 1e-3 and et <= 5e-3, (eR, et)
+    # the two best cloud scores are the half-turn twins and nearly equal: geometry alone is a coin flip
+    cs = np.sort(info["cloud_scores"])
+    assert cs[1] - cs[0] < 0.25 * cs[0] + 1e-3
+    ts = np.array(info["trajectory_scores"])
+    assert ts.min() < 0.1 and np.sort(ts)[1] > 0.4
+    mapalign.release_cached_engines()

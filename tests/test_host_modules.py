@@ -134,3 +134,90 @@ def test_suppress_bboxes_3d_nms():
     assert sorted(kept) == [1, 2]
     assert [r[5] for r in kept[1]] == [0.9, 0.8] and [r[5] for r in kept[2]] == [0.5]
     assert boxes.suppress_bboxes({}) == {}
+
+
+def test_bbox_comparison_class_has_the_reference_call_shape(tmp_path):
+    """task_def.py:190-197: BBoxComparison(gold, aligned, goldstd_mesh, visualise=, csv_output_file=).match_bboxes()"""
+    import mapalign
+    sq = lambda c: [np.array(c) + d for d in ([0, 0, 0], [0.2, 0, 0], [0.2, 0.2, 0], [0, 0.2, 0])]   # noqa: E731
+    gold = {0: [sq([0, 0, 0]) + [0, 0.9, 3], sq([5, 0, 0]) + [0, 0.8, 4]], 2: [sq([9, 1, 0]) + [0, 0.7, 5]]}
+    aligned = {1: [sq([0.05, 0, 0]) + [1, 0.9, 3]], 4: [sq([9.1, 1, 0]) + [0, 0.6, 5]]}
+    csv_path = tmp_path / "out.csv"
+    cmp_ = mapalign.BBoxComparison(gold, aligned, np.zeros((4, 3)), visualise=False, csv_output_file=str(csv_path))
+    res = cmp_.match_bboxes()
+    assert res is cmp_.result
+    assert sorted((g, a) for g, a, _ in res["matches"]) == [(0, 0), (2, 1)]
+    assert res["missing"] == [1] and res["damaged"] == [0] and res["unexpected"] == []
+    assert res == boxes.match_bboxes(gold, aligned)
+    lines = csv_path.read_text().strip().splitlines()
+    assert len(lines) == 4 and "missing" in lines[-1]
+
+
+def _pose_table(xyz):
+    """Array in the reference's pose layout: timestamp tx ty tz qx qy qz qw (database_query.py:22)."""
+    k = len(xyz)
+    return np.concatenate([np.arange(k)[:, None] * 0.1, xyz, np.tile([0, 0, 0, 1.0], (k, 1))], axis=1)
+
+
+def test_trajectory_helpers_and_half_turn_disambiguation():
+    # a walk along the carriage, 0.4 m off the centre line, recorded at uneven speed
+    s = np.sort(np.random.default_rng(0).uniform(0, 18, 80))
+    base = np.stack([1 + s, np.full_like(s, 1.9), np.full_like(s, 1.5)], axis=1)
+    assert np.allclose(coarse.trajectory_xyz(_pose_table(base)), base)
+    assert np.allclose(coarse.trajectory_xyz({"tx": base[:, 0], "ty": base[:, 1], "tz": base[:, 2]}), base)
+    assert coarse.trajectory_xyz(None) is None and coarse.trajectory_xyz(base[:1]) is None
+    poly = coarse.resample_polyline(base, 10)
+    assert np.allclose(np.diff(poly[:, 0]), np.diff(poly[:, 0])[0]) and np.allclose(poly[[0, -1]], base[[0, -1]])
+    # the comparison scan's frame: turned by 90 deg about z and shifted
+    Rz = syn.rotation_about_axis([0, 0, 1], np.pi / 2)
+    T_true = transforms.rt_to_matrix(Rz, [3.0, -2.0, 0.5])                 # comparison -> gold
+    comp = transforms.apply(np.linalg.inv(T_true), base)[::-1]               # walked from the other end
+    assert coarse.trajectory_residual(T_true, base, comp) < 1e-9
+    # the half-turn twin of T_true (about the vertical axis through the shell's centre)
+    c = np.array([10.0, 1.5, 1.25])
+    half = transforms.rotation_about_centre(syn.rotation_about_axis([0, 0, 1], np.pi), c)
+    assert coarse.trajectory_residual(half @ T_true, base, comp) > 0.5      # camera lands on the wrong side of the centre line
+
+
+def test_detector_adaptor_rows_and_batched_lift_bookkeeping():
+    """Row schema of detector.py:155 + :126-127 out of the torch adaptor (CPU, tiny input)."""
+    import torch
+    from mapalign import detect
+
+    torch.manual_seed(0)
+    model = detect.build_yolov10_like(num_classes=5, width=(8, 8, 16, 16, 32), max_det=20)
+
+    class TwoClass(torch.nn.Module):
+        def forward(self, x):
+            return torch.stack([x.mean(dim=(1, 2, 3)), 1.0 - x.mean(dim=(1, 2, 3))], dim=1)
+
+    det = detect.Detector(model, TwoClass(), batch_size=2, conf_thresh=0.0, device="cpu", half=False, crop_size=32)
+    imgs = (np.random.default_rng(0).random((3, 64, 96, 3)) * 255).astype(np.uint8)
+    raw, _ = det.infer(imgs)
+    assert raw.shape == (3, 20, 6)
+    preds = det(imgs)
+    assert sorted(preds) == [0, 1, 2] and all(len(preds[k]) == 20 for k in preds)
+    row = preds[1][0]
+    assert len(row) == 7 and isinstance(row[6], int) and row[4] in (0, 1)    # x1 y1 x2 y2 damage conf label
+    assert np.allclose(row[:4], raw[1, 0, :4].numpy()) and abs(row[5] - float(raw[1, 0, 4])) < 1e-6
+    # a stricter threshold drops rows, never reorders them
+    det.conf_thresh = float(np.quantile(raw[:, :, 4].numpy(), 0.7))
+    fewer = det(imgs)
+    assert 0 < sum(len(v) for v in fewer.values()) < 60
+
+    class FakeEngine:   # records what lift_batch hands to the ONE device call
+        def lift_boxes_batch(self, b, bf, d, K, T, scale):
+            self.args = (b, bf, d.shape, K, T.shape, scale)
+            return np.zeros((len(b), 4, 3)), np.ones((len(b), 4), bool)
+
+    eng = FakeEngine()
+    intr = {"fx": 100.0, "fy": 100.0, "cx": 48.0, "cy": 32.0, "image_width": 96, "image_height": 64}
+    poses = np.tile([0, 0, 0, 0, 0, 0, 1.0], (3, 1))
+    out = detect.lift_batch(eng, fewer, np.ones((3, 32, 48), np.float32), intr, poses)
+    b, bf, dshape, K, Tshape, _ = eng.args
+    assert len(b) == sum(len(v) for v in fewer.values()) and dshape == (3, 32, 48) and Tshape == (3, 4, 4)
+    assert K == (50.0, 50.0, 24.0, 16.0)                                      # intrinsics / (image_width / depth_width)
+    assert list(bf) == sorted(bf) and set(out) == {f for f in fewer if fewer[f]}
+    f0 = min(out)
+    assert np.allclose(b[0], np.array(fewer[f0][0][:4]) * 0.5)                # scale_bounding_box to depth resolution
+    assert out[f0][0][4:] == fewer[f0][0][-3:]

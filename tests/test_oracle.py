@@ -135,3 +135,88 @@ def test_oracle_reproduces_golden_depth(golden):
     g = golden("depth_a.npz")
     pts, mask = orc.unproject_oracle(g["depth"], g["K"], g["T"], float(g["scale"]))
     assert np.array_equal(mask, g["mask"]) and np.allclose(pts, g["points"], atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------
+# Independent second restatement: scipy cKDTree for the correspondences and Horn's
+# closed-form QUATERNION solve for the rigid step (a different search structure and a
+# different solver from the oracle's sklearn KD-tree + SVD Kabsch).  The oracle is unpinned by
+# the reference (its align.py is absent), so agreement of two independently written
+# restatements is the strongest cross-check available here.
+# ---------------------------------------------------------------------------------------
+def horn_quaternion_step(p, q, w):
+    """Horn 1987: the rotation is the eigenvector of the largest eigenvalue of the 4x4
+    matrix N built from the weighted cross-covariance; then t = mu_q - R mu_p."""
+    W = w.sum()
+    mu_p, mu_q = (w[:, None] * p).sum(0) / W, (w[:, None] * q).sum(0) / W
+    M = ((p - mu_p) * w[:, None]).T @ (q - mu_q)          # M_ab = sum w (p-mu_p)_a (q-mu_q)_b
+    Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz = M.ravel()
+    N = np.array([[Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx],
+                  [Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz],
+                  [Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy],
+                  [Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz]])
+    vals, vecs = np.linalg.eigh(N)
+    qw, qx, qy, qz = vecs[:, np.argmax(vals)]
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                  [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                  [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    return R, mu_q - R @ mu_p
+
+
+def second_restatement_icp(gold, comp, max_iter, gate, weights=None):
+    from scipy.spatial import cKDTree
+    gold = np.asarray(gold, dtype=np.float64)
+    comp = np.asarray(comp, dtype=np.float64)
+    tree = cKDTree(gold)
+    R, t = np.eye(3), np.zeros(3)
+    inliers = []
+    for _ in range(max_iter):
+        moved = comp @ R.T + t
+        d, j = tree.query(moved, k=1)
+        w = (d <= gate).astype(np.float64) if np.isfinite(gate) else np.ones(len(d))
+        if weights is not None:
+            w = w * weights
+        inliers.append(float(w.sum()))
+        keep = w > 0
+        dR, dt = horn_quaternion_step(moved[keep], gold[j[keep]], w[keep])
+        R, t = dR @ R, dR @ t + dt
+    return R, t, inliers
+
+
+@pytest.mark.parametrize("seed,n,gate,resample", [(0, 10_000, 0.10, True), (3, 6000, 0.35, True), (5, 4000, np.inf, False),
+                                                   (7, 8000, 0.10, True)])
+def test_oracle_agrees_with_independent_ckdtree_horn_restatement(seed, n, gate, resample):
+    gold, comp, R0, t0 = syn.make_pair(seed, n, resample=resample)
+    iters = 25
+    ref = orc.icp_oracle(gold, comp, max_iter=iters, max_corr_dist=gate, n_jobs=1)
+    R2, t2, inl2 = second_restatement_icp(gold, comp, iters, gate)
+    # same correspondences every iteration => same inlier counts, and transforms equal to rounding
+    assert [row["inliers"] for row in ref["trace"]] == inl2
+    eR, et = orc.rt_error(ref["R"], ref["t"], R2, t2)
+    assert eR < 1e-9 and et < 1e-9, (eR, et)
+
+
+def test_oracle_agrees_with_second_restatement_weighted():
+    gold, comp, _, _ = syn.make_pair(11, 5000)
+    w = np.random.default_rng(1).uniform(0.0, 2.0, len(comp))
+    ref = orc.icp_oracle(gold, comp, max_iter=12, max_corr_dist=0.2, weights=w, n_jobs=1)
+    R2, t2, _ = second_restatement_icp(gold, comp, 12, 0.2, weights=w)
+    eR, et = orc.rt_error(ref["R"], ref["t"], R2, t2)
+    assert eR < 1e-9 and et < 1e-9, (eR, et)
+
+
+def test_kabsch_weights_are_not_counts():
+    """Normalised weights (sum 1) over many exact correspondences must solve, not report
+    'fewer than 3 correspondences' (the W >= 3 test confused weight with count)."""
+    rng = np.random.default_rng(4)
+    p = rng.normal(size=(500, 3))
+    R0 = syn.rotation_about_axis([0.2, 0.9, -0.4], 0.3)
+    q = p @ R0.T + np.array([0.3, -0.1, 0.2])
+    w = np.full(500, 1.0 / 500)
+    dR, dt, ok = orc.kabsch_from_acc(orc.accumulate(p, q, w, np.zeros(500)))
+    assert ok and np.allclose(dR, R0, atol=1e-12) and np.allclose(dt, [0.3, -0.1, 0.2], atol=1e-12)
+    # one or two pairs, or no weight at all, are degenerate whatever their weight
+    for k in (0, 1, 2):
+        wk = np.zeros(500)
+        wk[:k] = 5.0
+        assert not orc.kabsch_from_acc(orc.accumulate(p, q, wk, np.zeros(500)))[2]
