@@ -561,6 +561,18 @@ constexpr int kRowCap = 128, kChunkCap = 256, kChunkLen = 8;
 #ifndef MA_ROWS_PER_TRIP
 #define MA_ROWS_PER_TRIP 2
 #endif
+#ifndef MA_CHUNK_PREFETCH
+#define MA_CHUNK_PREFETCH 0
+#endif
+#ifndef MA_MERGE_RINGS
+#define MA_MERGE_RINGS 0
+#endif
+#ifndef MA_SIDE_SKIP
+#define MA_SIDE_SKIP 0
+#endif
+#ifndef MA_FENCED_TICKET
+#define MA_FENCED_TICKET 0
+#endif
 
 struct WaveLds {
   float4 pos[kWave];
@@ -594,6 +606,19 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
       float b2 = __uint_as_float((uint32_t)(W.best[lq] >> 32));
       const float b2_in = b2;
       uint32_t bj = kNoMatch;
+#if MA_CHUNK_PREFETCH
+      {   // all (<= 8) candidates of the chunk in flight at once: one memory round trip per chunk item
+        float3 q[kChunkLen];
+#pragma unroll
+        for (int u = 0; u < kChunkLen; ++u) q[u] = ld_xyz(gold0, a + min((uint32_t)u, cnt - 1u));
+#pragma unroll
+        for (int u = 0; u < kChunkLen; ++u) {
+          const float dx = p.x - q[u].x, dy = p.y - q[u].y, dz = p.z - q[u].z;
+          const float d = dx * dx + dy * dy + dz * dz;
+          if (d < b2) { b2 = d; bj = a + min((uint32_t)u, cnt - 1u); }
+        }
+      }
+#else
       for (uint32_t t = 0; t < cnt; t += 4u) {
         float3 q[4];
         uint32_t at[4];
@@ -609,6 +634,7 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
           if (d < b2) { b2 = d; bj = at[u]; }   // level 0: position == index
         }
       }
+#endif
       if (COUNT) ncand += cnt;
       if (b2 < b2_in) atomicMin(&W.best[lq], pack_best(b2, bj));
     }
@@ -764,6 +790,42 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     more = more && !dismissed;
     ndismissed = (uint32_t)__popcll(__ballot(dismissed));
   }
+#if MA_MERGE_RINGS
+  // every ring the sphere (as it stands after the 3 x 3 block) reaches, in ONE round: the
+  // row items are bounded again by the then-current best when they are flushed, so the work
+  // per row shrinks as before, but the two flush phases per ring (two dependent memory round
+  // trips each) are paid once.
+  {
+    bool any_pushed = false;
+    for (int r = 2; ; ++r) {
+      const float lb = (float)(r - 1) * c - S.delta;
+      const bool mr = more && r <= rmax && lb * lb < best2;
+      if (!__any(mr)) break;
+      any_pushed = true;
+      for (int side = 0; side < 4; ++side) {
+        const bool zfixed = (side & 1) == 0;
+        const int dfix = (side == 0 || side == 3) ? -r : r;
+        const float ffix = zfixed ? fz : fy, fvar = zfixed ? fy : fz;
+        const int cfix = zfixed ? cz : cy, cvar = zfixed ? cy : cz, nfix = zfixed ? nz : ny, nvar = zfixed ? ny : nz;
+        const float gfix = gap2(dfix, ffix, cfix, nfix);
+        if (!__any(mr && gfix < best2)) continue;
+        for (int o = 0; o < 2 * r; ++o) {
+          const int dvar = side < 2 ? o - r : r - o;
+          const float d2yz = gfix + gap2(dvar, fvar, cvar, nvar);
+          const int dy = zfixed ? dvar : dfix, dz = zfixed ? dfix : dvar;
+          push_row(mr && d2yz < best2, cy + dy, cz + dz, d2yz);
+        }
+      }
+    }
+    if (any_pushed) {
+      wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
+      wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
+      const unsigned long long key = W.best[lane];
+      best2 = __uint_as_float((uint32_t)(key >> 32));
+      bestj = (uint32_t)key;
+    }
+  }
+#else
   for (int r = 2; __any(more); ++r) {
     const float lb = (float)(r - 1) * c - S.delta;
     more = more && r <= rmax && lb * lb < best2;
@@ -776,6 +838,9 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
       const float ffix = zfixed ? fz : fy, fvar = zfixed ? fy : fz;
       const int cfix = zfixed ? cz : cy, cvar = zfixed ? cy : cz, nfix = zfixed ? nz : ny, nvar = zfixed ? ny : nz;
       const float gfix = gap2(dfix, ffix, cfix, nfix);
+#if MA_SIDE_SKIP
+      if (!__any(more && gfix < best2)) continue;   // no query's sphere reaches this side of the ring
+#endif
       for (int o = 0; o < 2 * r; ++o) {
         const int dvar = side < 2 ? o - r : r - o;
         const float d2yz = gfix + gap2(dvar, fvar, cvar, nvar);
@@ -789,6 +854,7 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     best2 = __uint_as_float((uint32_t)(key >> 32));
     bestj = (uint32_t)key;
   }
+#endif
   if (fallback) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows_cnt, ncand);
 }
 
@@ -1184,10 +1250,16 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   if (threadIdx.x != 0) return;
   __hip_atomic_store(&acc_out[k], ((red[0] + red[1]) + red[2]) + red[3], __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
+#if MA_FENCED_TICKET
+  // memory-model form: release on the ticket, acquire by the last arriver
+  const uint32_t arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (arrived != (uint32_t)(kNAcc - 1)) return;
+#else
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const uint32_t arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (arrived != (uint32_t)(kNAcc - 1)) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (compiler barrier: the loads below stay below the add)
+#endif
   __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   double a[kNAcc];
 #pragma unroll
@@ -1211,14 +1283,28 @@ struct Pinhole {
   double T[12];  // camera->world rows 0..2, translation already minus the centring origin
 };
 
-// PASS 0: per-workgroup count of valid pixels.  PASS 1: write points at the scanned offsets.
-template <typename T, int PASS>
+// ONE pass over the depth image: every workgroup loads its 1024 pixels once, counts the valid
+// ones, and obtains the number of valid pixels in front of it by a decoupled look-back over the
+// status words of its predecessors (aggregate / inclusive prefix, published write-through at
+// agent scope) instead of a separate counting pass + scan + second read of the image.
+// Forward progress: workgroups take their logical index from an atomic ticket, so every
+// predecessor a workgroup waits for has already started (dispatch order is not assumed); every
+// spin is bounded and a timeout raises an error word instead of hanging the device.
+constexpr unsigned long long kScanAggregate = 1ull << 32, kScanPrefix = 2ull << 32;
+constexpr uint32_t kScanSpinLimit = 1u << 22;
+
+template <typename T>
 __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ depth, const int width,
                                                       const uint32_t npx, const Pinhole cam,
-                                                      uint32_t* __restrict__ block_counts,
-                                                      const uint32_t* __restrict__ block_offsets,
+                                                      uint32_t* __restrict__ ticket /*[0] ticket, [1] total, [2] error*/,
+                                                      unsigned long long* __restrict__ status,
                                                       float4* __restrict__ out) {
-  const uint32_t first = blockIdx.x * kPxPerBlock + threadIdx.x * kPxPerThread;
+  __shared__ uint32_t sh_block, sh_prefix;
+  __shared__ uint32_t wsum[kBlock / kWave];
+  if (threadIdx.x == 0) sh_block = atomicAdd(&ticket[0], 1u);
+  __syncthreads();
+  const uint32_t blk = sh_block;
+  const uint32_t first = blk * kPxPerBlock + threadIdx.x * kPxPerThread;
   double z[kPxPerThread];
   uint32_t cnt = 0;
 #pragma unroll
@@ -1236,7 +1322,6 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
     const uint32_t u = __shfl_up(incl, off, kWave);
     if (lane >= off) incl += u;
   }
-  __shared__ uint32_t wsum[kBlock / kWave];
   if (lane == kWave - 1) wsum[wv] = incl;
   __syncthreads();
   uint32_t wbase = 0, total = 0;
@@ -1244,11 +1329,47 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
     if (w < wv) wbase += wsum[w];
     total += wsum[w];
   }
-  if (PASS == 0) {
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
-    return;
+  if (wv == 0) {
+    if (lane == 0)
+      __hip_atomic_store(&status[blk], (blk == 0 ? kScanPrefix : kScanAggregate) | total, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t prefix = 0;
+    if (blk > 0) {
+      // look-back, 64 predecessors per trip: lane l inspects workgroup base - l
+      int base = (int)blk - 1;
+      uint32_t spins = 0;
+      for (;;) {
+        const int idx = base - lane;
+        const unsigned long long st = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : kScanPrefix;     // in front of workgroup 0: prefix 0
+        const uint32_t flag = (uint32_t)(st >> 32);
+        const unsigned long long not_ready = __ballot(flag == 0u), is_prefix = __ballot(flag == 2u);
+        // the nearest predecessor that already knows its inclusive prefix ends the walk
+        const int stop = is_prefix ? __builtin_ctzll(is_prefix) : kWave;
+        const unsigned long long window = stop >= kWave - 1 ? ~0ull : ((2ull << stop) - 1ull);
+        if (not_ready & window) {
+          if (++spins > kScanSpinLimit) { if (lane == 0) atomicExch(&ticket[2], 1u); break; }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        uint32_t v = lane <= stop ? (uint32_t)st : 0u;
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+        prefix += v;
+        if (is_prefix) break;
+        base -= kWave;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&status[blk], kScanPrefix | (unsigned long long)(prefix + total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) {
+      sh_prefix = prefix;
+      if (blk == gridDim.x - 1) ticket[1] = prefix + total;   // number of valid pixels of the image
+    }
   }
-  uint32_t pos = block_offsets[blockIdx.x] + wbase + (incl - cnt);
+  __syncthreads();
+  uint32_t pos = sh_prefix + wbase + (incl - cnt);
 #pragma unroll
   for (int k = 0; k < kPxPerThread; ++k) {
     if (z[k] > 0.0) {
@@ -1481,6 +1602,7 @@ struct ma_ctx {
   int* host_done = nullptr;      // pinned host word the solve sets when the loop stops (tol > 0 runs)
   std::vector<hipEvent_t> batch_ev;
   MemStats mem;
+  double last_op_ms = 0;         // device time of the last unprojection (ma_last_device_ms)
   bool oom = false;              // a C++ allocation failed inside the last call (no message storage)
   // RCCL communicator of the sharded-source mode (ma_comm_init); opaque here
   void* comm = nullptr;
@@ -1768,6 +1890,49 @@ void fill_stats(const DevState& s, double gpu_ms, ma_stats* st) {
   st->rmse = s.last_rmse;
   st->inliers = s.last_W;
   st->gpu_ms = gpu_ms;
+}
+
+// Depth frame already in ctx->depth_in -> world points appended at `out` (single-pass
+// k_unproject).  *total receives the number of valid pixels; ev0/ev1 bracket the device work.
+int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinhole& cam, float4* out, uint32_t* total) {
+  const uint32_t nb = div_up(npx, kPxPerBlock);
+  HIPCHK(ctx->keys_a.ensure(64));
+  HIPCHK(ctx->keys_b.ensure((size_t)nb * 8));
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->keys_a.p, 0, 16, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->keys_b.p, 0, (size_t)nb * 8, ctx->stream));
+  if (dtype == 0) {
+    hipLaunchKernelGGL(k_unproject<float>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(), width, npx,
+                       cam, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<unsigned long long>(), out);
+  } else {
+    hipLaunchKernelGGL(k_unproject<uint16_t>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<uint16_t>(), width,
+                       npx, cam, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<unsigned long long>(), out);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  uint32_t h[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(h, ctx->keys_a.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  ctx->last_op_ms = ms;
+  if (h[2]) return ctx->fail(MA_ERR_HIP, "k_unproject: look-back timed out (a predecessor workgroup never published its count)");
+  *total = h[1];
+  return MA_OK;
+}
+
+Pinhole make_pinhole(const float K[4], const double T[16], float depth_scale, const double origin[3]) {
+  Pinhole cam{};
+  cam.fx_inv = 1.0 / (double)K[0];
+  cam.fy_inv = 1.0 / (double)K[1];
+  cam.cx = K[2];
+  cam.cy = K[3];
+  cam.inv_scale = 1.0 / (double)depth_scale;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) cam.T[4 * r + c] = T[4 * r + c];
+    cam.T[4 * r + 3] = T[4 * r + 3] - origin[r];
+  }
+  return cam;
 }
 
 // No C++ exception crosses the C ABI: std::vector / std::string allocations inside the entry
@@ -2139,48 +2304,11 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   HIPCHK(ctx->depth_in.ensure((size_t)npx * esz));
   HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, (size_t)npx * esz, hipMemcpyHostToDevice, ctx->stream));
   ctx->depth_w = width; ctx->depth_h = height; ctx->depth_dtype = dtype;
-  Pinhole cam{};
-  cam.fx_inv = 1.0 / (double)K[0];
-  cam.fy_inv = 1.0 / (double)K[1];
-  cam.cx = K[2];
-  cam.cy = K[3];
-  cam.inv_scale = 1.0 / (double)depth_scale;
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) cam.T[4 * r + c] = T[4 * r + c];
-    cam.T[4 * r + 3] = T[4 * r + 3] - ctx->origin[r];
-  }
-  const uint32_t nb = div_up(npx, kPxPerBlock);
-  HIPCHK(ctx->keys_a.ensure((size_t)(nb + 1) * 4));
-  HIPCHK(ctx->keys_b.ensure((size_t)(nb + 1) * 4));
-  HIPCHK(hipMemsetAsync(ctx->keys_a.p, 0, (size_t)(nb + 1) * 4, ctx->stream));
+  const Pinhole cam = make_pinhole(K, T, depth_scale, ctx->origin);
   HIPCHK(ctx->src.ensure((size_t)npx * sizeof(float4)));
-  if (dtype == 0) {
-    hipLaunchKernelGGL((k_unproject<float, 0>), dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
-                       width, npx, cam, ctx->keys_a.as<uint32_t>(), (const uint32_t*)nullptr, (float4*)nullptr);
-  } else {
-    hipLaunchKernelGGL((k_unproject<uint16_t, 0>), dim3(nb), dim3(kBlock), 0, ctx->stream,
-                       ctx->depth_in.as<uint16_t>(), width, npx, cam, ctx->keys_a.as<uint32_t>(),
-                       (const uint32_t*)nullptr, (float4*)nullptr);
-  }
-  HIPCHK(hipGetLastError());
-  size_t tmp_bytes = 0;
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(),
-                                          ctx->keys_b.as<uint32_t>(), (int)(nb + 1), ctx->stream));
-  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(),
-                                          ctx->keys_b.as<uint32_t>(), (int)(nb + 1), ctx->stream));
-  if (dtype == 0) {
-    hipLaunchKernelGGL((k_unproject<float, 1>), dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
-                       width, npx, cam, (uint32_t*)nullptr, ctx->keys_b.as<uint32_t>(), ctx->src.as<float4>());
-  } else {
-    hipLaunchKernelGGL((k_unproject<uint16_t, 1>), dim3(nb), dim3(kBlock), 0, ctx->stream,
-                       ctx->depth_in.as<uint16_t>(), width, npx, cam, (uint32_t*)nullptr,
-                       ctx->keys_b.as<uint32_t>(), ctx->src.as<float4>());
-  }
-  HIPCHK(hipGetLastError());
   uint32_t total = 0;
-  HIPCHK(hipMemcpyAsync(&total, ctx->keys_b.as<uint32_t>() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int rc = unproject_frame(ctx, dtype, width, npx, cam, ctx->src.as<float4>(), &total);
+  if (rc) return rc;
   if (n_valid) *n_valid = total;
   if (total == 0) return ctx->fail(MA_ERR_EMPTY, "depth image has no valid pixel");
   ctx->n = total;
@@ -2226,48 +2354,10 @@ int ma_map_add_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int h
   HIPCHK(ctx->depth_in.ensure((size_t)npx * esz));
   HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, (size_t)npx * esz, hipMemcpyHostToDevice, ctx->stream));
   ctx->depth_w = width; ctx->depth_h = height; ctx->depth_dtype = dtype;
-  Pinhole cam{};
-  cam.fx_inv = 1.0 / (double)K[0];
-  cam.fy_inv = 1.0 / (double)K[1];
-  cam.cx = K[2];
-  cam.cy = K[3];
-  cam.inv_scale = 1.0 / (double)depth_scale;
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) cam.T[4 * r + c] = T[4 * r + c];
-    cam.T[4 * r + 3] = T[4 * r + 3] - ctx->map_origin[r];
-  }
-  const uint32_t nb = div_up(npx, kPxPerBlock);
-  HIPCHK(ctx->keys_a.ensure((size_t)(nb + 1) * 4));
-  HIPCHK(ctx->keys_b.ensure((size_t)(nb + 1) * 4));
-  HIPCHK(hipMemsetAsync(ctx->keys_a.p, 0, (size_t)(nb + 1) * 4, ctx->stream));
-  float4* out = ctx->map_pts.as<float4>() + ctx->map_n;
-  if (dtype == 0) {
-    hipLaunchKernelGGL((k_unproject<float, 0>), dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
-                       width, npx, cam, ctx->keys_a.as<uint32_t>(), (const uint32_t*)nullptr, (float4*)nullptr);
-  } else {
-    hipLaunchKernelGGL((k_unproject<uint16_t, 0>), dim3(nb), dim3(kBlock), 0, ctx->stream,
-                       ctx->depth_in.as<uint16_t>(), width, npx, cam, ctx->keys_a.as<uint32_t>(),
-                       (const uint32_t*)nullptr, (float4*)nullptr);
-  }
-  HIPCHK(hipGetLastError());
-  size_t tmp_bytes = 0;
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(),
-                                          ctx->keys_b.as<uint32_t>(), (int)(nb + 1), ctx->stream));
-  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(),
-                                          ctx->keys_b.as<uint32_t>(), (int)(nb + 1), ctx->stream));
-  if (dtype == 0) {
-    hipLaunchKernelGGL((k_unproject<float, 1>), dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
-                       width, npx, cam, (uint32_t*)nullptr, ctx->keys_b.as<uint32_t>(), out);
-  } else {
-    hipLaunchKernelGGL((k_unproject<uint16_t, 1>), dim3(nb), dim3(kBlock), 0, ctx->stream,
-                       ctx->depth_in.as<uint16_t>(), width, npx, cam, (uint32_t*)nullptr,
-                       ctx->keys_b.as<uint32_t>(), out);
-  }
-  HIPCHK(hipGetLastError());
+  const Pinhole cam = make_pinhole(K, T, depth_scale, ctx->map_origin);
   uint32_t total = 0;
-  HIPCHK(hipMemcpyAsync(&total, ctx->keys_b.as<uint32_t>() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int rc = unproject_frame(ctx, dtype, width, npx, cam, ctx->map_pts.as<float4>() + ctx->map_n, &total);
+  if (rc) return rc;
   ctx->map_n += total;
   if (n_added) *n_added = total;
   return MA_OK;
@@ -2629,6 +2719,12 @@ int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out) {
   out->device_frees = ctx->mem.frees;
   out->bytes_live = ctx->mem.bytes_live;
   out->bytes_peak = ctx->mem.bytes_peak;
+  return MA_OK;
+}
+
+int ma_last_device_ms(const ma_ctx* ctx, double* ms) {
+  if (!ctx || !ms) return MA_ERR_INVALID;
+  *ms = ctx->last_op_ms;
   return MA_OK;
 }
 

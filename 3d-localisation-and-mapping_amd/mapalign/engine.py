@@ -306,6 +306,12 @@ class MapAligner:
             b.shape[0], _f64p(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out + self._shift, valid.astype(bool)
 
+    def last_device_ms(self):
+        """Device time of the last set_source_from_depth / map_add_depth (the single-pass unprojection)."""
+        v = C.c_double(0.0)
+        self._chk(self._lib.ma_last_device_ms(self._ctx, C.byref(v)))
+        return float(v.value)
+
     def mem_info(self):
         """Device allocations of this context since it was created (hipMalloc / hipFree counts, bytes)."""
         mi = ma_mem_info()

@@ -131,6 +131,9 @@ int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out);
 int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height,
                              const float K[4], const double T_cam_to_world[16],
                              float depth_scale, uint64_t* n_valid);
+/* Device time (ms, hipEvents on the ctx stream) of the last ma_set_source_from_depth /
+ * ma_map_add_depth: memset of the scan status + the single-pass k_unproject. */
+int ma_last_device_ms(const ma_ctx* ctx, double* ms);
 /* Row N4: full-frame map builder — what RTAB-Map's .ply export does for the
  * reference, on the device: every depth frame is unprojected with its pose (same pinhole
  * model as ma_set_source_from_depth, pose_processor.py:88-122,262-271) into one buffer, and
