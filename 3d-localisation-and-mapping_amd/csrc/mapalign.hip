@@ -561,8 +561,11 @@ constexpr int kRowCap = 128, kChunkCap = 256, kChunkLen = 8;
 #ifndef MA_ROWS_PER_TRIP
 #define MA_ROWS_PER_TRIP 2
 #endif
-#ifndef MA_CHUNK_PREFETCH
-#define MA_CHUNK_PREFETCH 0
+#ifndef MA_CAND_FAST
+#define MA_CAND_FAST 0
+#endif
+#ifndef MA_ROW_SPLIT
+#define MA_ROW_SPLIT 0
 #endif
 #ifndef MA_MERGE_RINGS
 #define MA_MERGE_RINGS 0
@@ -571,7 +574,7 @@ constexpr int kRowCap = 128, kChunkCap = 256, kChunkLen = 8;
 #define MA_SIDE_SKIP 0
 #endif
 #ifndef MA_FENCED_TICKET
-#define MA_FENCED_TICKET 0
+#define MA_FENCED_TICKET 1
 #endif
 
 struct WaveLds {
@@ -606,18 +609,28 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
       float b2 = __uint_as_float((uint32_t)(W.best[lq] >> 32));
       const float b2_in = b2;
       uint32_t bj = kNoMatch;
-#if MA_CHUNK_PREFETCH
-      {   // all (<= 8) candidates of the chunk in flight at once: one memory round trip per chunk item
-        float3 q[kChunkLen];
+#if MA_CAND_FAST
+      // Four candidates per trip at consecutive positions a+t .. a+t+3, WITHOUT clamping to the
+      // chunk: the positions past its end hold other gold points (the next cells of the sorted
+      // array; four far-away pad entries follow the last point), and any gold point is a
+      // legitimate candidate — the minimum over a superset that contains the true neighbour is
+      // still the true neighbour.  One address per trip (the other three loads use immediate
+      // offsets) and the winner is tracked as a small offset from `a`: 10 instead of 14 VALU
+      // instructions per candidate.
+      uint32_t bo = 0xFFFFFFFFu;
+      for (uint32_t t = 0; t < cnt; t += 4u) {
+        const char* __restrict__ at = reinterpret_cast<const char*>(gold0) + ((a + t) << 4);
+        float3 q[4];
 #pragma unroll
-        for (int u = 0; u < kChunkLen; ++u) q[u] = ld_xyz(gold0, a + min((uint32_t)u, cnt - 1u));
+        for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float3*>(at + 16 * u);
 #pragma unroll
-        for (int u = 0; u < kChunkLen; ++u) {
+        for (int u = 0; u < 4; ++u) {
           const float dx = p.x - q[u].x, dy = p.y - q[u].y, dz = p.z - q[u].z;
           const float d = dx * dx + dy * dy + dz * dz;
-          if (d < b2) { b2 = d; bj = a + min((uint32_t)u, cnt - 1u); }
+          if (d < b2) { b2 = d; bo = t + (uint32_t)u; }
         }
       }
+      bj = a + bo;
 #else
       for (uint32_t t = 0; t < cnt; t += 4u) {
         float3 q[4];
@@ -655,6 +668,48 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
   // two chunk items per trip in wq_flush_chunks: 118 VGPRs, 3.62 ms.
   for (uint32_t i0 = 0; i0 < nrow; i0 += MA_ROWS_PER_TRIP * kWave) {
     uint32_t a[MA_ROWS_PER_TRIP], b[MA_ROWS_PER_TRIP], lq[MA_ROWS_PER_TRIP];
+#if MA_ROW_SPLIT
+    // Step 1: geometry of every item of the trip (LDS + VALU only).  Step 2: all table reads
+    // of the trip issued back to back.  Step 3: results consumed.  (Consuming a read inside
+    // the branch that issued it made the compiler wait for it there, i.e. before the next
+    // item's reads were even issued: the trip paid one memory latency per item.)
+    uint32_t cell[MA_ROWS_PER_TRIP];
+    int span[MA_ROWS_PER_TRIP];
+#pragma unroll
+    for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
+      const uint32_t i = i0 + (uint32_t)u * kWave + lane;
+      a[u] = 0; b[u] = 0; lq[u] = 0; cell[u] = 0; span[u] = -1;
+      if (i < nrow) {
+        lq[u] = W.row_lane[i];
+        const float d2yz = W.row_d2yz[i];
+        const float4 p = W.pos[lq[u]];
+        const float b2 = __uint_as_float((uint32_t)(W.best[lq[u]] >> 32));
+        if (d2yz < b2) {
+          const float rx = fast_sqrt(b2 - d2yz) + S.delta;
+          const int x0 = (int)fmaxf(floorf((p.x - rx - S.ox) * inv_c), 0.f);
+          const int x1 = (int)fminf(floorf((p.x + rx - S.ox) * inv_c), (float)(nx - 1));
+          if (x0 <= x1) { cell[u] = W.row_cell[i] + (uint32_t)x0; span[u] = x1 - x0; }
+        }
+      }
+    }
+    u4_unaligned v[MA_ROWS_PER_TRIP];
+    uint32_t far[MA_ROWS_PER_TRIP];
+#pragma unroll
+    for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
+      v[u] = u4_unaligned{0u, 0u, 0u, 0u};
+      far[u] = 0u;
+      if (span[u] >= 0) v[u] = ld_cell4(cs0, cell[u]);
+      if (span[u] > 2) far[u] = ld_cell(cs0, cell[u] + (uint32_t)span[u] + 1u);
+    }
+#pragma unroll
+    for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
+      if (span[u] >= 0) {
+        a[u] = v[u].x;
+        b[u] = span[u] == 0 ? v[u].y : (span[u] == 1 ? v[u].z : (span[u] == 2 ? v[u].w : far[u]));
+        if (COUNT) nrows_cnt += span[u] <= 2 ? 4u : 5u;
+      }
+    }
+#else
 #pragma unroll
     for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
       const uint32_t i = i0 + (uint32_t)u * kWave + lane;
@@ -684,6 +739,7 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
         }
       }
     }
+#endif
     // cut [a,b) into chunks; trip k pushes chunk k of every lane that still has one
 #pragma unroll
     for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
@@ -1335,29 +1391,46 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
                          __HIP_MEMORY_SCOPE_AGENT);
     uint32_t prefix = 0;
     if (blk > 0) {
-      // look-back, 64 predecessors per trip: lane l inspects workgroup base - l
+      // look-back, 256 predecessors per trip (a coherent load costs ~2 us on an idle chip and
+      // the walk is a dependent chain of them): lane l inspects workgroups base - l - 64 j,
+      // j = 0..3, the four loads in flight together; sub-window j is consumed only if no nearer
+      // one ended the walk
       int base = (int)blk - 1;
       uint32_t spins = 0;
-      for (;;) {
-        const int idx = base - lane;
-        const unsigned long long st = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                               : kScanPrefix;     // in front of workgroup 0: prefix 0
-        const uint32_t flag = (uint32_t)(st >> 32);
-        const unsigned long long not_ready = __ballot(flag == 0u), is_prefix = __ballot(flag == 2u);
-        // the nearest predecessor that already knows its inclusive prefix ends the walk
-        const int stop = is_prefix ? __builtin_ctzll(is_prefix) : kWave;
-        const unsigned long long window = stop >= kWave - 1 ? ~0ull : ((2ull << stop) - 1ull);
-        if (not_ready & window) {
+      bool done = false;
+      while (!done) {
+        unsigned long long st[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = base - lane - kWave * j;
+          st[j] = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : kScanPrefix;     // in front of workgroup 0: prefix 0
+        }
+        uint32_t add = 0;
+        int consumed = 0;        // leading sub-windows summed in full (all ready, no prefix among them)
+        bool retry = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (done || retry) continue;                      // (wave-uniform)
+          const uint32_t flag = (uint32_t)(st[j] >> 32);
+          const unsigned long long not_ready = __ballot(flag == 0u), is_prefix = __ballot(flag == 2u);
+          // the nearest predecessor that already knows its inclusive prefix ends the walk
+          const int stop = is_prefix ? __builtin_ctzll(is_prefix) : kWave;
+          const unsigned long long window = stop >= kWave - 1 ? ~0ull : ((2ull << stop) - 1ull);
+          if (not_ready & window) { retry = true; continue; }   // reload from this sub-window on
+          uint32_t v = lane <= stop ? (uint32_t)st[j] : 0u;
+#pragma unroll
+          for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+          add += v;
+          if (is_prefix) done = true;
+          else consumed = j + 1;
+        }
+        prefix += add;
+        base -= kWave * consumed;
+        if (retry) {
           if (++spins > kScanSpinLimit) { if (lane == 0) atomicExch(&ticket[2], 1u); break; }
           __builtin_amdgcn_s_sleep(1);
-          continue;
         }
-        uint32_t v = lane <= stop ? (uint32_t)st : 0u;
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-        prefix += v;
-        if (is_prefix) break;
-        base -= kWave;
       }
       if (lane == 0)
         __hip_atomic_store(&status[blk], kScanPrefix | (unsigned long long)(prefix + total), __ATOMIC_RELAXED,
@@ -2167,7 +2240,7 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(),
                                             (int)(ncells + 8), ctx->stream));
-    HIPCHK(ctx->gold[l].ensure((size_t)n * sizeof(float4)));
+    HIPCHK(ctx->gold[l].ensure(((size_t)n + 4) * sizeof(float4)));   // + 4 pad entries (level 0)
     if (l == 0) {
       hipLaunchKernelGGL(k_count_occupied, dim3(std::min<uint32_t>(div_up(ncells, kBlock), 2048)), dim3(kBlock),
                          0, ctx->stream, d_hist, (uint32_t)ncells, static_cast<unsigned long long*>(hist.p));
@@ -2184,6 +2257,13 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
                        (const float*)nullptr, ctx->vals_b.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1],
                        ctx->origin[2], l == 0 ? 1 : 2, ctx->inv0.as<uint32_t>(), ctx->gold[l].as<float4>());
     HIPCHK(hipGetLastError());
+    if (l == 0) {
+      // four far-away pad entries behind the last point: the candidate scan reads four
+      // consecutive positions per trip without clamping to the end of the array
+      static const float4 kFar[4] = {{3e18f, 3e18f, 3e18f, 0.f}, {3e18f, 3e18f, 3e18f, 0.f},
+                                     {3e18f, 3e18f, 3e18f, 0.f}, {3e18f, 3e18f, 3e18f, 0.f}};
+      HIPCHK(hipMemcpyAsync(ctx->gold[0].as<float4>() + n, kFar, sizeof(kFar), hipMemcpyHostToDevice, ctx->stream));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));   // hist / sort scratch is reused by the next level
     L.gold[l] = ctx->gold[l].as<float4>();
     L.cs[l] = ctx->cstart[l].as<uint32_t>();

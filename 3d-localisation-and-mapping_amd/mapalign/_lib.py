@@ -117,6 +117,33 @@ ABI = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (same soname as the system
+    one, ``libamdhip64.so.7``) and load it by FILE name, so a process that loads libmapalign
+    first (system runtime, bound by soname) and imports torch afterwards ends up with two HIP
+    runtimes, and the second one finds no device ("No HIP GPUs are available"; RCCL then fails
+    the same way).  The detector leg (mapalign.detect) and the torch.distributed bootstrap put
+    both in one process, so when torch is installed its bundled runtime is loaded FIRST and
+    libmapalign binds to it by soname, whatever the import order.  torch itself is not
+    imported here.  ``MAPALIGN_SYSTEM_HIP=1`` keeps the system runtime."""
+    if os.environ.get("MAPALIGN_SYSTEM_HIP") == "1":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return None
+        libdir = Path(list(spec.submodule_search_locations)[0]) / "lib"
+        loaded = None
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            cand = libdir / name
+            if cand.exists():
+                loaded = C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        return loaded
+    except OSError:      # pragma: no cover - a broken torch install must not take mapalign down
+        return None
+
+
 def load(path=None):
     """Load (once) and type the shared library.  Loading needs no GPU."""
     global _lib
@@ -127,6 +154,7 @@ def load(path=None):
         raise MapAlignLibraryError(
             f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
             f"g.build()' or make -C {PKG_ROOT / 'csrc'}); mapalign has no CPU fallback")
+    _share_torch_hip_runtime()
     try:
         lib = C.CDLL(str(p))
     except OSError as e:  # pragma: no cover - depends on the host's ROCm install

@@ -58,9 +58,11 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
     # whose distance sits within the fp32 storage error (~1 um) of the gate (2e-5 of the cloud)
     gpu_inl = res.trace[:, 0]
     assert np.abs(gpu_inl - np.array(inliers)).max() <= 20, np.abs(gpu_inl - np.array(inliers)).max()
-    # E = sum of squared distances: a point that flips across the gate moves it by gate^2
+    # E = sum of squared distances: a point that flips across the gate moves it by gate^2, and
+    # the ~1e-8 m difference in the transform that such a flip leaves behind moves E smoothly
+    # (dE/dT ~ 2 sum d_i ~ 1e5 m per metre in the early iterations)
     E_gpu, E_cpu = res.trace[:, 16], np.array(rmse) ** 2 * np.array(inliers)
-    slack = (np.abs(gpu_inl - np.array(inliers)) + 1.0) * 0.10 ** 2 + 1e-6 * E_cpu
+    slack = (np.abs(gpu_inl - np.array(inliers)) + 1.0) * 0.10 ** 2 + 2e-4 * E_cpu
     assert (np.abs(E_gpu - E_cpu) <= slack).all(), np.abs(E_gpu - E_cpu).max()
     if iters == 50:   # and the result is the ground truth of the synthetic pair
         eR0, et0 = orc.rt_error(res.R, res.t, R0, t0)
@@ -80,11 +82,25 @@ def test_5m_source_points_group_count_not_multiple_of_4(engine):
     engine.set_source(comp)
     iters = 6
     res = engine.icp(iters, 0.0, 0.10, with_trace=True)
-    T = np.eye(4)
+    # the same iterations through the stepping entry points: no schedule (chunks in cloud
+    # order), same remembered matches, same fixed-order sums -> bit-identical state
+    import torch
+    acc = torch.zeros(17, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    engine.state_set(None)
     for k in range(iters):
-        acc, T = engine.icp_step(T, 0.10)
-        assert np.array_equal(acc, res.trace[k, :17]), f"iteration {k}: scheduled and unscheduled sums differ"
-    assert np.array_equal(T, res.T)
+        engine.step_accumulate(acc.data_ptr(), 0.10)
+        engine.step_solve(acc.data_ptr(), 0.0, 0.10)
+        engine.sync()
+        assert float(acc[0]) == res.trace[k, 0], f"iteration {k}: scheduled and unscheduled inlier counts differ"
+    T, info = engine.state_get()
+    assert info["iterations"] == iters and np.array_equal(T, res.T)
+    # single steps from scratch (nothing remembered): the same correspondences up to
+    # fp32 near-ties, so the sums agree to rounding and the counts to a few points
+    T1 = np.eye(4)
+    for k in range(3):
+        a1, T1 = engine.icp_step(T1, 0.10)
+        assert abs(a1[0] - res.trace[k, 0]) <= 3 and np.allclose(a1, res.trace[k, :17], rtol=1e-6)
     again = engine.icp(iters, 0.0, 0.10, with_trace=True)
     assert np.array_equal(again.trace, res.trace)
     idx, d2 = engine.nn(None, 0.10)
@@ -160,14 +176,16 @@ def test_tol_early_exit_batches_match_the_oracle(engine):
     """tol > 0 with a large max_iter: the host stops enqueueing once the device reports `done`
     (batches of 8 iterations); the result is the oracle's early stop, not max_iter iterations."""
     gold, comp, _, _ = syn.make_pair(8, 30_000)
-    ref = orc.icp_oracle(gold, comp, max_iter=400, tol=1e-7, max_corr_dist=0.10, n_jobs=1)
-    assert ref["converged"] and ref["iterations"] < 200
+    # tol well above the ~1e-8 m rmse jitter that single points flipping across the gate cause,
+    # so that the stopping iteration is a property of the convergence curve, not of rounding
+    ref = orc.icp_oracle(gold, comp, max_iter=400, tol=1e-6, max_corr_dist=0.10, n_jobs=1)
+    assert ref["converged"] and 24 < ref["iterations"] < 200      # past the first host-side check (iteration 16)
     engine.set_gold(gold)
     engine.set_source(comp)
-    res = engine.icp(400, 1e-7, 0.10, with_trace=True)
-    assert res.converged and abs(res.iterations - ref["iterations"]) <= 2
+    res = engine.icp(400, 1e-6, 0.10, with_trace=True)
+    assert res.converged and abs(res.iterations - ref["iterations"]) <= 1
     eR, et = orc.rt_error(res.R, res.t, ref["R"], ref["t"])
-    assert eR <= 1e-6 and et <= 1e-6
+    assert eR <= 1e-5 and et <= 1e-5
     # and the context is immediately reusable
     assert engine.icp(3, 0.0, 0.10).iterations == 3
 
