@@ -561,21 +561,6 @@ constexpr int kRowCap = 128, kChunkCap = 256, kChunkLen = 8;
 #ifndef MA_ROWS_PER_TRIP
 #define MA_ROWS_PER_TRIP 2
 #endif
-#ifndef MA_CAND_FAST
-#define MA_CAND_FAST 0
-#endif
-#ifndef MA_ROW_SPLIT
-#define MA_ROW_SPLIT 0
-#endif
-#ifndef MA_MERGE_RINGS
-#define MA_MERGE_RINGS 0
-#endif
-#ifndef MA_SIDE_SKIP
-#define MA_SIDE_SKIP 0
-#endif
-#ifndef MA_FENCED_TICKET
-#define MA_FENCED_TICKET 1
-#endif
 
 struct WaveLds {
   float4 pos[kWave];
@@ -609,10 +594,9 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
       float b2 = __uint_as_float((uint32_t)(W.best[lq] >> 32));
       const float b2_in = b2;
       uint32_t bj = kNoMatch;
-#if MA_CAND_FAST
       // Four candidates per trip at consecutive positions a+t .. a+t+3, WITHOUT clamping to the
       // chunk: the positions past its end hold other gold points (the next cells of the sorted
-      // array; four far-away pad entries follow the last point), and any gold point is a
+      // array; eight far-away pad entries follow the last point), and any gold point is a
       // legitimate candidate — the minimum over a superset that contains the true neighbour is
       // still the true neighbour.  One address per trip (the other three loads use immediate
       // offsets) and the winner is tracked as a small offset from `a`: 10 instead of 14 VALU
@@ -631,29 +615,13 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
         }
       }
       bj = a + bo;
-#else
-      for (uint32_t t = 0; t < cnt; t += 4u) {
-        float3 q[4];
-        uint32_t at[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          at[u] = a + min(t + (uint32_t)u, cnt - 1u);
-          q[u] = ld_xyz(gold0, at[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float dx = p.x - q[u].x, dy = p.y - q[u].y, dz = p.z - q[u].z;
-          const float d = dx * dx + dy * dy + dz * dz;
-          if (d < b2) { b2 = d; bj = at[u]; }   // level 0: position == index
-        }
-      }
-#endif
       if (COUNT) ncand += cnt;
       if (b2 < b2_in) atomicMin(&W.best[lq], pack_best(b2, bj));
     }
   }
   nchunk = 0;
 }
+
 
 template <bool COUNT>
 __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const LevelSet& S, uint32_t& nrow,
@@ -668,48 +636,6 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
   // two chunk items per trip in wq_flush_chunks: 118 VGPRs, 3.62 ms.
   for (uint32_t i0 = 0; i0 < nrow; i0 += MA_ROWS_PER_TRIP * kWave) {
     uint32_t a[MA_ROWS_PER_TRIP], b[MA_ROWS_PER_TRIP], lq[MA_ROWS_PER_TRIP];
-#if MA_ROW_SPLIT
-    // Step 1: geometry of every item of the trip (LDS + VALU only).  Step 2: all table reads
-    // of the trip issued back to back.  Step 3: results consumed.  (Consuming a read inside
-    // the branch that issued it made the compiler wait for it there, i.e. before the next
-    // item's reads were even issued: the trip paid one memory latency per item.)
-    uint32_t cell[MA_ROWS_PER_TRIP];
-    int span[MA_ROWS_PER_TRIP];
-#pragma unroll
-    for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
-      const uint32_t i = i0 + (uint32_t)u * kWave + lane;
-      a[u] = 0; b[u] = 0; lq[u] = 0; cell[u] = 0; span[u] = -1;
-      if (i < nrow) {
-        lq[u] = W.row_lane[i];
-        const float d2yz = W.row_d2yz[i];
-        const float4 p = W.pos[lq[u]];
-        const float b2 = __uint_as_float((uint32_t)(W.best[lq[u]] >> 32));
-        if (d2yz < b2) {
-          const float rx = fast_sqrt(b2 - d2yz) + S.delta;
-          const int x0 = (int)fmaxf(floorf((p.x - rx - S.ox) * inv_c), 0.f);
-          const int x1 = (int)fminf(floorf((p.x + rx - S.ox) * inv_c), (float)(nx - 1));
-          if (x0 <= x1) { cell[u] = W.row_cell[i] + (uint32_t)x0; span[u] = x1 - x0; }
-        }
-      }
-    }
-    u4_unaligned v[MA_ROWS_PER_TRIP];
-    uint32_t far[MA_ROWS_PER_TRIP];
-#pragma unroll
-    for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
-      v[u] = u4_unaligned{0u, 0u, 0u, 0u};
-      far[u] = 0u;
-      if (span[u] >= 0) v[u] = ld_cell4(cs0, cell[u]);
-      if (span[u] > 2) far[u] = ld_cell(cs0, cell[u] + (uint32_t)span[u] + 1u);
-    }
-#pragma unroll
-    for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
-      if (span[u] >= 0) {
-        a[u] = v[u].x;
-        b[u] = span[u] == 0 ? v[u].y : (span[u] == 1 ? v[u].z : (span[u] == 2 ? v[u].w : far[u]));
-        if (COUNT) nrows_cnt += span[u] <= 2 ? 4u : 5u;
-      }
-    }
-#else
 #pragma unroll
     for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
       const uint32_t i = i0 + (uint32_t)u * kWave + lane;
@@ -739,7 +665,6 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
         }
       }
     }
-#endif
     // cut [a,b) into chunks; trip k pushes chunk k of every lane that still has one
 #pragma unroll
     for (int u = 0; u < MA_ROWS_PER_TRIP; ++u) {
@@ -846,42 +771,6 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     more = more && !dismissed;
     ndismissed = (uint32_t)__popcll(__ballot(dismissed));
   }
-#if MA_MERGE_RINGS
-  // every ring the sphere (as it stands after the 3 x 3 block) reaches, in ONE round: the
-  // row items are bounded again by the then-current best when they are flushed, so the work
-  // per row shrinks as before, but the two flush phases per ring (two dependent memory round
-  // trips each) are paid once.
-  {
-    bool any_pushed = false;
-    for (int r = 2; ; ++r) {
-      const float lb = (float)(r - 1) * c - S.delta;
-      const bool mr = more && r <= rmax && lb * lb < best2;
-      if (!__any(mr)) break;
-      any_pushed = true;
-      for (int side = 0; side < 4; ++side) {
-        const bool zfixed = (side & 1) == 0;
-        const int dfix = (side == 0 || side == 3) ? -r : r;
-        const float ffix = zfixed ? fz : fy, fvar = zfixed ? fy : fz;
-        const int cfix = zfixed ? cz : cy, cvar = zfixed ? cy : cz, nfix = zfixed ? nz : ny, nvar = zfixed ? ny : nz;
-        const float gfix = gap2(dfix, ffix, cfix, nfix);
-        if (!__any(mr && gfix < best2)) continue;
-        for (int o = 0; o < 2 * r; ++o) {
-          const int dvar = side < 2 ? o - r : r - o;
-          const float d2yz = gfix + gap2(dvar, fvar, cvar, nvar);
-          const int dy = zfixed ? dvar : dfix, dz = zfixed ? dfix : dvar;
-          push_row(mr && d2yz < best2, cy + dy, cz + dz, d2yz);
-        }
-      }
-    }
-    if (any_pushed) {
-      wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
-      wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
-      const unsigned long long key = W.best[lane];
-      best2 = __uint_as_float((uint32_t)(key >> 32));
-      bestj = (uint32_t)key;
-    }
-  }
-#else
   for (int r = 2; __any(more); ++r) {
     const float lb = (float)(r - 1) * c - S.delta;
     more = more && r <= rmax && lb * lb < best2;
@@ -894,9 +783,6 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
       const float ffix = zfixed ? fz : fy, fvar = zfixed ? fy : fz;
       const int cfix = zfixed ? cz : cy, cvar = zfixed ? cy : cz, nfix = zfixed ? nz : ny, nvar = zfixed ? ny : nz;
       const float gfix = gap2(dfix, ffix, cfix, nfix);
-#if MA_SIDE_SKIP
-      if (!__any(more && gfix < best2)) continue;   // no query's sphere reaches this side of the ring
-#endif
       for (int o = 0; o < 2 * r; ++o) {
         const int dvar = side < 2 ? o - r : r - o;
         const float d2yz = gfix + gap2(dvar, fvar, cvar, nvar);
@@ -910,7 +796,6 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     best2 = __uint_as_float((uint32_t)(key >> 32));
     bestj = (uint32_t)key;
   }
-#endif
   if (fallback) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows_cnt, ncand);
 }
 
@@ -1306,16 +1191,9 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   if (threadIdx.x != 0) return;
   __hip_atomic_store(&acc_out[k], ((red[0] + red[1]) + red[2]) + red[3], __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
-#if MA_FENCED_TICKET
   // memory-model form: release on the ticket, acquire by the last arriver
   const uint32_t arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
   if (arrived != (uint32_t)(kNAcc - 1)) return;
-#else
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const uint32_t arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (arrived != (uint32_t)(kNAcc - 1)) return;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (compiler barrier: the loads below stay below the add)
-#endif
   __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   double a[kNAcc];
 #pragma unroll
@@ -2240,7 +2118,7 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(),
                                             (int)(ncells + 8), ctx->stream));
-    HIPCHK(ctx->gold[l].ensure(((size_t)n + 4) * sizeof(float4)));   // + 4 pad entries (level 0)
+    HIPCHK(ctx->gold[l].ensure(((size_t)n + 8) * sizeof(float4)));   // + 8 pad entries (level 0)
     if (l == 0) {
       hipLaunchKernelGGL(k_count_occupied, dim3(std::min<uint32_t>(div_up(ncells, kBlock), 2048)), dim3(kBlock),
                          0, ctx->stream, d_hist, (uint32_t)ncells, static_cast<unsigned long long*>(hist.p));
@@ -2258,9 +2136,10 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
                        ctx->origin[2], l == 0 ? 1 : 2, ctx->inv0.as<uint32_t>(), ctx->gold[l].as<float4>());
     HIPCHK(hipGetLastError());
     if (l == 0) {
-      // four far-away pad entries behind the last point: the candidate scan reads four
-      // consecutive positions per trip without clamping to the end of the array
-      static const float4 kFar[4] = {{3e18f, 3e18f, 3e18f, 0.f}, {3e18f, 3e18f, 3e18f, 0.f},
+      // eight far-away pad entries behind the last point: the candidate scan reads whole groups of
+      // consecutive positions without clamping to the end of the array
+      static const float4 kFar[8] = {{3e18f, 3e18f, 3e18f, 0.f}, {3e18f, 3e18f, 3e18f, 0.f}, {3e18f, 3e18f, 3e18f, 0.f},
+                                     {3e18f, 3e18f, 3e18f, 0.f}, {3e18f, 3e18f, 3e18f, 0.f}, {3e18f, 3e18f, 3e18f, 0.f},
                                      {3e18f, 3e18f, 3e18f, 0.f}, {3e18f, 3e18f, 3e18f, 0.f}};
       HIPCHK(hipMemcpyAsync(ctx->gold[0].as<float4>() + n, kFar, sizeof(kFar), hipMemcpyHostToDevice, ctx->stream));
     }

@@ -53,13 +53,17 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(ma_params), offsetof(ma_params, tol), offsetof(ma_params, max_corr_dist), (size_t)0);
   printf("%zu %zu %zu %zu\n", sizeof(ma_stats), offsetof(ma_stats, rmse), offsetof(ma_stats, inliers), offsetof(ma_stats, gpu_ms));
   printf("%zu %zu %zu %zu\n", sizeof(ma_grid_info), offsetof(ma_grid_info, n_cells), offsetof(ma_grid_info, origin), offsetof(ma_grid_info, build_ms));
+  printf("%zu %zu %zu %zu\n", sizeof(ma_mem_info), offsetof(ma_mem_info, device_frees), offsetof(ma_mem_info, bytes_live), offsetof(ma_mem_info, bytes_peak));
+  printf("%d %d %d %d\n", MA_COMM_ID_BYTES, MA_ERR_COMM, MA_ERR_NO_MEMORY, MA_VERSION);
   return 0;
 }
 """)
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(prog)], check=True)
     rows = [[int(v) for v in line.split()] for line in subprocess.check_output([str(exe)]).decode().splitlines()]
-    P, S, G = _lib.ma_params, _lib.ma_stats, _lib.ma_grid_info
+    P, S, G, M = _lib.ma_params, _lib.ma_stats, _lib.ma_grid_info, _lib.ma_mem_info
+    assert rows[3] == [C.sizeof(M), M.device_frees.offset, M.bytes_live.offset, M.bytes_peak.offset]
+    assert rows[4][:3] == [_lib.MA_COMM_ID_BYTES, _lib.MA_ERR_COMM, _lib.MA_ERR_NO_MEMORY]
     assert rows[0][:3] == [C.sizeof(P), P.tol.offset, P.max_corr_dist.offset]
     assert rows[1] == [C.sizeof(S), S.rmse.offset, S.inliers.offset, S.gpu_ms.offset]
     assert rows[2] == [C.sizeof(G), G.n_cells.offset, G.origin.offset, G.build_ms.offset]
@@ -71,7 +75,7 @@ int main(void) {
 def test_no_cpu_fallback_without_gpu(lib_built):
     """Without a HIP device the product path must fail loudly, never compute on the CPU."""
     n = C.c_int(0)
-    hip = C.CDLL("libamdhip64.so")
+    hip = C.CDLL("libamdhip64.so.7")   # by soname: the runtime libmapalign is already bound to (system, or PyTorch's bundled copy)
     if hip.hipGetDeviceCount(C.byref(n)) == 0 and n.value > 0:
         pytest.skip("a GPU is present")
     import mapalign

@@ -29,8 +29,8 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
     """north_star: "(R,t) must match the reference CPU path to <= 1e-4 Frobenius on R and
     <= 1 mm on t for identical inputs" — the 1M-point pair, all 50 iterations, tol = 0, gate
     0.10 m.  The oracle runs its 50 KD-tree iterations on the host cores
-    (~1.9 s each on the 256-core GPU box); if this host is much slower, seeds 1 and 2 stop
-    after 20 iterations (still compared at equal iteration count) so the suite stays in budget."""
+    (1.2-3 s each on the 256-core GPU boxes, depending on their load); on a host that needs more
+    than 2 s per iteration, seeds 1 and 2 stop after 20 iterations (still compared at equal iteration count) so the suite stays in budget."""
     gold, comp, R0, t0 = syn.make_pair(seed, 1_000_000)
     engine.set_gold(gold)
     engine.set_source(comp)
@@ -46,7 +46,7 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
         inliers.append(acc[0])
         rmse.append(np.sqrt(acc[16] / acc[0]))
         k += 1
-        if seed > 0 and k == 5 and (time.perf_counter() - t_start) / 5 > 3.5:
+        if seed > 0 and k == 5 and (time.perf_counter() - t_start) / 5 > 2.0:
             iters = 20
     res = engine.icp(iters, 0.0, 0.10, with_trace=True)
     assert res.iterations == iters
@@ -271,7 +271,7 @@ def test_lift_boxes_batch_vs_oracle_and_per_frame_call(engine):
         pc, pv = engine.lift_boxes(boxes[sel], K, T[f], depth[f])
         assert np.array_equal(pv, ov) and np.array_equal(pc[pv], corners[sel][ov])
     # uint16 frames, empty batch, bad frame index
-    d16 = np.clip(depth, 0, 65535).astype(np.uint16)
+    d16 = np.clip(np.nan_to_num(depth), 0, 65535).astype(np.uint16)
     c16, v16 = engine.lift_boxes_batch(boxes, frame, d16, K, T)
     oc, ov = orc.lift_boxes_oracle(boxes[frame == 2], d16[2], K, T[2])
     assert np.array_equal(v16[frame == 2], ov) and np.allclose(c16[frame == 2][ov], oc[ov], atol=1e-9)
