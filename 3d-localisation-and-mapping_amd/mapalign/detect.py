@@ -227,13 +227,13 @@ class Detector:
         det_h, keep_h = det.cpu().numpy(), keep.cpu().numpy()
         preds, j = {}, 0
         for b in range(det_h.shape[0]):
-            rows = []
-            for k in np.nonzero(keep_h[b])[0]:
-                x1, y1, x2, y2, conf, label = det_h[b, k]
-                row = [float(x1), float(y1), float(x2), float(y2), float(conf), int(label)]   # detector.py:155
-                rows.append(lifting.insert_damage_class(row, int(damage[j])))                 # detector.py:126-127
-                j += 1
-            preds[b] = rows
+            sel = det_h[b][keep_h[b]]                     # [k, 6] = x1 y1 x2 y2 conf label   (detector.py:155)
+            k = sel.shape[0]
+            dmg = damage[j:j + k]
+            j += k
+            # detector.py:126-127: bbox.insert(-2, damage) -> [x1, y1, x2, y2, damage_cls, conf, label]
+            preds[b] = [[float(r[0]), float(r[1]), float(r[2]), float(r[3]), int(c), float(r[4]), int(r[5])]
+                        for r, c in zip(sel, dmg)]
         return preds
 
     __call__ = forward
@@ -253,18 +253,19 @@ def lift_batch(engine, predictions, depth_frames, camera_intrinsics, poses, scal
     P = np.asarray(poses, dtype=np.float64)
     T = P if P.shape[1:] == (4, 4) else np.stack([lifting.pose_to_matrix(p[:7]) for p in P])
     size_img = (camera_intrinsics["image_width"], camera_intrinsics["image_height"])
-    boxes, frame_of, owners = [], [], []
-    for f in sorted(predictions):
-        for r, row in enumerate(predictions[f]):
-            boxes.append(lifting.scale_bounding_box(row[:4], size_img, (wd, hd)))
-            frame_of.append(f)
-            owners.append((f, r))
-    if not boxes:
+    frames = [f for f in sorted(predictions) if predictions[f]]
+    if not frames:
         return {}
-    corners, _ = engine.lift_boxes_batch(np.asarray(boxes, dtype=np.float32), np.asarray(frame_of, dtype=np.uint32),
-                                         d, K, T, scale_depth)
-    out = {}
-    for i, (f, r) in enumerate(owners):
-        out.setdefault(f, []).append([corners[i, 0].copy(), corners[i, 1].copy(), corners[i, 2].copy(),
-                                      corners[i, 3].copy()] + list(predictions[f][r][-3:]))
+    counts = [len(predictions[f]) for f in frames]
+    rows = [row for f in frames for row in predictions[f]]
+    # Transforms.scale_bounding_box for every row at once (pose_processor.py:174-178)
+    scale = np.array([wd / size_img[0], hd / size_img[1], wd / size_img[0], hd / size_img[1]], dtype=np.float64)
+    boxes = (np.array([row[:4] for row in rows], dtype=np.float64) * scale).astype(np.float32)
+    frame_of = np.repeat(np.asarray(frames, dtype=np.uint32), counts)
+    corners, _ = engine.lift_boxes_batch(boxes, frame_of, d, K, T, scale_depth)
+    out, i = {}, 0
+    for f, k in zip(frames, counts):
+        out[f] = [[corners[i + r, 0], corners[i + r, 1], corners[i + r, 2], corners[i + r, 3]] + list(predictions[f][r][-3:])
+                  for r in range(k)]
+        i += k
     return out
