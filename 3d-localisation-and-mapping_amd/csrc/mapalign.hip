@@ -844,6 +844,7 @@ __device__ __forceinline__ uint32_t xcd_chunk(const uint32_t b, const Sched& sc,
 __device__ unsigned long long g_wgt[64][4096][2];
 __device__ uint32_t g_wghw[64][4096][2];
 __device__ uint32_t g_wgph[64][4096][4];   // wave 0: ticks from the start to: search begins, 3x3 block done, search done, sums formed
+__device__ unsigned long long g_rs[64][20][5];   // k_reduce_solve, per iteration and workgroup: entry, sum stored, ticket back, 19 sums read, solve done
 #endif
 
 #ifdef MA_NN_WAVES
@@ -1145,10 +1146,12 @@ __global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_
 
 // a5 (final sum) + a6 + a7 in ONE launch: the 19 reducing workgroups of k_reduce19, and the
 // one whose arrival ticket comes back last runs the solve (saves a dependent launch, ~4 us
-// of every iteration).  Hand-off across CUs / XCDs without L2 write-back fences: each sum is
-// stored write-through (agent-scope relaxed atomic store = `sc1`), drained (`vmcnt(0)`),
-// then the same lane takes its ticket with an agent-scope atomic add; the last arriver reads
-// the 19 sums with agent-scope relaxed loads (`sc1`, never L1-served) after its add returned.
+// of every iteration).  Hand-off across CUs / XCDs in the memory-model form: each sum is stored
+// with an agent-scope atomic store, the same lane takes its ticket with an agent-scope ACQ_REL
+// fetch-add (release: the sum is visible before the ticket; acquire: the last arriver sees all
+// nineteen), and the last arriver reads the sums with agent-scope atomic loads.  (Round 1 used
+// relaxed atomics + explicit s_waitcnt, which relied on gfx950's write-through behaviour; the
+// fenced form measured the same: 2.366 vs 2.362 ms per alignment.)
 //
 // One more workgroup (blockIdx kNAcc, beside the sums, not part of the hand-off) ranks the
 // scheduling groups by the cost the search kernel just recorded: order[r] = the group with
@@ -1164,8 +1167,15 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   // tested AFTER the first loads have been issued: every dependent memory round trip of
   // this small kernel is ~1 us of the iteration.
   const int done = st->done;
+#if MA_WGTIMES
+  const int dbg_it = st->iter;
+  if (threadIdx.x == 0 && dbg_it < 64) g_rs[dbg_it][blockIdx.x][0] = wall_clock64();
+#endif
   if (blockIdx.x == kNAcc) {
     rank_groups(G, wg_cost, order, gshift, done);
+#if MA_WGTIMES
+    if (threadIdx.x == 0 && dbg_it < 64) g_rs[dbg_it][blockIdx.x][4] = wall_clock64();
+#endif
     return;
   }
   const int k = blockIdx.x;
@@ -1191,14 +1201,28 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   if (threadIdx.x != 0) return;
   __hip_atomic_store(&acc_out[k], ((red[0] + red[1]) + red[2]) + red[3], __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
+#if MA_WGTIMES
+  if (dbg_it < 64) g_rs[dbg_it][k][1] = wall_clock64();
+#endif
   // memory-model form: release on the ticket, acquire by the last arriver
   const uint32_t arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#if MA_WGTIMES
+  if (dbg_it < 64) g_rs[dbg_it][k][2] = wall_clock64();
+#endif
   if (arrived != (uint32_t)(kNAcc - 1)) return;
   __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   double a[kNAcc];
 #pragma unroll
   for (int t = 0; t < kNAcc; ++t) a[t] = __hip_atomic_load(&acc_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if MA_WGTIMES
+  asm volatile("" :: "v"(a[0]), "v"(a[18]));
+  if (dbg_it < 64) g_rs[dbg_it][k][3] = wall_clock64();
+#endif
   solve_step(a, s0, st, trace, trace_cap, tol, host_done);
+#if MA_WGTIMES
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (dbg_it < 64) g_rs[dbg_it][k][4] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2547,6 +2571,10 @@ int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {
 #if MA_WGTIMES
 int ma_debug_wgphases(ma_ctx* ctx, uint32_t* ph) {
   HIPCHK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_wgph), sizeof(g_wgph)));
+  return MA_OK;
+}
+int ma_debug_rstimes(ma_ctx* ctx, unsigned long long* rs) {
+  HIPCHK(hipMemcpyFromSymbol(rs, HIP_SYMBOL(g_rs), sizeof(g_rs)));
   return MA_OK;
 }
 int ma_debug_wgtimes(ma_ctx* ctx, unsigned long long* times, uint32_t* hw) {

@@ -54,10 +54,17 @@ def bootstrap_comm(aligner, group=None):
     import torch.distributed as dist
 
     world, rank = _world(group)
-    payload = [aligner.comm_unique_id() if rank == 0 else None]
+    payload = [None]
+    if rank == 0:
+        try:
+            payload[0] = aligner.comm_unique_id()
+        except Exception as e:          # the other ranks are about to enter the broadcast: never leave them hanging
+            payload[0] = f"{type(e).__name__}: {e}"       # (a plain string: survives pickling)
     if world > 1:
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(payload, src=src, group=group)
+    if not isinstance(payload[0], (bytes, bytearray)):
+        raise RuntimeError(f"rank 0 could not create the RCCL bootstrap id: {payload[0]}")
     aligner.comm_init(payload[0], world, rank)
     return world, rank
 
