@@ -1242,26 +1242,36 @@ struct Pinhole {
 };
 
 // ONE pass over the depth image: every workgroup loads its 1024 pixels once, counts the valid
-// ones, and obtains the number of valid pixels in front of it by a decoupled look-back over the
-// status words of its predecessors (aggregate / inclusive prefix, published write-through at
-// agent scope) instead of a separate counting pass + scan + second read of the image.
-// Forward progress: workgroups take their logical index from an atomic ticket, so every
-// predecessor a workgroup waits for has already started (dispatch order is not assumed); every
-// spin is bounded and a timeout raises an error word instead of hanging the device.
+// ones, and learns how many valid pixels lie in front of it from the counts its predecessors
+// publish (write-through, agent scope) — no separate counting pass, scan and second read of the
+// image.  Two forms, chosen by the host:
+//   DIRECT  the whole grid is resident at once (<= 8 workgroups per CU), so every predecessor is
+//           running whatever the dispatch order: each workgroup publishes its count and then
+//           sums ALL its predecessors' counts itself, its 256 threads loading them side by side
+//           (<= 8 coherent loads per thread, one memory round trip; O(grid^2) words in total,
+//           2.9 MB for a 1280 x 960 frame).  No dependent chain between workgroups.
+//   CHAINED larger images: decoupled look-back (aggregate / inclusive-prefix status words, 256
+//           predecessors per trip); workgroups take their logical index from an atomic ticket,
+//           so every predecessor a workgroup waits for has already started.
+// Every spin is bounded; a timeout raises an error word instead of hanging the device.
 constexpr unsigned long long kScanAggregate = 1ull << 32, kScanPrefix = 2ull << 32;
 constexpr uint32_t kScanSpinLimit = 1u << 22;
+constexpr uint32_t kDirectMaxBlocks = 2048;     // also bounded by the device's resident capacity (host)
 
-template <typename T>
+template <typename T, bool DIRECT>
 __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ depth, const int width,
                                                       const uint32_t npx, const Pinhole cam,
                                                       uint32_t* __restrict__ ticket /*[0] ticket, [1] total, [2] error*/,
                                                       unsigned long long* __restrict__ status,
                                                       float4* __restrict__ out) {
   __shared__ uint32_t sh_block, sh_prefix;
-  __shared__ uint32_t wsum[kBlock / kWave];
-  if (threadIdx.x == 0) sh_block = atomicAdd(&ticket[0], 1u);
-  __syncthreads();
-  const uint32_t blk = sh_block;
+  __shared__ uint32_t wsum[kBlock / kWave], psum[kBlock / kWave];
+  uint32_t blk = blockIdx.x;
+  if (!DIRECT) {
+    if (threadIdx.x == 0) sh_block = atomicAdd(&ticket[0], 1u);
+    __syncthreads();
+    blk = sh_block;
+  }
   const uint32_t first = blk * kPxPerBlock + threadIdx.x * kPxPerThread;
   double z[kPxPerThread];
   uint32_t cnt = 0;
@@ -1287,7 +1297,44 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
     if (w < wv) wbase += wsum[w];
     total += wsum[w];
   }
-  if (wv == 0) {
+  if (DIRECT) {
+    if (threadIdx.x == 0)
+      __hip_atomic_store(&status[blk], kScanAggregate | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every thread sums its share of the predecessors' counts: predecessors t, t+256, ...
+    uint32_t mine = 0, spins = 0;
+    constexpr int kPer = kDirectMaxBlocks / kBlock;       // <= 8 loads in flight per thread
+    unsigned long long st[kPer];
+    bool pending = true;
+    while (pending) {
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+        const uint32_t idx = threadIdx.x + (uint32_t)j * kBlock;
+        st[j] = idx < blk ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanAggregate;
+      }
+      pending = false;
+      mine = 0;
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+        pending = pending || (uint32_t)(st[j] >> 32) == 0u;
+        mine += (uint32_t)st[j];
+      }
+      if (pending) {
+        if (++spins > kScanSpinLimit) { atomicExch(&ticket[2], 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) mine += __shfl_xor(mine, off, kWave);
+    if (lane == 0) psum[wv] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t prefix = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / kWave; ++w) prefix += psum[w];
+      sh_prefix = prefix;
+      if (blk == gridDim.x - 1) ticket[1] = prefix + total;   // number of valid pixels of the image
+    }
+  } else if (wv == 0) {
     if (lane == 0)
       __hip_atomic_store(&status[blk], (blk == 0 ? kScanPrefix : kScanAggregate) | total, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
@@ -1577,6 +1624,7 @@ struct ma_ctx {
   int* host_done = nullptr;      // pinned host word the solve sets when the loop stops (tol > 0 runs)
   std::vector<hipEvent_t> batch_ev;
   MemStats mem;
+  int n_cus = 256;               // compute units of the device (how many workgroups are resident at once)
   double last_op_ms = 0;         // device time of the last unprojection (ma_last_device_ms)
   bool oom = false;              // a C++ allocation failed inside the last call (no message storage)
   // RCCL communicator of the sharded-source mode (ma_comm_init); opaque here
@@ -1876,12 +1924,20 @@ int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinho
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->keys_a.p, 0, 16, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->keys_b.p, 0, (size_t)nb * 8, ctx->stream));
+  // DIRECT form only while the whole grid is resident at once (its workgroups wait for each
+  // other): the kernel's 86 SGPRs allow 7 workgroups per CU (SGPRs are granted in blocks of 16
+  // plus 16: floor(800 / 112) = 7 wavefronts per SIMD); 6 per CU leaves a margin
+  const bool direct = nb <= std::min<uint32_t>(kDirectMaxBlocks, (uint32_t)ctx->n_cus * 6u);
+  auto launch = [&](auto kern, auto* d) {
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(kBlock), 0, ctx->stream, d, width, npx, cam, ctx->keys_a.as<uint32_t>(),
+                       ctx->keys_b.as<unsigned long long>(), out);
+  };
   if (dtype == 0) {
-    hipLaunchKernelGGL(k_unproject<float>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(), width, npx,
-                       cam, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<unsigned long long>(), out);
+    if (direct) launch(k_unproject<float, true>, ctx->depth_in.as<float>());
+    else launch(k_unproject<float, false>, ctx->depth_in.as<float>());
   } else {
-    hipLaunchKernelGGL(k_unproject<uint16_t>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<uint16_t>(), width,
-                       npx, cam, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<unsigned long long>(), out);
+    if (direct) launch(k_unproject<uint16_t, true>, ctx->depth_in.as<uint16_t>());
+    else launch(k_unproject<uint16_t, false>, ctx->depth_in.as<uint16_t>());
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
@@ -1985,6 +2041,7 @@ int ma_create(int device, ma_ctx** out) {
   if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
   if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   ctx->stream = ctx->own_stream;
+  if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_done), 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
