@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
                                                       const uint32_t npx, const Pinhole cam,
                                                       uint32_t* __restrict__ ticket /*[0] ticket, [1] total, [2] error*/,
                                                       unsigned long long* __restrict__ status,
-                                                      float4* __restrict__ out) {
+                                                      float4* __restrict__ out, const uint32_t epoch) {
   __shared__ uint32_t sh_block, sh_prefix;
   __shared__ uint32_t wsum[kBlock / kWave], psum[kBlock / kWave];
   uint32_t blk = blockIdx.x;
@@ -1298,8 +1298,11 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
     total += wsum[w];
   }
   if (DIRECT) {
+    // status word = (epoch << 32) | count: a word of another call's epoch reads as "not published
+    // yet", so the array needs no clearing between calls (a fill kernel costs ~5 us, a quarter
+    // of this kernel); the host bumps the epoch per call and clears the array when it wraps
     if (threadIdx.x == 0)
-      __hip_atomic_store(&status[blk], kScanAggregate | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&status[blk], ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // every thread sums its share of the predecessors' counts: predecessors t, t+256, ...
     uint32_t mine = 0, spins = 0;
     constexpr int kPer = kDirectMaxBlocks / kBlock;       // <= 8 loads in flight per thread
@@ -1309,17 +1312,18 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
 #pragma unroll
       for (int j = 0; j < kPer; ++j) {
         const uint32_t idx = threadIdx.x + (uint32_t)j * kBlock;
-        st[j] = idx < blk ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kScanAggregate;
+        st[j] = idx < blk ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                          : (unsigned long long)epoch << 32;
       }
       pending = false;
       mine = 0;
 #pragma unroll
       for (int j = 0; j < kPer; ++j) {
-        pending = pending || (uint32_t)(st[j] >> 32) == 0u;
+        pending = pending || (uint32_t)(st[j] >> 32) != epoch;
         mine += (uint32_t)st[j];
       }
       if (pending) {
-        if (++spins > kScanSpinLimit) { atomicExch(&ticket[2], 1u); break; }
+        if (++spins > kScanSpinLimit) { atomicExch(&ticket[2], epoch); break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -1332,7 +1336,7 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
 #pragma unroll
       for (int w = 0; w < kBlock / kWave; ++w) prefix += psum[w];
       sh_prefix = prefix;
-      if (blk == gridDim.x - 1) ticket[1] = prefix + total;   // number of valid pixels of the image
+      if (blk == gridDim.x - 1) { ticket[1] = prefix + total; ticket[3] = epoch; }   // valid pixels of the image, and of which call
     }
   } else if (wv == 0) {
     if (lane == 0)
@@ -1614,6 +1618,10 @@ struct ma_ctx {
 
   // batched box lifting (a10 over many frames)
   DevBuf lift_poses, lift_frames;
+  // single-pass unprojection: ticket / total / error words and the per-workgroup status words
+  DevBuf scan_words, scan_status;
+  uint32_t scan_epoch = 0;
+  bool scan_was_direct = false;
 
   // loop state
   DevBuf state, partials, trace, acc19, ticket, wg_cost, seg_order, nn_idx, nn_d2, nn_tmp, prev;
@@ -1643,7 +1651,7 @@ struct ma_ctx {
   std::vector<DevBuf*> all_bufs() {
     std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &perm0, &inv0, &occ_a, &occ_b,
                               &src, &src_perm, &raw, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
-                              &depth_in, &lift_poses, &lift_frames, &state, &partials, &trace, &acc19, &ticket,
+                              &depth_in, &lift_poses, &lift_frames, &scan_words, &scan_status, &state, &partials, &trace, &acc19, &ticket,
                               &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
     for (int l = 0; l < kLevels; ++l) { v.push_back(&gold[l]); v.push_back(&cstart[l]); }
     return v;
@@ -1919,18 +1927,27 @@ void fill_stats(const DevState& s, double gpu_ms, ma_stats* st) {
 // k_unproject).  *total receives the number of valid pixels; ev0/ev1 bracket the device work.
 int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinhole& cam, float4* out, uint32_t* total) {
   const uint32_t nb = div_up(npx, kPxPerBlock);
-  HIPCHK(ctx->keys_a.ensure(64));
-  HIPCHK(ctx->keys_b.ensure((size_t)nb * 8));
-  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->keys_a.p, 0, 16, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->keys_b.p, 0, (size_t)nb * 8, ctx->stream));
   // DIRECT form only while the whole grid is resident at once (its workgroups wait for each
   // other): the kernel's 86 SGPRs allow 7 workgroups per CU (SGPRs are granted in blocks of 16
   // plus 16: floor(800 / 112) = 7 wavefronts per SIMD); 6 per CU leaves a margin
   const bool direct = nb <= std::min<uint32_t>(kDirectMaxBlocks, (uint32_t)ctx->n_cus * 6u);
+  const void* scan_words_before = ctx->scan_words.p;
+  const void* scan_status_before = ctx->scan_status.p;
+  HIPCHK(ctx->scan_words.ensure(64));
+  HIPCHK(ctx->scan_status.ensure((size_t)nb * 8));
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  // epoch-tagged status words (direct form): cleared only when the buffers are new or the epoch wraps
+  if (!direct || !ctx->scan_was_direct || ctx->scan_words.p != scan_words_before ||
+      ctx->scan_status.p != scan_status_before || ctx->scan_epoch >= 0x7FFFFFF0u) {
+    HIPCHK(hipMemsetAsync(ctx->scan_words.p, 0, 16, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->scan_status.p, 0, ctx->scan_status.cap, ctx->stream));
+    ctx->scan_epoch = 0;
+  }
+  ctx->scan_was_direct = direct;      // (the chained form leaves flag words behind that an epoch could collide with)
+  const uint32_t epoch = ++ctx->scan_epoch;
   auto launch = [&](auto kern, auto* d) {
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(kBlock), 0, ctx->stream, d, width, npx, cam, ctx->keys_a.as<uint32_t>(),
-                       ctx->keys_b.as<unsigned long long>(), out);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(kBlock), 0, ctx->stream, d, width, npx, cam, ctx->scan_words.as<uint32_t>(),
+                       ctx->scan_status.as<unsigned long long>(), out, epoch);
   };
   if (dtype == 0) {
     if (direct) launch(k_unproject<float, true>, ctx->depth_in.as<float>());
@@ -1942,12 +1959,14 @@ int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinho
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   uint32_t h[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(h, ctx->keys_a.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(h, ctx->scan_words.p, 16, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->last_op_ms = ms;
-  if (h[2]) return ctx->fail(MA_ERR_HIP, "k_unproject: look-back timed out (a predecessor workgroup never published its count)");
+  if (h[2] != 0u && (!direct || h[2] == epoch))
+    return ctx->fail(MA_ERR_HIP, "k_unproject: timed out waiting for a predecessor workgroup's count");
+  if (direct && h[3] != epoch) return ctx->fail(MA_ERR_HIP, "k_unproject: the last workgroup did not report a total");
   *total = h[1];
   return MA_OK;
 }

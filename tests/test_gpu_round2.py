@@ -350,3 +350,34 @@ def test_coarse_stage_uses_trajectories_on_a_half_turn_symmetric_shell(lib_built
     ts = np.array(info["trajectory_scores"])
     assert ts.min() < 0.1 and np.sort(ts)[1] > 0.4
     mapalign.release_cached_engines()
+
+
+# ----------------------------------------------------------------------------- a8, both scan forms
+def test_unprojection_direct_and_chained_forms_and_switching(engine):
+    """k_unproject reads the depth image once.  Frames whose grid is resident at once use the
+    direct form (epoch-tagged status words, no clearing between calls); larger images use the
+    chained look-back form.  Both must give the oracle's points in row-major pixel order, and
+    switching between them (stale words of the other form in the status array) must be safe."""
+    gold, _, _, _ = syn.make_pair(2, 50_000)
+    engine.set_gold(gold)
+    rng = np.random.default_rng(11)
+    K_small, K_big = (300.0, 301.0, 160.0, 120.0), (1500.0, 1500.0, 1024.0, 600.0)
+    T = syn.default_camera_pose()
+
+    def frame(w, h, holes):
+        d = rng.uniform(800.0, 9000.0, size=(h, w)).astype(np.float32)
+        d[rng.random((h, w)) < holes] = 0.0
+        return d
+
+    small = [frame(320, 240, 0.3) for _ in range(3)]          # 75 workgroups: direct form
+    big = frame(2048, 1200, 0.55)                             # 2400 workgroups: chained form
+    for depth, K in ((small[0], K_small), (small[1], K_small), (big, K_big), (small[2], K_small), (big, K_big), (small[0], K_small)):
+        n = engine.set_source_from_depth(depth, K, T, 1000.0)
+        ref, mask = orc.unproject_oracle(depth, K, T, 1000.0)
+        assert n == int(mask.sum()) == len(ref)
+        got = engine.get_source()
+        assert np.abs(got - ref).max() < 2e-5                  # fp32 storage of coordinates up to ~10 m
+    # an image without any valid pixel is an error, not an empty cloud
+    with pytest.raises(mapalign.MapAlignError) as e:
+        engine.set_source_from_depth(np.zeros((240, 320), np.float32), K_small, T, 1000.0)
+    assert e.value.status == _lib.MA_ERR_EMPTY
