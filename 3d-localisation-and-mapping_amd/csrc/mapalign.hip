@@ -2076,7 +2076,10 @@ int ma_destroy(ma_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm) comm_destroy(ctx);
-  for (DevBuf* b : ctx->all_bufs()) b->release();
+  try {
+    for (DevBuf* b : ctx->all_bufs()) b->release();
+  } catch (...) {   // (the buffer list is a std::vector: never let its allocation failure cross the ABI)
+  }
   if (ctx->host_done) (void)hipHostFree(ctx->host_done);
   for (hipEvent_t e : ctx->batch_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
