@@ -189,6 +189,65 @@ __global__ __launch_bounds__(kBlock) void k_cell_keys(const float* __restrict__ 
   if (counts) atomicAdd(&counts[c], 1u);
 }
 
+// Occupancy probes of the cell-edge / grid-phase search (13 per gold map): only WHETHER a cell
+// holds a point matters, so the probe marks a byte per cell with plain stores (idempotent: no
+// atomics, a quarter of the table bytes of a u32 histogram) and counts the marks 16 at a time.
+// (The histogram kernels took 55 + 28 us per probe at 1M points, a third of the grid build.)
+__global__ __launch_bounds__(kBlock) void k_mark_cells(const float* __restrict__ xyz, uint32_t n, double o0, double o1,
+                                                       double o2, GridP g, uint8_t* __restrict__ mark) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float x = (float)((double)xyz[3 * (size_t)i] - o0);
+  const float y = (float)((double)xyz[3 * (size_t)i + 1] - o1);
+  const float z = (float)((double)xyz[3 * (size_t)i + 2] - o2);
+  mark[cell_of(x, y, z, g)] = 1;
+}
+
+// marks: 0 / 1 bytes, padded with zeros to a multiple of 16
+__global__ __launch_bounds__(kBlock) void k_count_marks(const uint4* __restrict__ mark16, uint32_t n16,
+                                                        unsigned long long* __restrict__ out) {
+  uint32_t c = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n16; i += gridDim.x * kBlock) {
+    const uint4 v = mark16[i];
+    c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
+  __shared__ uint32_t part[kBlock / kWave];
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) t += part[w];
+    if (t) atomicAdd(out, (unsigned long long)t);
+  }
+}
+
+// Coarser levels are built on demand from the level-0 copy (already centred, float4):
+// cell ids of level l (+ histogram), and the gather that keeps .w = position in level 0.
+__global__ __launch_bounds__(kBlock) void k_cell_keys4(const float4* __restrict__ pts, uint32_t n, GridP g,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                       uint32_t* __restrict__ counts) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  const uint32_t c = cell_of(p.x, p.y, p.z, g);
+  keys[i] = c;
+  vals[i] = i;
+  atomicAdd(&counts[c], 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather4(const float4* __restrict__ gold0, const uint32_t* __restrict__ perm,
+                                                    uint32_t n, float4* __restrict__ out) {
+  const uint32_t pos = blockIdx.x * kBlock + threadIdx.x;
+  if (pos >= n) return;
+  const uint32_t j = perm[pos];
+  float4 v = gold0[j];
+  v.w = __uint_as_float(j);
+  out[pos] = v;
+}
+
 __global__ __launch_bounds__(kBlock) void k_count_occupied(const uint32_t* __restrict__ counts,
                                                            uint32_t ncells,
                                                            unsigned long long* __restrict__ out) {
@@ -232,8 +291,8 @@ __global__ __launch_bounds__(kBlock) void k_count_bad_weights(const float* __res
 }
 
 // sorted[pos] = centred(xyz[perm[pos]]).  w_mode 0: .w = weight (source cloud);
-// 1: .w = pos (level 0 of the gold map: its own position); 2: .w = lut[orig] (coarser
-// levels: the point's position in level 0).
+// 1: .w = pos (level 0 of the gold map: its own position).  (The coarser levels are gathered
+// from level 0 by k_gather4.)
 __global__ __launch_bounds__(kBlock) void k_gather(const float* __restrict__ xyz,
                                                    const float* __restrict__ weights,
                                                    const uint32_t* __restrict__ perm, uint32_t n,
@@ -248,16 +307,8 @@ __global__ __launch_bounds__(kBlock) void k_gather(const float* __restrict__ xyz
   v.y = (float)((double)xyz[3 * (size_t)i + 1] - o1);
   v.z = (float)((double)xyz[3 * (size_t)i + 2] - o2);
   if (w_mode == 0) v.w = weights ? weights[i] : 1.0f;
-  else if (w_mode == 1) v.w = __uint_as_float(pos);
-  else v.w = __uint_as_float(lut[i]);
+  else v.w = __uint_as_float(pos);
   out[pos] = v;
-}
-
-// inv[perm[pos]] = pos
-__global__ __launch_bounds__(kBlock) void k_invert_perm(const uint32_t* __restrict__ perm, uint32_t n,
-                                                        uint32_t* __restrict__ inv) {
-  const uint32_t pos = blockIdx.x * kBlock + threadIdx.x;
-  if (pos < n) inv[perm[pos]] = pos;
 }
 
 // Chebyshev distance (in cells, capped at kOccCap) from every level-0 cell to the nearest
@@ -1594,8 +1645,12 @@ struct ma_ctx {
   GridP grid{};                 // level 0 (finest)
   uint64_t ncells = 0, noccupied = 0;
   double build_ms = 0;
-  DevBuf gold[kLevels], cstart[kLevels], perm0, inv0, occ_a, occ_b;
+  DevBuf gold[kLevels], cstart[kLevels], perm0, occ_a, occ_b;
   LevelSet levels{};
+  // levels 1..3 serve only search spheres wider than 6 level-0 cells (ungated or widely gated
+  // runs): they are built when such a run first asks for them, not with every gold map
+  bool coarse_built = false;
+  float grid_lo[3] = {0, 0, 0}, grid_hi[3] = {0, 0, 0};   // box of the grid (after the phase shift)
 
   // source cloud
   bool have_src = false;
@@ -1649,7 +1704,7 @@ struct ma_ctx {
     return code;
   }
   std::vector<DevBuf*> all_bufs() {
-    std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &perm0, &inv0, &occ_a, &occ_b,
+    std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &perm0, &occ_a, &occ_b,
                               &src, &src_perm, &raw, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
                               &depth_in, &lift_poses, &lift_frames, &scan_words, &scan_status, &state, &partials, &trace, &acc19, &ticket,
                               &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
@@ -1797,19 +1852,16 @@ int sort_by_cell(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, co
 int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, const double o[3],
                    uint64_t* out) {
   const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
-  HIPCHK(ctx->cstart[0].ensure((ncells + 8) * 4));
-  HIPCHK(hipMemsetAsync(ctx->cstart[0].p, 0, (ncells + 1) * 4, ctx->stream));
-  HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
-  HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
-  hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0],
-                     o[1], o[2], g, 0, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
-                     ctx->cstart[0].as<uint32_t>());
-  HIPCHK(hipGetLastError());
+  const uint64_t n16 = (ncells + 15) / 16;
+  HIPCHK(ctx->occ_b.ensure(n16 * 16));
   HIPCHK(ctx->misc.ensure(64));
+  HIPCHK(hipMemsetAsync(ctx->occ_b.p, 0, n16 * 16, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 8, ctx->stream));
-  hipLaunchKernelGGL(k_count_occupied, dim3(std::min<uint32_t>(div_up(ncells, kBlock), 2048)), dim3(kBlock), 0,
-                     ctx->stream, ctx->cstart[0].as<uint32_t>(), (uint32_t)ncells,
-                     ctx->misc.as<unsigned long long>());
+  hipLaunchKernelGGL(k_mark_cells, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0], o[1], o[2], g,
+                     ctx->occ_b.as<uint8_t>());
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(k_count_marks, dim3(std::min<uint32_t>(div_up(n16, kBlock), 2048)), dim3(kBlock), 0, ctx->stream,
+                     ctx->occ_b.as<uint4>(), (uint32_t)n16, ctx->misc.as<unsigned long long>());
   HIPCHK(hipGetLastError());
   unsigned long long h = 0;
   HIPCHK(hipMemcpyAsync(&h, ctx->misc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1983,6 +2035,60 @@ Pinhole make_pinhole(const float K[4], const double T[16], float depth_scale, co
     cam.T[4 * r + 3] = T[4 * r + 3] - origin[r];
   }
   return cam;
+}
+
+// Levels 1..3 (cell edges 2c, 4c, 8c over the same box) from the level-0 copy.  Stable sort by
+// cell id of level l: inside a cell the points keep their level-0 order.
+int build_coarse_levels(ma_ctx* ctx) {
+  const uint32_t n = ctx->m;
+  DevBuf& hist = ctx->misc;
+  for (int l = 1; l < kLevels; ++l) {
+    const GridP g = make_grid(ctx->grid_lo, ctx->grid_hi, ctx->origin, ctx->grid.c * (float)(1 << l));
+    const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
+    HIPCHK(ctx->cstart[l].ensure((ncells + 8) * 4));
+    HIPCHK(hist.ensure((ncells + 8) * 4 + 64));
+    uint32_t* d_hist = reinterpret_cast<uint32_t*>(static_cast<char*>(hist.p) + 64);
+    HIPCHK(hipMemsetAsync(hist.p, 0, (ncells + 8) * 4 + 64, ctx->stream));
+    HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
+    HIPCHK(ctx->keys_b.ensure((size_t)n * 4));
+    HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
+    HIPCHK(ctx->vals_b.ensure((size_t)n * 4));
+    hipLaunchKernelGGL(k_cell_keys4, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->gold[0].as<float4>(), n, g,
+                       ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), d_hist);
+    HIPCHK(hipGetLastError());
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < ncells) ++bits;
+    size_t tmp_bytes = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                                              ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), (int)n, 0, bits, ctx->stream));
+    HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
+                                              ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), (int)n, 0, bits, ctx->stream));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), (int)(ncells + 8), ctx->stream));
+    HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), (int)(ncells + 8), ctx->stream));
+    HIPCHK(ctx->gold[l].ensure(((size_t)n + 8) * sizeof(float4)));
+    hipLaunchKernelGGL(k_gather4, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->gold[0].as<float4>(),
+                       ctx->vals_b.as<uint32_t>(), n, ctx->gold[l].as<float4>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // hist / sort scratch is reused by the next level
+    LevelSet& L = ctx->levels;
+    L.gold[l] = ctx->gold[l].as<float4>();
+    L.cs[l] = ctx->cstart[l].as<uint32_t>();
+    L.c[l] = g.c; L.inv_c[l] = g.inv_c;
+    L.nx[l] = g.nx; L.ny[l] = g.ny; L.nz[l] = g.nz;
+  }
+  ctx->coarse_built = true;
+  return MA_OK;
+}
+
+// A search sphere wider than 6 level-0 cells leaves the wavefront-cooperative level-0 search for
+// the multi-level one (wave_search: kWalk): only runs gated that widely, or ungated, need levels 1..3.
+int ensure_levels_for(ma_ctx* ctx, double max_corr_dist) {
+  if (ctx->coarse_built || !ctx->have_gold) return MA_OK;
+  const double reach = 6.0 * (double)ctx->grid.c;
+  if (std::isfinite(max_corr_dist) && max_corr_dist <= reach) return MA_OK;
+  return build_coarse_levels(ctx);
 }
 
 // No C++ exception crosses the C ABI: std::vector / std::string allocations inside the entry
@@ -2204,7 +2310,7 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   LevelSet L{};
   GridP g0{};
   uint64_t ncells0 = 0;
-  for (int l = 0; l < kLevels; ++l) {
+  for (int l = 0; l < 1; ++l) {     // level 0 now; levels 1..3 in build_coarse_levels, on demand
     const float cl = c * (float)(1 << l);
     const GridP g = make_grid(lo, hi, ctx->origin, cl);
     const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
@@ -2228,15 +2334,11 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
       HIPCHK(hipGetLastError());
       HIPCHK(hipMemcpyAsync(&ctx->noccupied, hist.p, 8, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx->perm0.ensure((size_t)n * 4));
-      HIPCHK(ctx->inv0.ensure((size_t)n * 4));
       HIPCHK(hipMemcpyAsync(ctx->perm0.p, ctx->vals_b.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      hipLaunchKernelGGL(k_invert_perm, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream,
-                         ctx->perm0.as<uint32_t>(), n, ctx->inv0.as<uint32_t>());
-      HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->raw.as<float>(),
                        (const float*)nullptr, ctx->vals_b.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1],
-                       ctx->origin[2], l == 0 ? 1 : 2, ctx->inv0.as<uint32_t>(), ctx->gold[l].as<float4>());
+                       ctx->origin[2], 1, (const uint32_t*)nullptr, ctx->gold[l].as<float4>());
     HIPCHK(hipGetLastError());
     if (l == 0) {
       // eight far-away pad entries behind the last point: the candidate scan reads whole groups of
@@ -2254,6 +2356,15 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     L.ox = g.ox; L.oy = g.oy; L.oz = g.oz;
     if (l == 0) L.delta = g.delta;
   }
+  // Until the coarser levels exist their slots alias level 0: a search that reached them would
+  // still be exact (every level holds every point), only slower.
+  for (int l = 1; l < kLevels; ++l) {
+    L.gold[l] = L.gold[0]; L.cs[l] = L.cs[0];
+    L.c[l] = L.c[0]; L.inv_c[l] = L.inv_c[0];
+    L.nx[l] = L.nx[0]; L.ny[l] = L.ny[0]; L.nz[l] = L.nz[0];
+  }
+  ctx->coarse_built = false;
+  for (int a = 0; a < 3; ++a) { ctx->grid_lo[a] = lo[a]; ctx->grid_hi[a] = hi[a]; }
   // distance-to-occupied table of level 0 (ping-pong relaxations; the result ends in occ_a)
   {
     const uint32_t nc = (uint32_t)ncells0;
@@ -2564,6 +2675,7 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   if (!T_out) return ctx->fail(MA_ERR_INVALID, "T_out is NULL");
   if (init) for (int i = 0; i < 16; ++i) if (!std::isfinite(init[i])) return ctx->fail(MA_ERR_INVALID, "non-finite init");
   HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ensure_levels_for(ctx, params->max_corr_dist))) return rc;
   if ((rc = ensure_loop_buffers(ctx, params->max_iter))) return rc;
   if ((rc = upload_state(ctx, init))) return rc;
   const float best2 = open_gate2(params->max_corr_dist);
@@ -2677,6 +2789,7 @@ int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16], dou
   if ((rc = check_params(ctx, params))) return rc;
   if ((rc = need_ready(ctx))) return rc;
   HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ensure_levels_for(ctx, params->max_corr_dist))) return rc;
   if ((rc = upload_state(ctx, T_in))) return rc;
   if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
   if ((rc = launch_reduce(ctx))) return rc;
@@ -2700,6 +2813,7 @@ int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_o
   if (!(max_corr_dist > 0.0)) return ctx->fail(MA_ERR_INVALID, "max_corr_dist must be > 0 (or +inf)");
   if (!idx_out && !d2_out) return ctx->fail(MA_ERR_INVALID, "no output requested");
   HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ensure_levels_for(ctx, max_corr_dist))) return rc;
   if ((rc = upload_state(ctx, T))) return rc;
   const size_t n = ctx->n;
   HIPCHK(ctx->nn_idx.ensure(n * 4));
@@ -2758,6 +2872,7 @@ int ma_step_accumulate(ma_ctx* ctx, const ma_params* params, void* acc_dev) {
   if (!ctx->state_valid) return ctx->fail(MA_ERR_STATE, "no valid stepping state: call ma_state_set after the clouds are set (a new gold map or source cloud invalidates it)");
   if (!acc_dev) return ctx->fail(MA_ERR_INVALID, "acc_dev is NULL");
   HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ensure_levels_for(ctx, params->max_corr_dist))) return rc;
   if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
   if ((rc = launch_reduce(ctx))) return rc;
   HIPCHK(hipMemcpyAsync(acc_dev, ctx->acc19.p, MA_ACC_LEN * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -2940,6 +3055,7 @@ int ma_icp_sharded(ma_ctx* ctx, const ma_params* params, const double init[16], 
   if (!T_out) return ctx->fail(MA_ERR_INVALID, "T_out is NULL");
   if (init) for (int i = 0; i < 16; ++i) if (!std::isfinite(init[i])) return ctx->fail(MA_ERR_INVALID, "non-finite init");
   HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ensure_levels_for(ctx, params->max_corr_dist))) return rc;
   if ((rc = ensure_loop_buffers(ctx, params->max_iter))) return rc;
   if ((rc = upload_state(ctx, init))) return rc;
   const float best2 = open_gate2(params->max_corr_dist);
