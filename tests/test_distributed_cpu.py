@@ -78,6 +78,51 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+class _FakeAligner:
+    """Stands in for MapAligner in the RCCL bootstrap (no GPU here): records what it is told."""
+
+    def __init__(self, fail):
+        self.fail, self.joined = fail, None
+
+    def comm_unique_id(self):
+        if self.fail:
+            raise RuntimeError("librccl could not be loaded")
+        return bytes(range(128))
+
+    def comm_init(self, uid, n_ranks, rank):
+        self.joined = (bytes(uid), n_ranks, rank)
+
+
+def _bootstrap_worker(rank, world, port, out_dir):
+    for p in (PKG, ROOT):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapalign import dist as mdist
+
+    ok = _FakeAligner(fail=False)
+    w, r = mdist.bootstrap_comm(ok)
+    bad = _FakeAligner(fail=True)
+    try:
+        mdist.bootstrap_comm(bad)
+        raised = ""
+    except RuntimeError as e:          # EVERY rank must get here: nobody may be left waiting in the broadcast
+        raised = str(e)
+    np.savez(os.path.join(out_dir, f"boot{rank}.npz"), w=w, r=r, uid=np.frombuffer(ok.joined[0], np.uint8),
+             n=ok.joined[1], k=ok.joined[2], raised=raised, bad_joined=bad.joined is not None)
+    dist.destroy_process_group()
+
+
+def test_world2_rccl_bootstrap_id_travels_and_failures_reach_every_rank(tmp_path):
+    world = 2
+    mp.spawn(_bootstrap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        z = np.load(tmp_path / f"boot{rank}.npz")
+        assert (int(z["w"]), int(z["r"]), int(z["n"]), int(z["k"])) == (2, rank, 2, rank)
+        assert np.array_equal(z["uid"], np.arange(128, dtype=np.uint8))      # rank 0's id reached this rank
+        assert "librccl could not be loaded" in str(z["raised"]) and not bool(z["bad_joined"])
+
+
 def _free_port():
     import socket
     s = socket.socket()
