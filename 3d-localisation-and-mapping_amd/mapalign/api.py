@@ -53,7 +53,7 @@ class GoldMap:
     """A gold ("base") map uploaded and indexed once, aligned against many times.
 
     ``align(GoldMap(gold), scan)`` skips the upload and the grid build of the gold map
-    (1.5 ms for 1M points, plus its upload) on every call after the first.  Owns its own context."""
+    (1.2 ms for 1M points, plus its upload) on every call after the first.  Owns its own context."""
 
     def __init__(self, gold_cloud, cell=0.0, device=0):
         self.engine = MapAligner(device)
