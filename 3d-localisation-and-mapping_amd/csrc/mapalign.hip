@@ -2239,7 +2239,7 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
   const uint32_t n = (uint32_t)m;
   HIPCHK(ctx->raw.ensure((size_t)n * 12));
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyDefault, ctx->stream));   // host OR device memory (include/mapalign.h)
   return build_gold_from_raw(ctx, n, cell);
   });
 }
@@ -2428,11 +2428,11 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
   ctx->state_valid = false;
   const uint32_t n = (uint32_t)n64;
   HIPCHK(ctx->raw.ensure((size_t)n * 12));
-  HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyDefault, ctx->stream));   // host OR device memory (include/mapalign.h)
   const float* d_w = nullptr;
   if (weights) {
     HIPCHK(ctx->wts.ensure((size_t)n * 4));
-    HIPCHK(hipMemcpyAsync(ctx->wts.p, weights, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->wts.p, weights, (size_t)n * 4, hipMemcpyDefault, ctx->stream));
     d_w = ctx->wts.as<float>();
     HIPCHK(ctx->misc.ensure(64));
     HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 8, ctx->stream));
@@ -2484,7 +2484,7 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   const uint32_t npx = (uint32_t)((uint64_t)width * height);
   const size_t esz = dtype == 0 ? 4 : 2;
   HIPCHK(ctx->depth_in.ensure((size_t)npx * esz));
-  HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, (size_t)npx * esz, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, (size_t)npx * esz, hipMemcpyDefault, ctx->stream));
   ctx->depth_w = width; ctx->depth_h = height; ctx->depth_dtype = dtype;
   const Pinhole cam = make_pinhole(K, T, depth_scale, ctx->origin);
   HIPCHK(ctx->src.ensure((size_t)npx * sizeof(float4)));
@@ -2534,7 +2534,7 @@ int ma_map_add_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int h
   }
   const size_t esz = dtype == 0 ? 4 : 2;
   HIPCHK(ctx->depth_in.ensure((size_t)npx * esz));
-  HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, (size_t)npx * esz, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, (size_t)npx * esz, hipMemcpyDefault, ctx->stream));
   ctx->depth_w = width; ctx->depth_h = height; ctx->depth_dtype = dtype;
   const Pinhole cam = make_pinhole(K, T, depth_scale, ctx->map_origin);
   uint32_t total = 0;
@@ -2623,7 +2623,7 @@ int ma_lift_boxes(ma_ctx* ctx, const void* depth, int dtype, int width, int heig
     if (width <= 0 || height <= 0 || (uint64_t)width * height >= 0xFFFFFFFEull) return ctx->fail(MA_ERR_INVALID, "bad image size");
     const size_t bytes = (size_t)width * height * (dtype == 0 ? 4 : 2);
     HIPCHK(ctx->depth_in.ensure(bytes));
-    HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->depth_in.p, depth, bytes, hipMemcpyDefault, ctx->stream));
     ctx->depth_w = width; ctx->depth_h = height; ctx->depth_dtype = dtype;
   } else if (ctx->depth_dtype < 0) {
     return ctx->fail(MA_ERR_STATE, "no depth frame uploaded yet");
@@ -2944,7 +2944,7 @@ int ma_lift_boxes_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int wi
   HIPCHK(ctx->raw.ensure((size_t)n_boxes * 16));
   HIPCHK(ctx->misc.ensure((size_t)nc * 24 + nc));
   // ONE upload of the whole batch of frames, one of the poses + frame indices, one of the boxes
-  HIPCHK(hipMemcpyAsync(ctx->lift_frames.p, depth_frames, frame_bytes * n_frames, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->lift_frames.p, depth_frames, frame_bytes * n_frames, hipMemcpyDefault, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->lift_poses.p, poses.data(), poses.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   uint32_t* d_frame = reinterpret_cast<uint32_t*>(ctx->lift_poses.as<double>() + poses.size());
   HIPCHK(hipMemcpyAsync(d_frame, box_frame, n_boxes * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -42,6 +42,37 @@ def _check_cloud(a, name):
     return a
 
 
+def _device_array(a, name, device, shape_tail, dtypes=("<f4",)):
+    """``a`` if it is an array already in GPU memory (a torch CUDA tensor, or any object with
+    ``__cuda_array_interface__``) -> ``(pointer, shape, typestr, keepalive)``; ``None`` for host
+    arrays.  The array must be C-contiguous, on ``device``, and complete: for a torch tensor the
+    producing stream is synchronised here; other producers synchronise themselves (or share
+    the context's stream through :meth:`MapAligner.set_stream`)."""
+    keep = a
+    if type(a).__module__.startswith("torch") and hasattr(a, "is_cuda"):
+        if not a.is_cuda:
+            return None
+        import torch
+        if a.device.index != device:
+            raise ValueError(f"{name} lives on {a.device}, the context on device {device}")
+        a = a.detach()
+        if a.is_floating_point() and a.dtype != torch.float32:
+            a = a.to(torch.float32)
+        keep = a = a.contiguous()
+        torch.cuda.current_stream(a.device).synchronize()
+    iface = getattr(a, "__cuda_array_interface__", None)
+    if iface is None:
+        return None
+    shape, typestr = tuple(iface["shape"]), iface["typestr"]
+    if iface.get("strides") is not None:
+        raise ValueError(f"{name} must be C-contiguous in device memory")
+    if typestr not in dtypes:
+        raise ValueError(f"{name} in device memory must have dtype {' or '.join(dtypes)}, got {typestr}")
+    if shape_tail is not None and (len(shape) != 1 + len(shape_tail) or shape[1:] != shape_tail):
+        raise ValueError(f"{name} must have shape [N{''.join(',%d' % d for d in shape_tail)}], got {shape}")
+    return int(iface["data"][0]), shape, typestr, keep
+
+
 def _cloud(a, name, shift=None):
     """[N,3] array-like -> contiguous float32, after subtracting the host-side shift in fp64."""
     a = _check_cloud(a, name)
@@ -96,6 +127,27 @@ class AlignResult:
     @property
     def t(self):
         return self.T[:3, 3].copy()
+
+
+def _depth_image(depth, device):
+    """2-D depth image (host array-like, or float32 / uint16 in this GPU's memory) ->
+    ``(pointer, dtype code, width, height, keepalive)``; dtype code 0 = float32, 1 = uint16."""
+    dev = _device_array(depth, "depth", device, None, ("<f4", "<u2"))
+    if dev is not None:
+        ptr, shape, typestr, keep = dev
+        if len(shape) != 2:
+            raise ValueError("depth must be a 2-D image")
+        return C.c_void_p(ptr), 1 if typestr == "<u2" else 0, shape[1], shape[0], keep
+    d = np.asarray(depth)
+    if d.ndim != 2:
+        raise ValueError("depth must be a 2-D image")
+    if d.dtype == np.uint16:
+        dtype = 1
+    else:
+        d = d.astype(np.float32, copy=False)
+        dtype = 0
+    d = np.ascontiguousarray(d)
+    return d.ctypes.data_as(C.c_void_p), dtype, d.shape[1], d.shape[0], d
 
 
 class MapAligner:
@@ -158,6 +210,16 @@ class MapAligner:
 
     # -- clouds ---------------------------------------------------------------------
     def set_gold(self, gold_cloud, cell=0.0):
+        """``gold_cloud``: [M,3] host array-like, or a float32 array already in this GPU's memory
+        (torch CUDA tensor / ``__cuda_array_interface__``) — then nothing crosses PCIe."""
+        dev = _device_array(gold_cloud, "gold_cloud", self.device, (3,))
+        if dev is not None:
+            ptr, shape, _, _keep = dev
+            self._shift = np.zeros(3)
+            self._chk(self._lib.ma_set_gold(self._ctx, C.cast(C.c_void_p(ptr), C.POINTER(C.c_float)), shape[0], float(cell)))
+            self.n_gold = shape[0]
+            self.n_source = 0
+            return self.grid_info()
         raw = _check_cloud(gold_cloud, "gold_cloud")
         self._shift = np.zeros(3)
         if raw.shape[0] and raw.dtype != np.float32:
@@ -178,35 +240,42 @@ class MapAligner:
                 "build_ms": float(gi.build_ms)}
 
     def set_source(self, comparison_cloud, weights=None):
-        s = _cloud(comparison_cloud, "comparison_cloud", self._shift)
-        w = None
+        """``comparison_cloud`` / ``weights``: host array-likes or float32 arrays in this GPU's
+        memory (as in :meth:`set_gold`; a device cloud needs a gold map without a host-side
+        large-coordinate shift, i.e. one set from fp32 or device data)."""
+        fp = C.POINTER(C.c_float)
+        dev = _device_array(comparison_cloud, "comparison_cloud", self.device, (3,))
+        if dev is not None:
+            if np.any(self._shift != 0.0):
+                raise ValueError("a device-resident comparison cloud cannot be combined with a gold map that was "
+                                 "shifted on the host (coordinates above %g m given in fp64)" % LARGE_COORDINATE_M)
+            xyz_p, n, keep = C.cast(C.c_void_p(dev[0]), fp), dev[1][0], dev[3]
+        else:
+            s = keep = _cloud(comparison_cloud, "comparison_cloud", self._shift)
+            xyz_p, n = s.ctypes.data_as(fp), s.shape[0]
+        w_p = None
         if weights is not None:
-            w = np.ascontiguousarray(weights, dtype=np.float32).reshape(-1)
-            if w.shape[0] != s.shape[0]:
+            wdev = _device_array(weights, "weights", self.device, ())
+            if wdev is not None:
+                w_p, nw, keep_w = C.cast(C.c_void_p(wdev[0]), fp), wdev[1][0], wdev[3]
+            else:
+                w = keep_w = np.ascontiguousarray(weights, dtype=np.float32).reshape(-1)
+                w_p, nw = w.ctypes.data_as(fp), w.shape[0]
+            if nw != n:
                 raise ValueError("weights must have one entry per comparison point")
-        self._chk(self._lib.ma_set_source(self._ctx, s.ctypes.data_as(C.POINTER(C.c_float)),
-                                          None if w is None else w.ctypes.data_as(C.POINTER(C.c_float)),
-                                          s.shape[0]))
-        self.n_source = s.shape[0]
+        self._chk(self._lib.ma_set_source(self._ctx, xyz_p, w_p, n))
+        self.n_source = n
 
     def set_source_from_depth(self, depth, K, T_cam_to_world, depth_scale=1000.0):
         """Fused depth -> world unprojection into the source buffer (row a8).  Returns #valid pixels."""
-        d = np.asarray(depth)
-        if d.ndim != 2:
-            raise ValueError("depth must be a 2-D image")
-        if d.dtype == np.uint16:
-            dtype = 1
-        else:
-            d = d.astype(np.float32, copy=False)
-            dtype = 0
-        d = np.ascontiguousarray(d)
+        d_p, dtype, width, height, _keep = _depth_image(depth, self.device)
         Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
         T = np.array(T_cam_to_world, dtype=np.float64).reshape(4, 4)
         T[:3, 3] -= self._shift
         T = np.ascontiguousarray(T)
         nv = C.c_uint64(0)
         self._chk(self._lib.ma_set_source_from_depth(
-            self._ctx, d.ctypes.data_as(C.c_void_p), dtype, d.shape[1], d.shape[0],
+            self._ctx, d_p, dtype, width, height,
             Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T), float(depth_scale), C.byref(nv)))
         self.n_source = int(nv.value)
         return self.n_source
@@ -217,11 +286,7 @@ class MapAligner:
         self._map_shift = None
 
     def map_add_depth(self, depth, K, T_cam_to_world, depth_scale=1000.0):
-        d = np.asarray(depth)
-        if d.ndim != 2:
-            raise ValueError("depth must be a 2-D image")
-        dtype = 1 if d.dtype == np.uint16 else 0
-        d = np.ascontiguousarray(d if dtype == 1 else d.astype(np.float32, copy=False))
+        d_p, dtype, width, height, _keep = _depth_image(depth, self.device)
         Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
         T = np.array(T_cam_to_world, dtype=np.float64).reshape(4, 4)
         if self._map_shift is None:      # georeferenced poses: integer-metre host shift, as for clouds
@@ -230,7 +295,7 @@ class MapAligner:
         T[:3, 3] -= self._map_shift
         T = np.ascontiguousarray(T)
         nv = C.c_uint64(0)
-        self._chk(self._lib.ma_map_add_depth(self._ctx, d.ctypes.data_as(C.c_void_p), dtype, d.shape[1], d.shape[0],
+        self._chk(self._lib.ma_map_add_depth(self._ctx, d_p, dtype, width, height,
                                              Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T), float(depth_scale),
                                              C.byref(nv)))
         return int(nv.value)

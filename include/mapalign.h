@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MA_VERSION 200 /* 0.2.0 */
+#define MA_VERSION 201 /* 0.2.1 */
 #define MA_ACC_LEN 17  /* W, s_p[3], s_q[3], S[9] row-major (S_ab = sum w p'_a q_b), E */
 #define MA_TRACE_STRIDE 20 /* per-iteration trace row: acc[17], rmse, table_words_read, candidates */
 #define MA_NO_MATCH 0xFFFFFFFFu
@@ -105,6 +105,12 @@ int ma_destroy(ma_ctx* ctx);
  * default stream).  external == 0: return to the ctx's own stream (hip_stream ignored). */
 int ma_set_stream(ma_ctx* ctx, void* hip_stream, int external);
 int ma_sync(ma_ctx* ctx);
+
+/* Bulk inputs (point arrays, weights, depth frames) may live in HOST memory or in the memory
+ * of the context's device (a torch tensor's data_ptr, the output of a decoder on the GPU): the
+ * library copies them with hipMemcpyDefault on the context's stream, so a device-resident
+ * input never crosses PCIe.  A device input must be complete before the call (or produced on
+ * the stream given to ma_set_stream); small arguments (K, poses, boxes, params) are host memory. */
 
 /* Gold ("base") map: upload M x 3 fp32 points and build the uniform grid used by the
  * nearest-neighbour search (row a4; replaces loading the gold .ply and whatever index

@@ -381,3 +381,50 @@ def test_unprojection_direct_and_chained_forms_and_switching(engine):
     with pytest.raises(mapalign.MapAlignError) as e:
         engine.set_source_from_depth(np.zeros((240, 320), np.float32), K_small, T, 1000.0)
     assert e.value.status == _lib.MA_ERR_EMPTY
+
+
+# ----------------------------------------------------------------------------- device-resident inputs
+def test_device_resident_inputs_match_host_inputs(engine):
+    """Clouds, weights and depth frames that already live in the GPU's memory (torch tensors,
+    `__cuda_array_interface__`) go through the same C entry points (hipMemcpyDefault) and give
+    bitwise the results of the host arrays — nothing is converted on the way."""
+    import torch
+
+    gold, comp, R0, t0 = syn.make_pair(3, 200_000)
+    w = np.random.default_rng(3).uniform(0.25, 2.0, len(comp)).astype(np.float32)
+    g_d, c_d, w_d = (torch.from_numpy(a).cuda() for a in (gold, comp, w))
+
+    engine.set_gold(gold)
+    engine.set_source(comp, w)
+    host = engine.icp(max_iter=30, tol=0.0, max_corr_dist=0.10)
+    engine.set_gold(g_d)
+    engine.set_source(c_d, w_d)
+    dev = engine.icp(max_iter=30, tol=0.0, max_corr_dist=0.10)
+    assert np.array_equal(host.T, dev.T) and host.inliers == dev.inliers
+    assert np.linalg.norm(dev.R - R0) < 1e-3
+
+    # the drop-in call takes them too; fp64 tensors and strided views are converted on the device
+    R1, t1 = mapalign.align(g_d, c_d.double()[::1], max_iter=30)
+    R2, t2 = mapalign.align(gold, comp, max_iter=30)
+    assert np.array_equal(R1, R2) and np.array_equal(t1, t2)
+    view = torch.stack([c_d, c_d], dim=1)[:, 0, :]          # non-contiguous view of the same points
+    assert not view.is_contiguous()
+    R3, t3 = mapalign.align(g_d, view, max_iter=30)
+    assert np.array_equal(R3, R2) and np.array_equal(t3, t2)
+
+    # depth frame on the device (float32 millimetres and uint16)
+    depth, K, T = syn.make_depth_frame(0, width=320, height=240, fx=250.0, fy=250.0, cx=160.0, cy=120.0)
+    engine.set_gold(gold)
+    n_host = engine.set_source_from_depth(depth, K, T, 1000.0)
+    a = engine.icp(max_iter=5, tol=0.0, max_corr_dist=0.10)
+    n_dev = engine.set_source_from_depth(torch.from_numpy(depth).cuda(), K, T, 1000.0)
+    b = engine.icp(max_iter=5, tol=0.0, max_corr_dist=0.10)
+    assert n_host == n_dev > 0 and np.array_equal(a.T, b.T)
+    d16 = np.clip(depth, 0, 65535).astype(np.uint16)
+    assert engine.set_source_from_depth(torch.from_numpy(d16.astype(np.int32)).to(torch.uint16).cuda(), K, T, 1000.0) \
+        == engine.set_source_from_depth(d16, K, T, 1000.0)
+
+    with pytest.raises(ValueError):
+        engine.set_gold(g_d[:, :2])
+    with pytest.raises(ValueError):
+        engine.set_source(c_d, w_d[:-1])
