@@ -116,12 +116,14 @@ __device__ __forceinline__ uint32_t cell_of(float x, float y, float z, const Gri
 // grid build (once per cloud; not part of the timed loop)
 // ---------------------------------------------------------------------------------------
 // Per-workgroup min / max / non-finite count of an n x 3 fp32 cloud.
+// STRIDE floats per point: 3 for raw clouds, 4 for the float4 buffers.
+template <int STRIDE>
 __global__ __launch_bounds__(kBlock) void k_minmax(const float* __restrict__ xyz, uint32_t n,
                                                    float* __restrict__ out /*[grid][8]*/) {
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   float bad = 0.f;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    const float x = xyz[STRIDE * (size_t)i], y = xyz[STRIDE * (size_t)i + 1], z = xyz[STRIDE * (size_t)i + 2];
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
       lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
       lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
@@ -1474,20 +1476,26 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
   }
 }
 
-// N4: voxel keys of the accumulated map points (21 bits per axis around the map origin)
+// N4: voxel keys of the accumulated map points.  The voxel of a point is floor(p / voxel) per axis
+// (anchored at the map origin); the key numbers the voxels of the map's bounding box z-major,
+// (vz * dims.y + vy) * dims.x + vx with indices relative to the box's first voxel, so that the
+// radix sort only has to look at the ~30 bits a real map uses instead of 63.
+struct VoxelBox {
+  long long q0[3];              // first voxel index per axis
+  unsigned long long d[3];      // voxels per axis
+};
 __global__ __launch_bounds__(kBlock) void k_voxel_keys(const float4* __restrict__ pts, uint32_t n, float inv_voxel,
-                                                       unsigned long long* __restrict__ keys,
+                                                       const VoxelBox box, unsigned long long* __restrict__ keys,
                                                        uint32_t* __restrict__ vals) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float4 p = pts[i];
-  const long long half = 1ll << 20;
-  auto q = [&](float v) -> unsigned long long {
-    long long c = (long long)floorf(v * inv_voxel) + half;
-    c = c < 0 ? 0 : (c > 2 * half - 1 ? 2 * half - 1 : c);
+  auto q = [&](float v, int a) -> unsigned long long {
+    long long c = (long long)floorf(v * inv_voxel) - box.q0[a];
+    c = c < 0 ? 0 : (c > (long long)box.d[a] - 1 ? (long long)box.d[a] - 1 : c);
     return (unsigned long long)c;
   };
-  keys[i] = (q(p.z) << 42) | (q(p.y) << 21) | q(p.x);
+  keys[i] = (q(p.z, 2) * box.d[1] + q(p.y, 1)) * box.d[0] + q(p.x, 0);
   vals[i] = i;
 }
 
@@ -1498,25 +1506,72 @@ __global__ __launch_bounds__(kBlock) void k_voxel_heads(const unsigned long long
   flags[i] = (i < n && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
 }
 
-// one thread per voxel: fp64 centroid of its points in sorted (= insertion) order
-__global__ __launch_bounds__(kBlock) void k_voxel_mean(const unsigned long long* __restrict__ keys,
-                                                       const uint32_t* __restrict__ vals,
-                                                       const uint32_t* __restrict__ flags,
-                                                       const uint32_t* __restrict__ segid, uint32_t n,
-                                                       const float4* __restrict__ pts, double o0, double o1, double o2,
-                                                       float* __restrict__ xyz) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n || !flags[i]) return;
-  const unsigned long long key = keys[i];
-  double sx = 0.0, sy = 0.0, sz = 0.0, cnt = 0.0;
-  for (uint32_t j = i; j < n && keys[j] == key; ++j) {
-    const float4 p = pts[vals[j]];
-    sx += p.x; sy += p.y; sz += p.z; cnt += 1.0;
+// fp64 centroid per voxel, in two steps whose work per thread is bounded (a thread per voxel
+// walking its whole run took 3.3 ms of a 7 ms map build: a wavefront waits for its longest run).
+// Step 1, one thread per kVoxRun consecutive sorted points: the points before the block's first
+// voxel head belong to a voxel that started in an earlier block -> pre[block]; every head opens a
+// piece that ends at the next head or at the block's end -> acc[voxel] (written exactly once, by
+// the block that holds the head).  Step 2, one thread per voxel: acc[voxel] + pre[] of the blocks
+// its run continues into, in block order.  The summation order depends only on the sorted order
+// of the points (stable sort = insertion order within a voxel): deterministic.
+constexpr uint32_t kVoxRun = 16;
+struct alignas(32) VoxelSum { double x, y, z, n; };
+__global__ __launch_bounds__(kBlock) void k_voxel_pieces(const uint32_t* __restrict__ vals,
+                                                         const uint32_t* __restrict__ flags,
+                                                         const uint32_t* __restrict__ segid, const uint32_t n,
+                                                         const float4* __restrict__ pts, VoxelSum* __restrict__ acc,
+                                                         VoxelSum* __restrict__ pre, uint32_t* __restrict__ heads) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t i0 = (uint64_t)t * kVoxRun;
+  if (i0 >= n) return;
+  const uint32_t cnt = (uint32_t)min((uint64_t)kVoxRun, (uint64_t)n - i0);
+  VoxelSum s = {0.0, 0.0, 0.0, 0.0};
+  long long cur = -1;   // voxel of the piece being summed; -1: the block's prefix piece
+  auto close = [&]() {
+    if (cur < 0) pre[t] = s; else acc[cur] = s;
+  };
+  for (uint32_t k0 = 0; k0 < cnt; k0 += 4u) {
+    uint32_t v[4], f[4];
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool in = k0 + u < cnt;
+      v[u] = in ? vals[i0 + k0 + u] : 0u;
+      f[u] = in ? flags[i0 + k0 + u] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = pts[v[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (k0 + u >= cnt) break;
+      if (f[u]) {
+        close();
+        cur = (long long)segid[i0 + k0 + u];
+        heads[cur] = (uint32_t)(i0 + k0 + u);
+        s = {0.0, 0.0, 0.0, 0.0};
+      }
+      s.x += p[u].x; s.y += p[u].y; s.z += p[u].z; s.n += 1.0;
+    }
   }
-  const uint32_t s = segid[i];
-  xyz[3 * (size_t)s] = (float)(sx / cnt + o0);
-  xyz[3 * (size_t)s + 1] = (float)(sy / cnt + o1);
-  xyz[3 * (size_t)s + 2] = (float)(sz / cnt + o2);
+  close();
+  if (i0 + cnt == n) heads[segid[n]] = n;   // sentinel: one past the last voxel's run (segid[n] = number of voxels)
+}
+
+__global__ __launch_bounds__(kBlock) void k_voxel_finish(const VoxelSum* __restrict__ acc, const VoxelSum* __restrict__ pre,
+                                                         const uint32_t* __restrict__ heads, const uint32_t nvox,
+                                                         const double o0, const double o1, const double o2,
+                                                         float* __restrict__ xyz) {
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= nvox) return;
+  VoxelSum s = acc[v];
+  const uint32_t t0 = heads[v] / kVoxRun, t1 = (heads[v + 1] - 1u) / kVoxRun;
+  for (uint32_t t = t0 + 1u; t <= t1; ++t) {
+    const VoxelSum q = pre[t];
+    s.x += q.x; s.y += q.y; s.z += q.z; s.n += q.n;
+  }
+  xyz[3 * (size_t)v] = (float)(s.x / s.n + o0);
+  xyz[3 * (size_t)v + 1] = (float)(s.y / s.n + o1);
+  xyz[3 * (size_t)v + 2] = (float)(s.z / s.n + o2);
 }
 
 // a10: one thread per box corner.  cam.T here is the plain camera->world matrix (world frame).
@@ -1672,7 +1727,7 @@ struct ma_ctx {
   int depth_w = 0, depth_h = 0, depth_dtype = -1;
 
   // map builder (N4)
-  DevBuf map_pts, map_keys_a, map_keys_b, map_flags, map_seg;
+  DevBuf map_pts, map_keys_a, map_keys_b, map_flags, map_seg, map_acc, map_pre, map_heads;
   uint64_t map_n = 0, map_cap = 0;
   float map_voxel = 0.f;
   double map_origin[3] = {0, 0, 0};
@@ -1714,7 +1769,7 @@ struct ma_ctx {
     return code;
   }
   std::vector<DevBuf*> all_bufs() {
-    std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &perm0, &occ_a, &occ_b,
+    std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b,
                               &src, &src_perm, &raw, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
                               &depth_in, &lift_poses, &lift_frames, &scan_words, &scan_status, &state, &partials, &trace, &acc19, &ticket,
                               &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
@@ -1809,10 +1864,11 @@ int need_ready(ma_ctx* ctx) {
 }
 
 // bounding box (and finiteness check) of a device-resident n x 3 cloud
-int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3]) {
+int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3], int stride = 3) {
   const int nb = std::min<uint32_t>(div_up(n, kBlock), 1024);
   HIPCHK(ctx->misc.ensure((size_t)nb * 8 * sizeof(float)));
-  hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, ctx->misc.as<float>());
+  if (stride == 4) hipLaunchKernelGGL(k_minmax<4>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, ctx->misc.as<float>());
+  else hipLaunchKernelGGL(k_minmax<3>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, ctx->misc.as<float>());
   HIPCHK(hipGetLastError());
   std::vector<float> h((size_t)nb * 8);
   HIPCHK(hipMemcpyAsync(h.data(), ctx->misc.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -2561,17 +2617,37 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
   HIPCHK(ctx->map_flags.ensure((size_t)(n + 1) * 4));
   HIPCHK(ctx->map_seg.ensure((size_t)(n + 1) * 4));
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  // voxel box of the map (points are finite: k_unproject drops everything else) and the key width
+  float lo[3], hi[3];
+  int rc = cloud_bounds(ctx, ctx->map_pts.as<float>(), n, lo, hi, 4);
+  if (rc) return rc;
+  const float inv_voxel = 1.0f / ctx->map_voxel;
+  VoxelBox box;
+  int key_bits = 0;
+  {
+    long double cells = 1.0L;
+    for (int a = 0; a < 3; ++a) {
+      const long long q0 = (long long)floorf(lo[a] * inv_voxel), q1 = (long long)floorf(hi[a] * inv_voxel);
+      box.q0[a] = q0;
+      box.d[a] = (unsigned long long)(q1 - q0 + 1);
+      cells *= (long double)box.d[a];
+    }
+    if (cells >= 9.0e18L) return ctx->fail(MA_ERR_TOO_LARGE, "the map's bounding box holds 2^63 or more voxels");
+    const unsigned long long last = box.d[0] * box.d[1] * box.d[2] - 1ull;
+    while (key_bits < 64 && (last >> key_bits) != 0ull) ++key_bits;
+    key_bits = std::max(key_bits, 1);
+  }
   hipLaunchKernelGGL(k_voxel_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->map_pts.as<float4>(), n,
-                     1.0f / ctx->map_voxel, ctx->map_keys_a.as<unsigned long long>(), ctx->vals_a.as<uint32_t>());
+                     inv_voxel, box, ctx->map_keys_a.as<unsigned long long>(), ctx->vals_a.as<uint32_t>());
   HIPCHK(hipGetLastError());
   size_t tmp_bytes = 0;
   HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->map_keys_a.as<unsigned long long>(),
                                             ctx->map_keys_b.as<unsigned long long>(), ctx->vals_a.as<uint32_t>(),
-                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, 63, ctx->stream));
+                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, key_bits, ctx->stream));
   HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
   HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp_bytes, ctx->map_keys_a.as<unsigned long long>(),
                                             ctx->map_keys_b.as<unsigned long long>(), ctx->vals_a.as<uint32_t>(),
-                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, 63, ctx->stream));
+                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, key_bits, ctx->stream));
   hipLaunchKernelGGL(k_voxel_heads, dim3(div_up((uint64_t)n + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
                      ctx->map_keys_b.as<unsigned long long>(), n, ctx->map_flags.as<uint32_t>());
   HIPCHK(hipGetLastError());
@@ -2584,10 +2660,17 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
   HIPCHK(hipMemcpyAsync(&nvox, ctx->map_seg.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx->raw.ensure((size_t)nvox * 12));
-  hipLaunchKernelGGL(k_voxel_mean, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream,
-                     ctx->map_keys_b.as<unsigned long long>(), ctx->vals_b.as<uint32_t>(), ctx->map_flags.as<uint32_t>(),
-                     ctx->map_seg.as<uint32_t>(), n, ctx->map_pts.as<float4>(), ctx->map_origin[0], ctx->map_origin[1],
-                     ctx->map_origin[2], ctx->raw.as<float>());
+  const uint32_t nblk = div_up(n, kVoxRun);
+  HIPCHK(ctx->map_acc.ensure((size_t)nvox * sizeof(VoxelSum)));
+  HIPCHK(ctx->map_pre.ensure((size_t)nblk * sizeof(VoxelSum)));
+  HIPCHK(ctx->map_heads.ensure(((size_t)nvox + 1) * 4));
+  hipLaunchKernelGGL(k_voxel_pieces, dim3(div_up(nblk, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->vals_b.as<uint32_t>(),
+                     ctx->map_flags.as<uint32_t>(), ctx->map_seg.as<uint32_t>(), n, ctx->map_pts.as<float4>(),
+                     ctx->map_acc.as<VoxelSum>(), ctx->map_pre.as<VoxelSum>(), ctx->map_heads.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(k_voxel_finish, dim3(div_up(nvox, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->map_acc.as<VoxelSum>(),
+                     ctx->map_pre.as<VoxelSum>(), ctx->map_heads.as<uint32_t>(), nvox, ctx->map_origin[0],
+                     ctx->map_origin[1], ctx->map_origin[2], ctx->raw.as<float>());
   HIPCHK(hipGetLastError());
   if (xyz_out) {
     if (*n_io < nvox) { *n_io = nvox; return ctx->fail(MA_ERR_INVALID, "output capacity too small"); }

@@ -428,3 +428,31 @@ def test_device_resident_inputs_match_host_inputs(engine):
         engine.set_gold(g_d[:, :2])
     with pytest.raises(ValueError):
         engine.set_source(c_d, w_d[:-1])
+
+
+def test_map_builder_long_voxel_runs_and_repeatability(engine):
+    """Voxels that hold hundreds to thousands of points: their runs span many of the 16-point
+    blocks the centroid kernels work in (prefix pieces, open pieces, the sentinel of the last
+    voxel); checked against the NumPy restatement, and two builds must agree bitwise."""
+    K = (250.0, 250.0, 159.5, 119.5)
+    rects = syn.carriage_rectangles(np.random.default_rng(8))
+    poses = []
+    for k, x in enumerate((-3.0, 2.5, 5.0, 7.5)):            # negative coordinates too
+        T = syn.default_camera_pose()
+        T[:3, 3] = (x, 1.4 + 0.05 * k, 1.3)
+        poses.append(T)
+    frames = [syn.render_depth(rects, T, 320, 240, *K) for T in poses]
+    pts = np.concatenate([orc.unproject_oracle(d, K, T, 1000.0)[0] for d, T in zip(frames, poses)])
+    origin = np.round(poses[0][:3, 3])
+    for voxel in (0.4, 0.011):                                # very dense voxels; nearly one point per voxel
+        clouds = []
+        for _ in range(2):
+            engine.map_begin(voxel, 4 * 320 * 240)
+            assert sum(engine.map_add_depth(d, K, T) for d, T in zip(frames, poses)) == len(pts)
+            clouds.append(engine.map_finish())
+        assert np.array_equal(clouds[0], clouds[1])
+        ref = orc.voxel_centroids_oracle(pts, voxel, origin)
+        assert clouds[0].shape == ref.shape
+        assert np.abs(clouds[0].astype(np.float64) - ref).max() <= 2e-5
+    counts = np.unique(np.floor((pts - origin) / 0.4).astype(np.int64), axis=0, return_counts=True)[1]
+    assert counts.max() > 500 and len(ref) > 0.5 * len(pts)   # the two regimes really were exercised
