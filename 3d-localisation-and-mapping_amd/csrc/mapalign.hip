@@ -1914,26 +1914,35 @@ int sort_by_cell(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, co
   return MA_OK;
 }
 
-// histogram of the raw gold points at cell edge c -> number of occupied cells
-int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, const double o[3],
-                   uint64_t* out) {
-  const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
-  const uint64_t n16 = (ncells + 15) / 16;
-  HIPCHK(ctx->occ_b.ensure(n16 * 16));
+// byte marks of the raw gold points in each of `count` (<= 4) candidate grids -> numbers of
+// occupied cells.  The probes are enqueued back to back (same mark buffer, cleared in stream
+// order) and read back with ONE synchronisation.
+int occupied_cells_multi(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP* grids, int count, const double o[3],
+                         uint64_t* out) {
+  uint64_t n16_max = 0;
+  for (int k = 0; k < count; ++k) n16_max = std::max<uint64_t>(n16_max, ((uint64_t)grids[k].nx * grids[k].ny * grids[k].nz + 15) / 16);
+  HIPCHK(ctx->occ_b.ensure(n16_max * 16));
   HIPCHK(ctx->misc.ensure(64));
-  HIPCHK(hipMemsetAsync(ctx->occ_b.p, 0, n16 * 16, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 8, ctx->stream));
-  hipLaunchKernelGGL(k_mark_cells, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0], o[1], o[2], g,
-                     ctx->occ_b.as<uint8_t>());
-  HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(k_count_marks, dim3(std::min<uint32_t>(div_up(n16, kBlock), 2048)), dim3(kBlock), 0, ctx->stream,
-                     ctx->occ_b.as<uint4>(), (uint32_t)n16, ctx->misc.as<unsigned long long>());
-  HIPCHK(hipGetLastError());
-  unsigned long long h = 0;
-  HIPCHK(hipMemcpyAsync(&h, ctx->misc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 8 * (size_t)count, ctx->stream));
+  for (int k = 0; k < count; ++k) {
+    const GridP& g = grids[k];
+    const uint64_t n16 = ((uint64_t)g.nx * g.ny * g.nz + 15) / 16;
+    HIPCHK(hipMemsetAsync(ctx->occ_b.p, 0, n16 * 16, ctx->stream));
+    hipLaunchKernelGGL(k_mark_cells, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0], o[1], o[2], g,
+                       ctx->occ_b.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_count_marks, dim3(std::min<uint32_t>(div_up(n16, kBlock), 2048)), dim3(kBlock), 0, ctx->stream,
+                       ctx->occ_b.as<uint4>(), (uint32_t)n16, ctx->misc.as<unsigned long long>() + k);
+    HIPCHK(hipGetLastError());
+  }
+  unsigned long long h[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(h, ctx->misc.p, 8 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  *out = h;
+  for (int k = 0; k < count; ++k) out[k] = h[k];
   return MA_OK;
+}
+int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, const double o[3], uint64_t* out) {
+  return occupied_cells_multi(ctx, d_xyz, n, &g, 1, o, out);
 }
 
 int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
@@ -2358,15 +2367,22 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     }
     for (int a = 0; a < 3; ++a) {
       const float base = best_lo[a];
-      for (int ph = 1; ph < 4; ++ph) {
+      GridP trial_grid[3];
+      float trial_lo[3];
+      int nt = 0;
+      for (int ph = 1; ph < 4; ++ph) {      // the three shifts of one axis are probed together (one synchronisation)
         float trial[3] = {best_lo[0], best_lo[1], best_lo[2]};
         trial[a] = base - 0.25f * (float)ph * c;
         const GridP g = make_grid(trial, hi, ctx->origin, c);
         if ((uint64_t)g.nx * g.ny * g.nz > kMaxCells) continue;
-        uint64_t occ = 0;
-        if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g, ctx->origin, &occ))) return rc;
-        if (occ < best_occ) { best_occ = occ; best_lo[a] = trial[a]; }
+        trial_grid[nt] = g;
+        trial_lo[nt++] = trial[a];
       }
+      if (nt == 0) continue;
+      uint64_t occ[3] = {0, 0, 0};
+      if ((rc = occupied_cells_multi(ctx, ctx->raw.as<float>(), n, trial_grid, nt, ctx->origin, occ))) return rc;
+      for (int k = 0; k < nt; ++k)
+        if (occ[k] < best_occ) { best_occ = occ[k]; best_lo[a] = trial_lo[k]; }
     }
     for (int a = 0; a < 3; ++a) lo[a] = best_lo[a];
   }

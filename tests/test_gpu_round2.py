@@ -227,6 +227,12 @@ def test_icp_sharded_one_rank_communicator_equals_icp_bitwise(lib_built):
         res = eng.icp_sharded(25, 0.0, 0.10, with_trace=True)
         assert np.array_equal(res.T, ref.T) and np.array_equal(res.trace[:, :18], ref.trace[:, :18])
         assert res.iterations == 25 and res.inliers == ref.inliers
+        # with a convergence test the solve stops the state early while every rank keeps issuing
+        # its max_iter all-reduces (collective counts must match across ranks): same result as ma_icp
+        ref_tol = eng.icp(60, 1e-5, 0.10)
+        res_tol = eng.icp_sharded(60, 1e-5, 0.10)
+        assert ref_tol.converged and res_tol.converged and res_tol.iterations == ref_tol.iterations < 60
+        assert np.array_equal(res_tol.T, ref_tol.T)
         # small host vectors through the same communicator (pair-mode gather, fleet statistics)
         g = eng.comm_allgather(np.arange(5.0))
         assert g.shape == (1, 5) and np.array_equal(g[0], np.arange(5.0))
