@@ -31,11 +31,23 @@ import numpy as np
 from . import transforms
 
 
-def principal_frame(points):
-    """(centroid, axes [3,3] columns by decreasing variance, right-handed, variances)."""
-    p = np.asarray(points, dtype=np.float64)
-    c = p.mean(axis=0)
-    w, v = np.linalg.eigh(np.cov((p - c).T))
+PCA_MAX_POINTS = 1 << 18
+
+
+def principal_frame(points, max_points=PCA_MAX_POINTS):
+    """(centroid, axes [3,3] columns by decreasing variance, right-handed, variances).
+
+    The centroid is taken over all points; the covariance over every k-th point once the cloud
+    holds more than ``max_points`` (a fixed stride, so the result is repeatable): the axes of a
+    million-point scan do not change in the fourth digit, and the two fp64 covariance passes over
+    the full clouds were three quarters of the whole coarse stage (2 x 33 ms of 88 ms, 1M-point pair)."""
+    p = np.asarray(points)
+    # (reductions along axis 0 of an [N,3] array run at a tenth of NumPy's contiguous speed)
+    c = np.ascontiguousarray(p.T).mean(axis=1, dtype=np.float64)
+    if len(p) > max_points:
+        p = p[::-(-len(p) // max_points)]
+    d = np.asarray(p, dtype=np.float64) - c
+    w, v = np.linalg.eigh(d.T @ d / max(len(d) - 1, 1))
     order = np.argsort(w)[::-1]
     axes = v[:, order]
     if np.linalg.det(axes) < 0:
@@ -94,14 +106,22 @@ def trajectory_residual(T, base_traj, comp_traj, n=64):
 
 
 def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0, base_pose_df=None,
-                 comparison_pose_df=None):
+                 comparison_pose_df=None, truncate=None):
     """Returns (stages, T_coarse, info); ``engine`` is a MapAligner with the gold map set.
 
     ``stages`` = [(R, centre), T_translate] in the reference's mixed format.  With both
-    trajectories given, each candidate's score is ``sqrt(cloud_rmse^2 + trajectory_rms^2)``.
+    trajectories given, each candidate's score is ``sqrt(cloud_rms^2 + trajectory_rms^2)``.
+
+    The cloud score of a candidate is the rms of its nearest-neighbour distances TRUNCATED at
+    ``truncate`` metres (default: 5 % of the gold map's bounding-box diagonal): the right
+    candidate leaves centimetres, a wrong one decimetres to metres, and the truncation both
+    keeps a few outlying parts of a wrong candidate from dominating and bounds the search (an
+    ungated exact search for points that lie metres from the map walks thousands of grid rows
+    each: 5-9 ms per wrong candidate for 20k samples against a 1M-point map, 3-5 ms truncated
+    at 1 m; the right candidate costs 0.15 ms either way).
     """
-    gold = np.asarray(gold_cloud, dtype=np.float64)
-    comp = np.asarray(comparison_cloud, dtype=np.float64)
+    gold = np.asarray(gold_cloud)
+    comp = np.asarray(comparison_cloud)
     cg, ag, _ = principal_frame(gold)
     cc, ac, _ = principal_frame(comp)
     rng = np.random.default_rng(seed)
@@ -111,10 +131,14 @@ def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0, bas
     use_traj = base_traj is not None and comp_traj is not None
     scores, cloud_scores, traj_scores = [], [], []
     cands = candidate_rotations(ag, ac)
+    if truncate is None:
+        gi = engine.grid_info()                                  # the gold map's box, as the engine gridded it
+        truncate = 0.05 * float(np.linalg.norm(np.asarray(gi["dims"], dtype=np.float64) * gi["cell"]))
+    truncate = max(float(truncate), 1e-6)
     for R in cands:
         T = transforms.rt_to_matrix(np.eye(3), cg - cc) @ transforms.rotation_about_centre(R, cc)
-        acc, _ = engine.icp_step(T, max_corr_dist=np.inf)
-        cloud = float(np.sqrt(acc[16] / max(acc[0], 1.0)))
+        _, d2 = engine.nn(T, max_corr_dist=truncate)            # inf where nothing lies within the bound
+        cloud = float(np.sqrt(np.mean(np.minimum(d2.astype(np.float64), truncate * truncate))))
         traj = trajectory_residual(T, base_traj, comp_traj) if use_traj else 0.0
         cloud_scores.append(cloud)
         traj_scores.append(traj)
@@ -124,4 +148,4 @@ def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0, bas
     stages = [(R, cc), transforms.rt_to_matrix(np.eye(3), cg - cc)]
     return stages, transforms.compose(stages), {"scores": scores, "cloud_scores": cloud_scores,
                                                 "trajectory_scores": traj_scores if use_traj else None,
-                                                "chosen": best}
+                                                "chosen": best, "truncate_m": truncate}
