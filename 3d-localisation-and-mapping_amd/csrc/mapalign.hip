@@ -159,6 +159,58 @@ __global__ __launch_bounds__(kBlock) void k_minmax(const float* __restrict__ xyz
   }
 }
 
+// fp64 clouds (what Open3D / NumPy hand over by default): bounds in fp64 and the conversion to
+// the engine's fp32 frame on the device, so that the host never walks the arrays.
+__global__ __launch_bounds__(kBlock) void k_minmax_f64(const double* __restrict__ xyz, uint32_t n,
+                                                       double* __restrict__ out /*[grid][8]*/) {
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  double bad = 0.0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      lo[0] = fmin(lo[0], x); hi[0] = fmax(hi[0], x);
+      lo[1] = fmin(lo[1], y); hi[1] = fmax(hi[1], y);
+      lo[2] = fmin(lo[2], z); hi[2] = fmax(hi[2], z);
+    } else {
+      bad += 1.0;
+    }
+  }
+  __shared__ double red[kBlock / kWave][8];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fmin(lo[a], __shfl_down(lo[a], off, kWave));
+      hi[a] = fmax(hi[a], __shfl_down(hi[a], off, kWave));
+    }
+    bad += __shfl_down(bad, off, kWave);
+  }
+  if (lane == 0) {
+    for (int a = 0; a < 3; ++a) { red[wv][a] = lo[a]; red[wv][3 + a] = hi[a]; }
+    red[wv][6] = bad; red[wv][7] = 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int k = threadIdx.x;
+    double v = red[0][k];
+    for (int w = 1; w < kBlock / kWave; ++w) {
+      const double u = red[w][k];
+      v = (k < 3) ? fmin(v, u) : (k < 6 ? fmax(v, u) : v + u);
+    }
+    out[blockIdx.x * 8 + k] = v;
+  }
+}
+
+// raw[i] = (float)(xyz[i] - shift[axis]): the subtraction in fp64, one rounding to fp32
+__global__ __launch_bounds__(kBlock) void k_f64_to_raw(const double* __restrict__ xyz, uint64_t n3, double s0, double s1,
+                                                       double s2, float* __restrict__ raw) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n3) return;
+  const uint32_t a = (uint32_t)(i % 3u);
+  raw[i] = (float)(xyz[i] - (a == 0 ? s0 : (a == 1 ? s1 : s2)));
+}
+
 // key = cell id, val = original index; also the per-cell histogram (integer atomics:
 // the counts are order-independent, hence deterministic).
 #ifndef MA_BRICK_SHIFT
@@ -1734,7 +1786,7 @@ struct ma_ctx {
   bool map_has_origin = false;
 
   // scratch for builds
-  DevBuf raw, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
+  DevBuf raw, raw64, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
 
   // batched box lifting (a10 over many frames)
   DevBuf lift_poses, lift_frames;
@@ -1770,7 +1822,7 @@ struct ma_ctx {
   }
   std::vector<DevBuf*> all_bufs() {
     std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b,
-                              &src, &src_perm, &raw, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
+                              &src, &src_perm, &raw, &raw64, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
                               &depth_in, &lift_poses, &lift_frames, &scan_words, &scan_status, &state, &partials, &trace, &acc19, &ticket,
                               &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
     for (int l = 0; l < kLevels; ++l) { v.push_back(&gold[l]); v.push_back(&cstart[l]); }
@@ -2189,6 +2241,7 @@ int guarded(ma_ctx* ctx, F&& body) noexcept {
 // Builds the gold map (grids of all levels, distance table) from the n x 3 fp32 world-frame
 // points already resident in ctx->raw; ev0 must have been recorded by the caller.
 static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell);
+static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights);
 
 extern "C" {
 
@@ -2501,6 +2554,12 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
   const uint32_t n = (uint32_t)n64;
   HIPCHK(ctx->raw.ensure((size_t)n * 12));
   HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyDefault, ctx->stream));   // host OR device memory (include/mapalign.h)
+  return build_source_from_raw(ctx, n, weights);
+  });
+}
+
+// ctx->raw holds the n x 3 fp32 source points (relative to the host-side shift, if any)
+static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights) {
   const float* d_w = nullptr;
   if (weights) {
     HIPCHK(ctx->wts.ensure((size_t)n * 4));
@@ -2537,6 +2596,73 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
   ctx->src_sorted = true;
   ctx->have_src = true;
   return MA_OK;
+}
+
+// fp64 staging: upload (host or device memory), bounds in fp64; `shift` is chosen here when
+// choose_shift (gold map) and applied as given otherwise (source cloud)
+static int stage_f64(ma_ctx* ctx, const double* xyz, uint32_t n, bool choose_shift, double shift[3]) {
+  HIPCHK(ctx->raw64.ensure((size_t)n * 24));
+  HIPCHK(ctx->raw.ensure((size_t)n * 12));
+  HIPCHK(hipMemcpyAsync(ctx->raw64.p, xyz, (size_t)n * 24, hipMemcpyDefault, ctx->stream));
+  if (choose_shift) {
+    const int nb = std::min<uint32_t>(div_up(n, kBlock), 1024);
+    HIPCHK(ctx->misc.ensure((size_t)nb * 8 * sizeof(double)));
+    hipLaunchKernelGGL(k_minmax_f64, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->raw64.as<double>(), n, ctx->misc.as<double>());
+    HIPCHK(hipGetLastError());
+    std::vector<double> h((size_t)nb * 8);
+    HIPCHK(hipMemcpyAsync(h.data(), ctx->misc.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, bad = 0, big = 0;
+    for (int b = 0; b < nb; ++b) {
+      for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], h[(size_t)b * 8 + a]); hi[a] = std::max(hi[a], h[(size_t)b * 8 + 3 + a]); }
+      bad += h[(size_t)b * 8 + 6];
+    }
+    if (bad > 0) return ctx->fail(MA_ERR_INVALID, "cloud has non-finite coordinates (filter them first, as the reference's read_point_cloud(remove_nan_points=True, remove_infinite_points=True) does)");
+    for (int a = 0; a < 3; ++a) big = std::max({big, std::fabs(lo[a]), std::fabs(hi[a])});
+    // georeferenced coordinates lose centimetres in fp32: an integer-metre shift (half-to-even, as
+    // numpy.round) to the box centre is taken out in fp64 first
+    for (int a = 0; a < 3; ++a) shift[a] = big > MA_LARGE_COORDINATE_M ? std::nearbyint(0.5 * (lo[a] + hi[a])) : 0.0;
+  }
+  const uint64_t n3 = 3ull * n;
+  hipLaunchKernelGGL(k_f64_to_raw, dim3((uint32_t)((n3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                     ctx->raw64.as<double>(), n3, shift[0], shift[1], shift[2], ctx->raw.as<float>());
+  HIPCHK(hipGetLastError());
+  return MA_OK;
+}
+
+int ma_set_gold_f64(ma_ctx* ctx, const double* xyz, uint64_t m, float cell, double shift_out[3]) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if ((!xyz && m) || !shift_out) return ctx->fail(MA_ERR_INVALID, "NULL argument");
+  if (m == 0) return ctx->fail(MA_ERR_EMPTY, "gold cloud is empty");
+  if (m >= (1ull << 28)) return ctx->fail(MA_ERR_TOO_LARGE, "gold cloud has 2^28 or more points (32-bit byte offsets into the cell-sorted arrays)");
+  if (std::isnan(cell) || std::isinf(cell)) return ctx->fail(MA_ERR_INVALID, "cell must be finite");
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->have_gold = false;
+  ctx->have_src = false;
+  ctx->state_valid = false;
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = stage_f64(ctx, xyz, (uint32_t)m, true, shift_out);
+  if (rc) return rc;
+  return build_gold_from_raw(ctx, (uint32_t)m, cell);
+  });
+}
+
+int ma_set_source_f64(ma_ctx* ctx, const double* xyz, const float* weights, uint64_t n64, const double shift[3]) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "set the gold map before the source cloud");
+  if (!xyz && n64) return ctx->fail(MA_ERR_INVALID, "xyz is NULL");
+  if (n64 == 0) return ctx->fail(MA_ERR_EMPTY, "source cloud is empty");
+  if (n64 >= (1ull << 31)) return ctx->fail(MA_ERR_TOO_LARGE, "source cloud has 2^31 or more points (32-bit item counts of the sort)");
+  double s[3] = {0.0, 0.0, 0.0};
+  if (shift) for (int a = 0; a < 3; ++a) { if (!std::isfinite(shift[a])) return ctx->fail(MA_ERR_INVALID, "non-finite shift"); s[a] = shift[a]; }
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->have_src = false;
+  ctx->state_valid = false;
+  int rc = stage_f64(ctx, xyz, (uint32_t)n64, false, s);
+  if (rc) return rc;
+  return build_source_from_raw(ctx, (uint32_t)n64, weights);   // (non-finite coordinates are caught by its fp32 bounds pass)
   });
 }
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MA_VERSION 201 /* 0.2.1 */
+#define MA_VERSION 202 /* 0.2.2 */
 #define MA_ACC_LEN 17  /* W, s_p[3], s_q[3], S[9] row-major (S_ab = sum w p'_a q_b), E */
 #define MA_TRACE_STRIDE 20 /* per-iteration trace row: acc[17], rmse, table_words_read, candidates */
 #define MA_NO_MATCH 0xFFFFFFFFu
@@ -124,6 +124,19 @@ int ma_grid_info_get(const ma_ctx* ctx, ma_grid_info* out);
  * are stored relative to its origin).  Weights scale a correspondence's contribution to the
  * sums (w = 1 is one plain correspondence); they need not sum to anything in particular. */
 int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t n);
+
+/* The same for fp64 clouds — what Open3D and NumPy hand over by default (the reference's
+ * arrays are np.asarray(pcd.points), float64).  Upload, bounds and the conversion to the engine's
+ * fp32 frame happen on the device; the host never walks the arrays.  Georeferenced coordinates
+ * (any |coordinate| above MA_LARGE_COORDINATE_M) would lose centimetres in fp32, so
+ * ma_set_gold_f64 then takes an integer-metre shift (the box centre, rounded half-to-even) out in
+ * fp64 first and reports it in shift_out (zeros otherwise): the context works in the shifted
+ * frame, i.e. every transform it returns is T_local with T_world = S T_local S^-1, S = translation
+ * by the shift — the caller passes the same shift to ma_set_source_f64 (NULL = zeros) and
+ * conjugates results (mapalign/engine.py does). */
+#define MA_LARGE_COORDINATE_M 1000.0
+int ma_set_gold_f64(ma_ctx* ctx, const double* xyz, uint64_t m, float cell, double shift_out[3]);
+int ma_set_source_f64(ma_ctx* ctx, const double* xyz, const float* weights, uint64_t n, const double shift[3]);
 int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out);
 
 /* Row a8: fused depth -> 3-D unprojection written straight into the source-cloud device

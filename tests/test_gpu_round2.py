@@ -418,6 +418,15 @@ def test_device_resident_inputs_match_host_inputs(engine):
     R3, t3 = mapalign.align(g_d, view, max_iter=30)
     assert np.array_equal(R3, R2) and np.array_equal(t3, t2)
 
+    # fp64 host arrays (Open3D's dtype) are converted on the device: same bits as the fp32 arrays they round to
+    R4, t4 = mapalign.align(gold.astype(np.float64), comp.astype(np.float64), weights=w, max_iter=30)
+    R5, t5 = mapalign.align(gold, comp, weights=w, max_iter=30)
+    assert np.array_equal(R4, R5) and np.array_equal(t4, t5)
+    with pytest.raises(mapalign.MapAlignError):
+        bad = gold.astype(np.float64)
+        bad[5, 1] = np.nan
+        engine.set_gold(bad)
+
     # depth frame on the device (float32 millimetres and uint16)
     depth, K, T = syn.make_depth_frame(0, width=320, height=240, fx=250.0, fy=250.0, cx=160.0, cy=120.0)
     engine.set_gold(gold)
