@@ -47,7 +47,9 @@ def apply(T, points):
     """Row-vector form of ``(T @ [p,1])[:3]`` (``pose_processor.py:254-260``)."""
     T = to_matrix(T)
     p = np.asarray(points, dtype=np.float64)
-    return p @ T[:3, :3].T + T[:3, 3]
+    out = p @ np.ascontiguousarray(T[:3, :3].T)
+    out += T[:3, 3]
+    return out
 
 
 def is_rigid(T, atol=1e-9):
