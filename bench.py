@@ -170,8 +170,22 @@ def end_to_end(gold, comp, device):
         t0 = time.perf_counter()
         mapalign.align(g64, c64, max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
         f64_in.append((time.perf_counter() - t0) * 1e3)
+    # the reference's call shape (task_def.py:175-187): Alignment(...).compare() on two .ply files, the scan far off
+    import tempfile
+    from mapalign import ply, synthetic as syn
+    with tempfile.TemporaryDirectory() as d:
+        far = syn.make_pair(0, len(comp), angle_deg=150.0, t0=(7.0, -1.0, 0.5))[1]
+        gp, sp = os.path.join(d, "gold.ply"), os.path.join(d, "scan.ply")
+        ply.write_ply(gp, gold)
+        ply.write_ply(sp, far)
+        cmp_ms = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            mapalign.Alignment(base_map_filepath=gp, comparison_map_filepath=sp, device=device).compare(d)
+            cmp_ms.append((time.perf_counter() - t0) * 1e3)
     mapalign.release_cached_engines()
     return {"end_to_end_ms": float(np.median(warm)), "end_to_end_ms_first_call": first,
+            "compare_call_ms_two_1m_ply_files": float(np.median(cmp_ms[1:])),
             "end_to_end_ms_gold_resident": resident, "end_to_end_ms_device_inputs": float(np.median(dev_in)),
             "end_to_end_ms_fp64_host_inputs": float(np.median(f64_in)),
             "device_allocs_in_warm_calls": int(allocs[-1] - allocs[0]),
