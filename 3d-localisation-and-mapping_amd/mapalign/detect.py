@@ -204,17 +204,32 @@ class Detector:
             return torch.zeros(int(keep.sum()), dtype=torch.long, device=det.device)
         b_idx, k_idx = keep.nonzero(as_tuple=True)
         H, W = x.shape[2], x.shape[3]
-        crops = []
-        for b, k in zip(b_idx.tolist(), k_idx.tolist()):
-            x1, y1, x2, y2 = det[b, k, :4].tolist()
-            xa, ya = int(min(max(x1, 0), W - 1)), int(min(max(y1, 0), H - 1))
-            xb, yb = int(min(max(x2, xa + 1), W)), int(min(max(y2, ya + 1), H))
-            crops.append(F.interpolate(x[b:b + 1, :, ya:yb, xa:xb], size=(self.crop_size, self.crop_size),
-                                       mode="bilinear", align_corners=False))
+        S = self.crop_size
+        # crop rectangles in whole pixels, as slicing image[y1:y2, x1:x2] gives them (at least 1 x 1)
+        box = det[b_idx, k_idx, :4]
+        xa = box[:, 0].clamp(0, W - 1).floor()
+        ya = box[:, 1].clamp(0, H - 1).floor()
+        xb = torch.minimum(torch.maximum(box[:, 2], xa + 1), torch.full_like(xa, W)).floor()
+        yb = torch.minimum(torch.maximum(box[:, 3], ya + 1), torch.full_like(ya, H)).floor()
+        # every crop of a classifier batch is cut and resized by ONE grid_sample: output pixel o
+        # samples the crop at (o + 0.5) * w / S - 0.5, clamped to the crop (edge replication) —
+        # the positions of F.interpolate(crop, bilinear, align_corners=False) — then shifted into
+        # the image; align_corners=True makes integer coordinates pixel centres
+        o = (torch.arange(S, device=det.device, dtype=torch.float32) + 0.5) / S
         labels = []
         with torch.no_grad():
-            for s in range(0, len(crops), self.batch_size):
-                out = self.damage_classifier(torch.cat(crops[s:s + self.batch_size], 0))
+            for s in range(0, box.shape[0], self.batch_size):
+                e = min(s + self.batch_size, box.shape[0])
+                w, h = (xb - xa)[s:e, None], (yb - ya)[s:e, None]
+                sx = (o[None, :] * w - 0.5).clamp(min=0.0).minimum(w - 1.0) + xa[s:e, None]      # [n, S]
+                sy = (o[None, :] * h - 0.5).clamp(min=0.0).minimum(h - 1.0) + ya[s:e, None]
+                gx = sx * (2.0 / max(W - 1, 1)) - 1.0
+                gy = sy * (2.0 / max(H - 1, 1)) - 1.0
+                grid = torch.stack([gx[:, None, :].expand(-1, S, -1), gy[:, :, None].expand(-1, -1, S)], dim=-1)
+                # (sampled in fp32: half-precision grid coordinates would be off by up to half a pixel)
+                crops = F.grid_sample(x[b_idx[s:e]].float(), grid, mode="bilinear", padding_mode="border",
+                                      align_corners=True)
+                out = self.damage_classifier(crops.to(self.dtype))
                 logits = out.logits if hasattr(out, "logits") else out
                 labels.append(logits.argmax(-1))
         return torch.cat(labels)

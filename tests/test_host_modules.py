@@ -205,6 +205,36 @@ def test_detector_adaptor_rows_and_batched_lift_bookkeeping():
     fewer = det(imgs)
     assert 0 < sum(len(v) for v in fewer.values()) < 60
 
+    # the crops the damage classifier sees are image[y1:y2, x1:x2] resized bilinearly (classifier.py:69-88),
+    # cut and resized a whole classifier batch at a time
+    class Recorder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def forward(self, x):
+            self.seen.append(x.clone())
+            return torch.zeros(x.shape[0], 2)
+
+    rec = Recorder()
+    det2 = detect.Detector(model, rec, batch_size=4, conf_thresh=0.0, device="cpu", half=False, crop_size=16)
+    x = det2._prepare(imgs)
+    boxes6 = torch.tensor([[[3.7, 2.2, 40.9, 30.1, 0.9, 1], [-5.0, 10.0, 8.0, 11.2, 0.8, 0], [90.0, 60.0, 300.0, 300.0, 0.7, 2],
+                            [20.0, 20.0, 20.5, 20.5, 0.6, 1], [0.0, 0.0, 96.0, 64.0, 0.5, 0]]] * 3)
+    keep = torch.ones(3, 5, dtype=torch.bool)
+    det2._damage(x, boxes6, keep)
+    got = torch.cat(rec.seen)
+    assert got.shape == (15, 3, 16, 16) and len(rec.seen) == 4                      # 15 crops in batches of 4
+    H, W = x.shape[2], x.shape[3]
+    k = 0
+    for b in range(3):
+        for x1, y1, x2, y2 in boxes6[b, :, :4].tolist():
+            xa, ya = int(min(max(x1, 0), W - 1)), int(min(max(y1, 0), H - 1))
+            xb, yb = int(min(max(x2, xa + 1), W)), int(min(max(y2, ya + 1), H))
+            want = torch.nn.functional.interpolate(x[b:b + 1, :, ya:yb, xa:xb], size=(16, 16), mode="bilinear", align_corners=False)
+            assert torch.allclose(got[k], want[0], atol=1e-5), (b, x1, y1, x2, y2)
+            k += 1
+
     class FakeEngine:   # records what lift_batch hands to the ONE device call
         def lift_boxes_batch(self, b, bf, d, K, T, scale):
             self.args = (b, bf, d.shape, K, T.shape, scale)
