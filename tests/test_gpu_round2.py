@@ -471,3 +471,27 @@ def test_map_builder_long_voxel_runs_and_repeatability(engine):
         assert np.abs(clouds[0].astype(np.float64) - ref).max() <= 2e-5
     counts = np.unique(np.floor((pts - origin) / 0.4).astype(np.int64), axis=0, return_counts=True)[1]
     assert counts.max() > 500 and len(ref) > 0.5 * len(pts)   # the two regimes really were exercised
+
+
+def test_clump_of_coincident_returns_in_both_clouds(engine):
+    """Real scans carry clumps of coincident points (invalid returns mapped to one position): 20 000
+    copies of one point in the gold map AND in the scan put a 20 000-point run into one grid cell,
+    which every query near it has to scan chunk by chunk.  Must stay exact and finish promptly."""
+    gold, comp, R0, t0 = syn.make_pair(11, 150_000, 120_000)
+    spot = gold[777].copy()
+    gold = np.concatenate([gold, np.tile(spot, (20_000, 1))]).astype(np.float32)
+    comp_spot = (spot.astype(np.float64) - t0) @ R0
+    comp = np.concatenate([comp, np.tile(comp_spot, (20_000, 1))]).astype(np.float32)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    t_start = time.perf_counter()
+    res = engine.icp(30, 0.0, 0.10)
+    assert time.perf_counter() - t_start < 5.0
+    ref = orc.icp_oracle(gold, comp, max_iter=30, max_corr_dist=0.10, n_jobs=-1)
+    eR, et = orc.rt_error(res.R, res.t, ref["R"], ref["t"])
+    assert eR <= R_TOL_FRO and et <= T_TOL_M
+    assert abs(res.inliers - ref["inliers"]) <= 2
+    idx, d2 = engine.nn(res.T, 0.10)
+    # the scan's clump lands on the map's clump (30 iterations leave centimetres): all its points match within the gate
+    clump = np.arange(len(comp) - 20_000, len(comp))
+    assert np.all(np.isfinite(d2[clump])) and np.all(d2[clump] < 0.05 ** 2) and np.all(idx[clump] != NO_MATCH)
