@@ -2769,6 +2769,8 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
   {
     long double cells = 1.0L;
     for (int a = 0; a < 3; ++a) {
+      if (!(std::fabs(lo[a] * inv_voxel) < 4.0e18f) || !(std::fabs(hi[a] * inv_voxel) < 4.0e18f))
+        return ctx->fail(MA_ERR_TOO_LARGE, "voxel indices of the map do not fit 63 bits (coordinates / voxel too large)");
       const long long q0 = (long long)floorf(lo[a] * inv_voxel), q1 = (long long)floorf(hi[a] * inv_voxel);
       box.q0[a] = q0;
       box.d[a] = (unsigned long long)(q1 - q0 + 1);
