@@ -370,6 +370,18 @@ def main():
             # exercise the library's own RCCL path at N > 1 as well (a fleet-level
             # stats vector through the communicator); never fatal for the benchmark itself
             try:
+                # every rank first checks locally that the library can reach librccl, and the ranks
+                # agree through torch.distributed before any of them enters the library's communicator
+                # bootstrap (a rank that cannot would otherwise leave the others waiting in it)
+                try:
+                    eng.comm_unique_id()
+                    can = 1.0
+                except Exception:
+                    can = 0.0
+                agree = torch.tensor([can], dtype=torch.float64, device=f"cuda:{local_rank}")
+                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+                if float(agree.item()) < 1.0:
+                    raise RuntimeError("librccl is not loadable from libmapalign on every rank")
                 mdist.bootstrap_comm(eng)
                 err = eng.comm_allreduce(err, "max")
                 eng.comm_destroy()
