@@ -25,6 +25,7 @@ import pickle
 import numpy as np
 
 from . import boxes, coarse, ply, transforms
+from ._lib import MapAlignError
 from .api import cached_engine
 
 DATA_ROOT = os.path.join("src", "common", "data")     # visualise.py:241
@@ -45,7 +46,7 @@ class Alignment:
     def __init__(self, base_pose_df=None, comparison_pose_df=None, base_bboxes=None, comparison_bboxes=None,
                  visualise=False, *, base_map_filepath=None, comparison_map_filepath=None,
                  map_resolver=default_map_resolver, pickle_path=None, device=0, max_iter=50, tol=0.0,
-                 max_corr_dist=0.10, coarse_stage=True):
+                 max_corr_dist=0.10, coarse_stage=True, gate_schedule="auto"):
         self.base_pose_df = base_pose_df
         self.comparison_pose_df = comparison_pose_df
         self.base_bboxes = base_bboxes or {}
@@ -58,6 +59,15 @@ class Alignment:
         self.device = device
         self.max_iter, self.tol, self.max_corr_dist = max_iter, tol, max_corr_dist
         self.coarse_stage = coarse_stage
+        # Gates tried before the final one.  The principal-axes start of the coarse stage is good to
+        # a few degrees at best on real scans, and a 0.10 m gate alone only recovers starts within
+        # about 2 degrees / 15 cm of the answer (tools/basin_probe.py: 3 deg / 0.37 m already fails),
+        # whereas 0.8 -> 0.4 -> 0.2 -> 0.1 m recovers 6 deg / 1 m for 5-20 ms more.  "auto": 8x, 4x,
+        # 2x max_corr_dist, up to 15 iterations each (stopping when the rmse settles); None: the final
+        # gate only; or an explicit list of (gate_m, max_iterations).
+        if gate_schedule == "auto":
+            gate_schedule = [(8.0 * max_corr_dist, 15), (4.0 * max_corr_dist, 15), (2.0 * max_corr_dist, 15)] if coarse_stage else None
+        self.gate_schedule = list(gate_schedule) if gate_schedule else []
         self.transformations = []
 
     def align_clouds(self, gold_cloud, comparison_cloud):
@@ -71,10 +81,19 @@ class Alignment:
                                                        base_pose_df=self.base_pose_df,
                                                        comparison_pose_df=self.comparison_pose_df)
             eng.set_source(comparison_cloud)
-            res = eng.icp(self.max_iter, self.tol, self.max_corr_dist, init=T0)
-        T_icp = res.T @ np.linalg.inv(T0)          # refinement applied AFTER the coarse stages
+            T, gpu_ms, widened = T0, 0.0, []
+            for gate, iters in self.gate_schedule:          # wide gates first: pulls a rough start into the final gate's basin
+                try:
+                    r = eng.icp(int(iters), 1e-5, float(gate), init=T)
+                except MapAlignError:                       # nothing inside this gate (or collinear): keep T, try the next one
+                    continue
+                T, gpu_ms = r.T, gpu_ms + r.gpu_ms
+                widened.append((float(gate), r.iterations, r.rmse))
+            res = eng.icp(self.max_iter, self.tol, self.max_corr_dist, init=T)
+        T_icp = res.T @ np.linalg.inv(T0)          # refinement (all gates) applied AFTER the coarse stages
         stages = list(stages) + [T_icp]
-        info.update(iterations=res.iterations, rmse=res.rmse, inliers=res.inliers, gpu_ms=res.gpu_ms)
+        info.update(iterations=res.iterations, rmse=res.rmse, inliers=res.inliers, gpu_ms=gpu_ms + res.gpu_ms,
+                    gate_schedule=widened)
         return stages, res.T, info
 
     def compare(self, data_folder):

@@ -567,7 +567,7 @@ def test_alignment_adaptor_far_start_with_ply_and_pickle(tmp_path):
         pickle.dump({"pose_df": None}, f)
     al = Alignment(base_pose_df=None, comparison_pose_df=None, base_bboxes=gold_boxes, comparison_bboxes=comp_boxes,
                    visualise=False, base_map_filepath=str(gold_path), comparison_map_filepath=str(comp_path),
-                   pickle_path=str(pkl))
+                   pickle_path=str(pkl), gate_schedule=None)   # one gate: the same loop the oracle runs below
     aligned, T, gold_pts, info = al.compare("scan")
     eR, et = orc.rt_error(T[:3, :3], T[:3, 3], R0, t0)
     assert eR <= 2e-3 and et <= 2e-2                         # independent resample: sampling noise, not parity

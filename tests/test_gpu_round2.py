@@ -495,3 +495,42 @@ def test_clump_of_coincident_returns_in_both_clouds(engine):
     # the scan's clump lands on the map's clump (30 iterations leave centimetres): all its points match within the gate
     clump = np.arange(len(comp) - 20_000, len(comp))
     assert np.all(np.isfinite(d2[clump])) and np.all(d2[clump] < 0.05 ** 2) and np.all(idx[clump] != NO_MATCH)
+
+
+def test_alignment_gate_schedule_recovers_a_rough_coarse_start(lib_built):
+    """The coarse stage is good to a few degrees at best on real scans.  From a start 5 degrees /
+    0.8 m off, the 0.10 m gate alone stays wrong; the adaptor's default schedule (0.8 -> 0.4 ->
+    0.2 m before the final gate) reaches the answer, and from a good start both agree."""
+    gold, comp, R0, t0 = syn.make_pair(5, 200_000)
+    T_true = transforms.rt_to_matrix(R0, t0)
+    c = gold.mean(axis=0).astype(np.float64)
+    dR = syn.rotation_about_axis([0.2, -0.4, 0.9], np.deg2rad(5.0))
+    off = np.eye(4)
+    off[:3, :3] = dR
+    off[:3, 3] = c - dR @ c + np.array([0.6, -0.4, 0.3])
+    rough = off @ T_true
+
+    class RoughCoarse:                                   # stands in for a principal-axes start that is a few degrees off
+        @staticmethod
+        def coarse_align(eng, g, s, **kw):
+            return [rough], rough, {}
+
+    import mapalign.alignment as al_mod
+    real = al_mod.coarse
+    al_mod.coarse = RoughCoarse
+    try:
+        _, T_single, _ = mapalign.Alignment(gate_schedule=None).align_clouds(gold, comp)
+        stages, T_sched, info = mapalign.Alignment().align_clouds(gold, comp)
+    finally:
+        al_mod.coarse = real
+    eR1, et1 = orc.rt_error(T_single[:3, :3], T_single[:3, 3], R0, t0)
+    eR2, et2 = orc.rt_error(T_sched[:3, :3], T_sched[:3, 3], R0, t0)
+    assert et1 > 0.2 and eR2 <= 1e-3 and et2 <= 5e-3, (eR1, et1, eR2, et2)
+    assert [g for g, _, _ in info["gate_schedule"]] == [0.8, 0.4, 0.2]
+    assert np.allclose(transforms.compose(stages), T_sched, atol=1e-9)
+    # from the truth-adjacent start of the benchmark pair the schedule changes nothing that matters
+    _, T_a, _ = mapalign.Alignment(coarse_stage=False, gate_schedule=None).align_clouds(gold, comp)
+    _, T_b, _ = mapalign.Alignment(coarse_stage=False, gate_schedule=[(0.8, 15), (0.4, 15), (0.2, 15)]).align_clouds(gold, comp)
+    eR, et = orc.rt_error(T_a[:3, :3], T_a[:3, 3], T_b[:3, :3], T_b[:3, 3])
+    assert eR <= 1e-4 and et <= 1e-3
+    mapalign.release_cached_engines()
