@@ -170,6 +170,7 @@ def align_pairs(pairs, *, max_iter=50, tol=0.0, max_corr_dist=0.10, cell=0.0, de
     world, rank = _world(group)
     n_pairs = pairs.n if hasattr(pairs, "n") else len(pairs)
     gather_device = "cpu"
+    default_align_fn = None
     if align_fn is None:
         import torch
 
@@ -184,10 +185,21 @@ def align_pairs(pairs, *, max_iter=50, tol=0.0, max_corr_dist=0.10, cell=0.0, de
             T[:3, :3], T[:3, 3] = R, t
             return T
 
+        default_align_fn = align_fn
+
     mine = []
-    for i in pairs_for_rank(n_pairs, world, rank):
-        g, c = pairs(i) if callable(pairs) else pairs[i]
-        mine.append(np.concatenate([[float(i)], np.asarray(align_fn(g, c), dtype=np.float64).reshape(16)]))
+    my_ids = pairs_for_rank(n_pairs, world, rank)
+    get = (lambda i: pairs(i)) if callable(pairs) else (lambda i: pairs[i])
+    if align_fn is default_align_fn:
+        # this rank's pairs as one pipelined stream: the next pair is uploaded and indexed while the current one iterates
+        from .api import align_many
+        Ts = align_many((get(i) for i in my_ids), max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist, cell=cell,
+                        device=dev)
+        mine = [np.concatenate([[float(i)], np.asarray(T, dtype=np.float64).reshape(16)]) for i, T in zip(my_ids, Ts)]
+    else:
+        for i in my_ids:
+            g, c = get(i)
+            mine.append(np.concatenate([[float(i)], np.asarray(align_fn(g, c), dtype=np.float64).reshape(16)]))
     if world == 1:
         table = np.asarray(mine, dtype=np.float64).reshape(-1, 17)
     else:

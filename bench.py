@@ -170,6 +170,12 @@ def end_to_end(gold, comp, device):
         t0 = time.perf_counter()
         mapalign.align(g64, c64, max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
         f64_in.append((time.perf_counter() - t0) * 1e3)
+    # a stream of pairs on this GPU (mapalign.align_many): the next pair is staged in a second context while the current one iterates
+    stream = [(gold, comp)] * 12
+    mapalign.align_many(stream[:3], max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
+    t0 = time.perf_counter()
+    mapalign.align_many(stream, max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
+    piped = (time.perf_counter() - t0) / len(stream) * 1e3
     # the reference's call shape (task_def.py:175-187): Alignment(...).compare() on two .ply files, the scan far off
     import tempfile
     from mapalign import ply, synthetic as syn
@@ -186,6 +192,7 @@ def end_to_end(gold, comp, device):
     mapalign.release_cached_engines()
     return {"end_to_end_ms": float(np.median(warm)), "end_to_end_ms_first_call": first,
             "compare_call_ms_two_1m_ply_files": float(np.median(cmp_ms[1:])),
+            "end_to_end_ms_per_pair_pipelined_stream": piped, "end_to_end_it_per_s_pipelined_stream": ITERS / (piped * 1e-3),
             "end_to_end_ms_gold_resident": resident, "end_to_end_ms_device_inputs": float(np.median(dev_in)),
             "end_to_end_ms_fp64_host_inputs": float(np.median(f64_in)),
             "device_allocs_in_warm_calls": int(allocs[-1] - allocs[0]),

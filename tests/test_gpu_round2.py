@@ -534,3 +534,28 @@ def test_alignment_gate_schedule_recovers_a_rough_coarse_start(lib_built):
     eR, et = orc.rt_error(T_a[:3, :3], T_a[:3, 3], T_b[:3, :3], T_b[:3, 3])
     assert eR <= 1e-4 and et <= 1e-3
     mapalign.release_cached_engines()
+
+
+def test_align_many_pipelines_pairs_and_equals_align_pair_by_pair(lib_built):
+    """A stream of pairs on one GPU: the next pair is staged in a second context while the current
+    one iterates.  Every result equals mapalign.align of that pair bit for bit, in order."""
+    pairs = [syn.make_pair(40 + k, 60_000 + 5_000 * k, 50_000)[:2] for k in range(5)]
+    one_by_one = []
+    for g, c in pairs:
+        R, t = mapalign.align(g, c, max_iter=30)
+        one_by_one.append(transforms.rt_to_matrix(R, t))
+    for pipeline in (True, False):
+        Ts = mapalign.align_many(iter(pairs), max_iter=30, pipeline=pipeline)
+        assert len(Ts) == len(pairs)
+        for a, b in zip(Ts, one_by_one):
+            assert np.array_equal(a, b)
+    assert mapalign.align_many([], max_iter=5) == []
+    # an error in one pair surfaces as that pair's exception and leaves the contexts usable
+    bad = [pairs[0], (pairs[1][0], np.full((10, 3), np.nan, np.float32)), pairs[2]]
+    with pytest.raises(mapalign.MapAlignError):
+        mapalign.align_many(bad, max_iter=5)
+    assert np.array_equal(mapalign.align_many(pairs[:2], max_iter=30)[1], one_by_one[1])
+    from mapalign import dist as mdist
+    out = mdist.align_pairs(pairs, max_iter=30, device=0)       # single process: all pairs, pipelined
+    assert all(np.array_equal(a, b) for a, b in zip(out, one_by_one))
+    mapalign.release_cached_engines()

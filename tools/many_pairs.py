@@ -1,0 +1,15 @@
+"""Throughput of a stream of 1M-point pairs on one GPU: pair by pair against the pipelined align_many (GPU box)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "3d-localisation-and-mapping_amd"))
+import numpy as np, mapalign
+from mapalign import synthetic as syn
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+base = [syn.make_pair(s, n)[:2] for s in range(3)]
+pairs = [base[k % 3] for k in range(24)]
+for pipeline in (False, True, False, True):
+    mapalign.align_many(pairs[:3], pipeline=pipeline)
+    t0 = time.perf_counter()
+    Ts = mapalign.align_many(pairs, pipeline=pipeline)
+    dt = time.perf_counter() - t0
+    print("pipeline=%-5s %d pairs of %d points: %.2f ms per pair (%.0f pairs/s, %.0f ICP iterations/s incl. upload and grid build)"
+          % (pipeline, len(pairs), n, dt / len(pairs) * 1e3, len(pairs) / dt, 50 * len(pairs) / dt))
