@@ -544,8 +544,8 @@ def test_align_many_pipelines_pairs_and_equals_align_pair_by_pair(lib_built):
     for g, c in pairs:
         R, t = mapalign.align(g, c, max_iter=30)
         one_by_one.append(transforms.rt_to_matrix(R, t))
-    for pipeline in (True, False):
-        Ts = mapalign.align_many(iter(pairs), max_iter=30, pipeline=pipeline)
+    for workers in (3, 2, 1):
+        Ts = mapalign.align_many(iter(pairs), max_iter=30, workers=workers)
         assert len(Ts) == len(pairs)
         for a, b in zip(Ts, one_by_one):
             assert np.array_equal(a, b)

@@ -6,10 +6,10 @@ from mapalign import synthetic as syn
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 base = [syn.make_pair(s, n)[:2] for s in range(3)]
 pairs = [base[k % 3] for k in range(24)]
-for pipeline in (False, True, False, True):
-    mapalign.align_many(pairs[:3], pipeline=pipeline)
+for workers in (1, 2, 3, 4, 1, 3):
+    mapalign.align_many(pairs[:4], workers=workers)
     t0 = time.perf_counter()
-    Ts = mapalign.align_many(pairs, pipeline=pipeline)
+    Ts = mapalign.align_many(pairs, workers=workers)
     dt = time.perf_counter() - t0
-    print("pipeline=%-5s %d pairs of %d points: %.2f ms per pair (%.0f pairs/s, %.0f ICP iterations/s incl. upload and grid build)"
-          % (pipeline, len(pairs), n, dt / len(pairs) * 1e3, len(pairs) / dt, 50 * len(pairs) / dt))
+    print("workers=%d %d pairs of %d points: %.2f ms per pair (%.0f pairs/s, %.0f ICP iterations/s incl. upload and grid build)"
+          % (workers, len(pairs), n, dt / len(pairs) * 1e3, len(pairs) / dt, 50 * len(pairs) / dt))
