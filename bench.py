@@ -171,7 +171,7 @@ def end_to_end(gold, comp, device):
         mapalign.align(g64, c64, max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
         f64_in.append((time.perf_counter() - t0) * 1e3)
     # a stream of pairs on this GPU (mapalign.align_many): three worker threads, one context each, take pairs as they finish
-    stream = [(gold, comp)] * 12
+    stream = [(gold, comp)] * 24
     mapalign.align_many(stream[:3], max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
     t0 = time.perf_counter()
     mapalign.align_many(stream, max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
@@ -284,13 +284,17 @@ def config_concurrent(gold, comp, device, R0):
 
     import mapalign
 
-    engs = []
-    for _ in range(4):
+    from mapalign import synthetic as syn
+
+    engs, truth = [], []
+    for k in range(4):                                   # four different pairs (seeds 0-3), as a fleet would hold
+        g, c, Rk, _ = (gold, comp, R0, None) if k == 0 else syn.make_pair(k, len(gold))
         e = mapalign.MapAligner(device)
-        e.set_gold(gold)
-        e.set_source(comp)
+        e.set_gold(g)
+        e.set_source(c)
         e.icp(ITERS, 0.0, GATE)
         engs.append(e)
+        truth.append(Rk)
     out, reps = {}, 20
     for K in (1, 2, 4):
         errs = [0.0] * K
@@ -298,7 +302,7 @@ def config_concurrent(gold, comp, device, R0):
         def work(i):
             for _ in range(reps):
                 r = engs[i].icp(ITERS, 0.0, GATE)
-            errs[i] = float(np.linalg.norm(r.R - R0))
+            errs[i] = float(np.linalg.norm(r.R - truth[i]))
 
         ths = [threading.Thread(target=work, args=(i,)) for i in range(K)]
         t0 = time.perf_counter()
