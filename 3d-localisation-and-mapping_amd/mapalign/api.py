@@ -121,7 +121,9 @@ def align_many(pairs, *, max_iter=DEFAULT_MAX_ITER, tol=DEFAULT_TOL, max_corr_di
     grid build included, 4.05 ms per pair one by one against ~2 ms with three workers
     (``tools/many_pairs.py``, ``tools/concurrent_pairs.py``).  Every pair is staged and iterated inside one
     context, so each result is exactly that of ``align`` on that pair.  ``pipeline=False`` (or
-    ``workers=1``) runs the pairs one after the other.
+    ``workers=1``) runs the pairs one after the other.  Consecutive pairs that share their gold
+    array OBJECT (``[(gold, s) for s in scans]``) re-use the indexed gold map of the worker's context
+    (do not modify such an array in place while the call runs).
     """
     seq = iter(pairs)
     workers = 1 if not pipeline else max(1, int(workers))
@@ -142,6 +144,7 @@ def align_many(pairs, *, max_iter=DEFAULT_MAX_ITER, tol=DEFAULT_TOL, max_corr_di
 
     def run(slot):
         eng, lock = cached_engine(device, slot)
+        held = None          # the gold array this worker's context currently holds (kept alive, compared by identity)
         while True:
             job = take()
             if job is None:
@@ -149,7 +152,10 @@ def align_many(pairs, *, max_iter=DEFAULT_MAX_ITER, tol=DEFAULT_TOL, max_corr_di
             i, (g, c) = job
             try:
                 with lock:
-                    eng.set_gold(g, cell)
+                    if g is not held:             # one gold map, many scans: every worker indexes it once
+                        held = None
+                        eng.set_gold(g, cell)
+                        held = g
                     eng.set_source(c)
                     results[i] = eng.icp(max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist).T
             except BaseException as e:      # reported below, for the first failing pair

@@ -171,7 +171,7 @@ def end_to_end(gold, comp, device):
         mapalign.align(g64, c64, max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
         f64_in.append((time.perf_counter() - t0) * 1e3)
     # a stream of pairs on this GPU (mapalign.align_many): three worker threads, one context each, take pairs as they finish
-    stream = [(gold, comp)] * 24
+    stream = [(gold.copy(), comp) for _ in range(24)]     # distinct gold objects: every pair builds its own grid
     mapalign.align_many(stream[:3], max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
     t0 = time.perf_counter()
     mapalign.align_many(stream, max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)

@@ -549,6 +549,13 @@ def test_align_many_pipelines_pairs_and_equals_align_pair_by_pair(lib_built):
         assert len(Ts) == len(pairs)
         for a, b in zip(Ts, one_by_one):
             assert np.array_equal(a, b)
+    # one gold map, many scans: the same gold OBJECT is indexed once per worker, results unchanged
+    g0 = pairs[0][0]
+    scans = [p[1] for p in pairs]
+    same_gold = mapalign.align_many([(g0, s) for s in scans], max_iter=30, workers=2)
+    for T, s in zip(same_gold, scans):
+        R, t = mapalign.align(g0, s, max_iter=30)
+        assert np.array_equal(T, transforms.rt_to_matrix(R, t))
     assert mapalign.align_many([], max_iter=5) == []
     # an error in one pair surfaces as that pair's exception and leaves the contexts usable
     bad = [pairs[0], (pairs[1][0], np.full((10, 3), np.nan, np.float32)), pairs[2]]
