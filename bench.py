@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--cell", type=float, default=0.0, help="grid cell edge (m); 0 = density-driven")
     ap.add_argument("--mode", choices=["pairs", "sharded"], default="pairs")
+    ap.add_argument("--pairs-per-gpu", type=int, default=1,
+                    help="alignments iterating at once on each GPU (separate contexts / streams / host threads); the headline "
+                         "metric is quoted at 1 — more is the fleet-throughput figure of configs.concurrent_pairs as a whole run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=ITERS, help="oracle iterations for parity_vs_cpu (default: all 50)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs.c3 / c4 / c5_per_gpu objects")
@@ -400,9 +403,24 @@ def main():
             return eng.icp_sharded(ITERS, 0.0, GATE)
     else:
         eng.set_source(comp)
+        K = max(1, args.pairs_per_gpu)
+        if K == 1:
+            def step():
+                return eng.icp(ITERS, 0.0, GATE)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            others = []
+            for k in range(1, K):                       # further pairs of this rank: other seeds, own contexts
+                gk, ck, _, _ = syn.make_pair(seed + 1000 * k, args.points)
+                ek = mapalign.MapAligner(local_rank)
+                ek.set_gold(gk, args.cell)
+                ek.set_source(ck)
+                others.append(ek)
+            pool = ThreadPoolExecutor(max_workers=K)
 
-        def step():
-            return eng.icp(ITERS, 0.0, GATE)
+            def step():
+                futs = [pool.submit(e.icp, ITERS, 0.0, GATE) for e in [eng] + others]
+                return [f.result() for f in futs][0]
 
     for _ in range(args.warmup):
         step()
@@ -416,7 +434,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    pairs_per_step = 1 if sharded else world
+    pairs_per_step = 1 if sharded else world * max(1, args.pairs_per_gpu)
     value = pairs_per_step * args.steps * ITERS / elapsed
 
     # ---- result check + fleet stats (outside the timed region) ---------------------------
@@ -509,6 +527,8 @@ def main():
             "config": {"workload": ("configs[1]: 1M-point synthetic cloud pair, 50 ICP iterations, 1xMI355X"
                                     if args.points == N_POINTS else
                                     f"{args.points}-point synthetic cloud pair (configs[1] at another size), 50 ICP iterations")
+                       + (f" - {args.pairs_per_gpu} independent pairs iterating at once per GPU (NOT the headline configuration)"
+                          if args.pairs_per_gpu > 1 and not sharded else "")
                        + ("" if world == 1 else f" - one pair per GPU x{world}" if not sharded
                           else f" - one pair sharded over {world} GPUs, RCCL all-reduce of 17 doubles/iteration inside the library"),
                        "points_gold": len(gold), "points_comparison": len(comp), "iterations_per_step": ITERS,
