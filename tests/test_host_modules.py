@@ -251,3 +251,53 @@ def test_detector_adaptor_rows_and_batched_lift_bookkeeping():
     f0 = min(out)
     assert np.allclose(b[0], np.array(fewer[f0][0][:4]) * 0.5)                # scale_bounding_box to depth resolution
     assert out[f0][0][4:] == fewer[f0][0][-3:]
+
+
+def test_align_many_scheduling_with_stand_in_contexts(monkeypatch):
+    """Host logic of mapalign.align_many without a GPU: results come back in input order whatever the
+    worker interleaving, a gold array shared by consecutive pairs is indexed once per worker, and the
+    first failing pair's exception is raised after the workers have stopped taking pairs."""
+    import threading
+    import time as _time
+    from types import SimpleNamespace
+
+    from mapalign import api
+
+    class FakeEngine:
+        def __init__(self):
+            self.gold_builds = 0
+            self.gold = self.src = None
+
+        def set_gold(self, g, cell):
+            self.gold_builds += 1
+            self.gold = g
+
+        def set_source(self, c):
+            if np.isnan(c).any():
+                raise ValueError("bad scan")
+            self.src = c
+
+        def icp(self, max_iter, tol, max_corr_dist):
+            _time.sleep(0.002 * float(self.src[0, 0] % 3))        # uneven durations: workers finish out of order
+            T = np.eye(4)
+            T[0, 3] = float(self.gold[0, 0]) + 10.0 * float(self.src[0, 0])
+            return SimpleNamespace(T=T)
+
+    fakes = {}
+    monkeypatch.setattr(api, "cached_engine", lambda device=0, slot=0: fakes.setdefault(slot, (FakeEngine(), threading.Lock())))
+    gold = np.full((4, 3), 7.0)
+    pairs = [(gold, np.full((2, 3), float(k))) for k in range(17)]
+    for workers in (1, 2, 3):
+        fakes.clear()
+        Ts = api.align_many(pairs, workers=workers)
+        assert [T[0, 3] for T in Ts] == [7.0 + 10.0 * k for k in range(17)]
+        assert len(fakes) == workers and all(e.gold_builds == 1 for e, _ in fakes.values())   # the shared gold: once per worker
+    fakes.clear()
+    distinct = [(gold.copy(), s) for _, s in pairs]
+    api.align_many(distinct, workers=2)
+    assert sum(e.gold_builds for e, _ in fakes.values()) == 17
+    bad = list(pairs)
+    bad[5] = (gold, np.full((2, 3), np.nan))
+    with pytest.raises(ValueError, match="bad scan"):
+        api.align_many(bad, workers=3)
+    assert api.align_many([], workers=3) == []
