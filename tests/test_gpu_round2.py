@@ -528,6 +528,10 @@ def test_alignment_gate_schedule_recovers_a_rough_coarse_start(lib_built):
     assert et1 > 0.2 and eR2 <= 1e-3 and et2 <= 5e-3, (eR1, et1, eR2, et2)
     assert [g for g, _, _ in info["gate_schedule"]] == [0.8, 0.4, 0.2]
     assert np.allclose(transforms.compose(stages), T_sched, atol=1e-9)
+    # the same schedule through align(): a start 5 degrees / 0.8 m off
+    R_a, t_a, info_a = mapalign.align(gold, comp, init=rough, gate_schedule=[(0.8, 15), (0.4, 15), (0.2, 15)], return_info=True)
+    eR3, et3 = orc.rt_error(R_a, t_a, R0, t0)
+    assert eR3 <= 1e-3 and et3 <= 5e-3 and len(info_a["gate_schedule"]) == 3
     # from the truth-adjacent start of the benchmark pair the schedule changes nothing that matters
     _, T_a, _ = mapalign.Alignment(coarse_stage=False, gate_schedule=None).align_clouds(gold, comp)
     _, T_b, _ = mapalign.Alignment(coarse_stage=False, gate_schedule=[(0.8, 15), (0.4, 15), (0.2, 15)]).align_clouds(gold, comp)
