@@ -176,9 +176,12 @@ def end_to_end(gold, comp, device):
     # a stream of pairs on this GPU (mapalign.align_many): three worker threads, one context each, take pairs as they finish
     stream = [(gold.copy(), comp) for _ in range(24)]     # distinct gold objects: every pair builds its own grid
     mapalign.align_many(stream[:3], max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
-    t0 = time.perf_counter()
-    mapalign.align_many(stream, max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
-    piped = (time.perf_counter() - t0) / len(stream) * 1e3
+    piped = []
+    for _ in range(3):                                   # (a run of 24 pairs varies by +-10 % with the workers' interleaving)
+        t0 = time.perf_counter()
+        mapalign.align_many(stream, max_iter=ITERS, tol=0.0, max_corr_dist=GATE, device=device)
+        piped.append((time.perf_counter() - t0) / len(stream) * 1e3)
+    piped = float(np.median(piped))
     # the reference's call shape (task_def.py:175-187): Alignment(...).compare() on two .ply files, the scan far off
     import tempfile
     from mapalign import ply, synthetic as syn
