@@ -570,3 +570,39 @@ def test_align_many_pipelines_pairs_and_equals_align_pair_by_pair(lib_built):
     out = mdist.align_pairs(pairs, max_iter=30, device=0)       # single process: all pairs, pipelined
     assert all(np.array_equal(a, b) for a, b in zip(out, one_by_one))
     mapalign.release_cached_engines()
+
+
+def test_icp_loop_fuzz_vs_oracle(engine):
+    """The whole loop (search, sums, solve, compose) against the oracle on 60 seeded cases: volumes, slabs,
+    clusters and carriage shells of 50-12 000 points, gates 0.03 m ... none, density-driven and fixed
+    cell edges, a third of the cases weighted; 6 iterations each."""
+    rng = np.random.default_rng(2027)
+    for case in range(60):
+        m, n = int(rng.integers(50, 12000)), int(rng.integers(50, 12000))
+        kind = case % 4
+        if kind == 0:
+            gold = rng.uniform(-1, 1, (m, 3)) * rng.uniform(0.3, 5.0, 3)
+        elif kind == 1:
+            gold = rng.uniform(-3, 3, (m, 3))
+            gold[:, rng.integers(0, 3)] *= 0.01
+        elif kind == 2:
+            c = rng.uniform(-2, 2, (max(m // 300, 2), 3))
+            gold = c[rng.integers(0, len(c), m)] + rng.normal(0, 0.05, (m, 3))
+        else:
+            gold = syn.sample_rectangles(syn.carriage_rectangles(rng), m, rng)
+        gold = gold.astype(np.float32)
+        near = gold[rng.integers(0, m, n)].astype(np.float64) + rng.normal(0, 0.003, (n, 3))
+        R0 = syn.rotation_about_axis(rng.normal(size=3), rng.uniform(0, 0.02))
+        t0 = rng.normal(0, 0.01, 3)
+        comp = ((near - t0) @ R0).astype(np.float32)
+        gate = [0.03, 0.1, 0.5, np.inf][int(rng.integers(0, 4))]
+        w = rng.uniform(0.1, 3.0, n).astype(np.float32) if case % 3 == 0 else None
+        cell = [0.0, 0.0, 0.02, 0.2, 1.5][int(rng.integers(0, 5))]
+        engine.set_gold(gold, cell)
+        engine.set_source(comp, w)
+        res = engine.icp(6, 0.0, gate)
+        ref = orc.icp_oracle(gold, comp, max_iter=6, max_corr_dist=gate, weights=w, n_jobs=4)
+        eR, et = orc.rt_error(res.R, res.t, ref["R"], ref["t"])
+        # (a tenth of the parity bars: with a 3 cm gate a few points sit within rounding of the gate and flip)
+        assert ref["ok"] and eR <= 1e-5 and et <= 1e-4, (case, kind, m, n, gate, cell, eR, et)
+        assert abs(res.inliers - ref["inliers"]) <= 1e-3 * max(ref["inliers"], 1.0), (case, res.inliers, ref["inliers"])
