@@ -126,7 +126,7 @@ def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0, bas
     cc, ac, _ = principal_frame(comp)
     rng = np.random.default_rng(seed)
     sub = comp if len(comp) <= sample else comp[rng.choice(len(comp), sample, replace=False)]
-    engine.set_source(sub.astype(np.float32))
+    engine.set_source(np.ascontiguousarray(sub))       # dtype kept: fp64 georeferenced coordinates are shifted before they become fp32
     base_traj, comp_traj = trajectory_xyz(base_pose_df), trajectory_xyz(comparison_pose_df)
     use_traj = base_traj is not None and comp_traj is not None
     scores, cloud_scores, traj_scores = [], [], []

@@ -606,3 +606,17 @@ def test_icp_loop_fuzz_vs_oracle(engine):
         # (a tenth of the parity bars: with a 3 cm gate a few points sit within rounding of the gate and flip)
         assert ref["ok"] and eR <= 1e-5 and et <= 1e-4, (case, kind, m, n, gate, cell, eR, et)
         assert abs(res.inliers - ref["inliers"]) <= 1e-3 * max(ref["inliers"], 1.0), (case, res.inliers, ref["inliers"])
+
+
+def test_alignment_adaptor_with_georeferenced_fp64_clouds(lib_built):
+    """The whole adaptor (coarse stage on a sub-sample, gate schedule, final loop) on UTM-like fp64
+    coordinates: every stage must work in the shifted frame; the scan starts 150 degrees / 8 m off."""
+    gold, comp, R0, t0 = syn.make_pair(19, 60_000, 50_000, angle_deg=150.0, t0=np.array([7.0, -4.0, 1.5]))
+    off = np.array([412_345.0, 5_234_567.0, 120.0])
+    g64, c64 = gold.astype(np.float64) + off, comp.astype(np.float64) + off
+    stages, T, info = mapalign.Alignment().align_clouds(g64, c64)
+    moved = c64[::53] @ T[:3, :3].T + T[:3, 3]
+    expect = comp[::53].astype(np.float64) @ R0.T + t0 + off
+    assert np.abs(moved - expect).max() < 0.02, np.abs(moved - expect).max()
+    assert np.allclose(transforms.compose(stages), T, atol=1e-6)
+    mapalign.release_cached_engines()
