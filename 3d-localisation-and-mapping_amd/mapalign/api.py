@@ -165,6 +165,11 @@ def align_many(pairs, *, max_iter=DEFAULT_MAX_ITER, tol=DEFAULT_TOL, max_corr_di
                 return
             i, (g, c) = job
             try:
+                if isinstance(g, GoldMap):        # a resident gold map brings its own context (its lock serialises its users)
+                    with g.lock:
+                        g.engine.set_source(c)
+                        results[i] = g.engine.icp(max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist).T
+                    continue
                 with lock:
                     if g is not held:             # one gold map, many scans: every worker indexes it once
                         held = None

@@ -560,6 +560,9 @@ def test_align_many_pipelines_pairs_and_equals_align_pair_by_pair(lib_built):
     for T, s in zip(same_gold, scans):
         R, t = mapalign.align(g0, s, max_iter=30)
         assert np.array_equal(T, transforms.rt_to_matrix(R, t))
+    with mapalign.GoldMap(g0) as gm:                       # a resident gold map in the stream: its own context is used
+        via_gm = mapalign.align_many([(gm, s) for s in scans[:3]], max_iter=30, workers=2)
+    assert all(np.array_equal(a, b) for a, b in zip(via_gm, same_gold[:3]))
     assert mapalign.align_many([], max_iter=5) == []
     # an error in one pair surfaces as that pair's exception and leaves the contexts usable
     bad = [pairs[0], (pairs[1][0], np.full((10, 3), np.nan, np.float32)), pairs[2]]
