@@ -28,7 +28,14 @@ Extra objects on the JSON line (all measured in this run, outside the timed regi
                  of the same 1M-point pair (north_star tolerance: 1e-4 Frobenius / 1 mm)
   configs        c3 (1280x960 depth frame -> fused unprojection -> 50 iterations against the
                  1M gold map), c4 (batch-32 detector inference on PyTorch-ROCm + one-call box
-                 lift), c5_per_gpu (a 2M-point pair, the per-GPU size of configs[4])
+                 lift), c5_per_gpu (a 2M-point pair, the per-GPU size of configs[4]),
+                 concurrent_pairs (1 / 2 / 4 independent alignments iterating at once on this GPU)
+  config.end_to_end_*  the drop-in call itself from host arrays (first / warm / fp64 / device-resident
+                 inputs / resident gold map / a stream of pairs through align_many) and the
+                 reference-shaped Alignment(...).compare() on two .ply files
+
+``--pairs-per-gpu K`` (default 1 = the headline configuration) runs the timed region with K independent
+pairs iterating at once on every GPU; stdout carries exactly ONE line (everything else goes to stderr).
 """
 import argparse
 import hashlib
