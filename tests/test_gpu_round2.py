@@ -427,6 +427,21 @@ def test_device_resident_inputs_match_host_inputs(engine):
         bad[5, 1] = np.nan
         engine.set_gold(bad)
 
+    # the fp64 entry points of the C ABI take device pointers too (here: torch float64 tensors)
+    import ctypes as C
+    g64_d, c64_d = g_d.double().contiguous(), c_d.double().contiguous()
+    torch.cuda.synchronize()
+    shift = np.zeros(3)
+    f64p = C.POINTER(C.c_double)
+    engine._chk(engine._lib.ma_set_gold_f64(engine._ctx, C.cast(C.c_void_p(g64_d.data_ptr()), f64p), len(gold), 0.0,
+                                            shift.ctypes.data_as(f64p)))
+    engine._chk(engine._lib.ma_set_source_f64(engine._ctx, C.cast(C.c_void_p(c64_d.data_ptr()), f64p), None, len(comp), None))
+    engine._shift, engine.n_gold, engine.n_source = shift, len(gold), len(comp)
+    raw64 = engine.icp(max_iter=30, tol=0.0, max_corr_dist=0.10)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    assert not shift.any() and np.array_equal(raw64.T, engine.icp(max_iter=30, tol=0.0, max_corr_dist=0.10).T)
+
     # depth frame on the device (float32 millimetres and uint16)
     depth, K, T = syn.make_depth_frame(0, width=320, height=240, fx=250.0, fy=250.0, cx=160.0, cy=120.0)
     engine.set_gold(gold)
