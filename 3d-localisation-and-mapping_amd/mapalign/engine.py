@@ -56,7 +56,9 @@ def _device_array(a, name, device, shape_tail, dtypes=("<f4",)):
         if a.device.index != device:
             raise ValueError(f"{name} lives on {a.device}, the context on device {device}")
         a = a.detach()
-        if a.is_floating_point() and a.dtype != torch.float32:
+        if a.is_floating_point() and a.dtype not in (torch.float32, torch.float64):
+            a = a.to(torch.float32)                      # half / bfloat16: widened on the device
+        elif a.dtype == torch.float64 and "<f8" not in dtypes:
             a = a.to(torch.float32)
         keep = a = a.contiguous()
         torch.cuda.current_stream(a.device).synchronize()
@@ -210,13 +212,19 @@ class MapAligner:
 
     # -- clouds ---------------------------------------------------------------------
     def set_gold(self, gold_cloud, cell=0.0):
-        """``gold_cloud``: [M,3] host array-like, or a float32 array already in this GPU's memory
-        (torch CUDA tensor / ``__cuda_array_interface__``) — then nothing crosses PCIe."""
-        dev = _device_array(gold_cloud, "gold_cloud", self.device, (3,))
+        """``gold_cloud``: [M,3] host array-like, or a float32 / float64 array already in this GPU's
+        memory (torch CUDA tensor / ``__cuda_array_interface__``) — then nothing crosses PCIe."""
+        dev = _device_array(gold_cloud, "gold_cloud", self.device, (3,), ("<f4", "<f8"))
         if dev is not None:
-            ptr, shape, _, _keep = dev
+            ptr, shape, typestr, _keep = dev
             self._shift = np.zeros(3)
-            self._chk(self._lib.ma_set_gold(self._ctx, C.cast(C.c_void_p(ptr), C.POINTER(C.c_float)), shape[0], float(cell)))
+            if typestr == "<f8":                         # fp64 on the device: bounds, shift and conversion there too
+                shift = np.zeros(3)
+                self._chk(self._lib.ma_set_gold_f64(self._ctx, C.cast(C.c_void_p(ptr), C.POINTER(C.c_double)), shape[0],
+                                                    float(cell), _f64p(shift)))
+                self._shift = shift
+            else:
+                self._chk(self._lib.ma_set_gold(self._ctx, C.cast(C.c_void_p(ptr), C.POINTER(C.c_float)), shape[0], float(cell)))
             self.n_gold = shape[0]
             self.n_source = 0
             return self.grid_info()
@@ -254,16 +262,19 @@ class MapAligner:
                 "build_ms": float(gi.build_ms)}
 
     def set_source(self, comparison_cloud, weights=None):
-        """``comparison_cloud`` / ``weights``: host array-likes or float32 arrays in this GPU's
-        memory (as in :meth:`set_gold`; a device cloud needs a gold map without a host-side
-        large-coordinate shift, i.e. one set from fp32 or device data)."""
+        """``comparison_cloud`` / ``weights``: host array-likes or arrays in this GPU's memory (as in
+        :meth:`set_gold`).  fp64 clouds, host or device, are shifted and converted on the device;
+        an fp32 DEVICE cloud cannot follow a gold map that needed a large-coordinate shift."""
         fp = C.POINTER(C.c_float)
-        dev = _device_array(comparison_cloud, "comparison_cloud", self.device, (3,))
+        dev = _device_array(comparison_cloud, "comparison_cloud", self.device, (3,), ("<f4", "<f8"))
+        f64 = False
         if dev is not None:
-            if np.any(self._shift != 0.0):
-                raise ValueError("a device-resident comparison cloud cannot be combined with a gold map that was "
-                                 "shifted on the host (coordinates above %g m given in fp64)" % LARGE_COORDINATE_M)
-            xyz_p, n, keep = C.cast(C.c_void_p(dev[0]), fp), dev[1][0], dev[3]
+            f64 = dev[2] == "<f8"
+            if not f64 and np.any(self._shift != 0.0):
+                raise ValueError("an fp32 device-resident comparison cloud cannot be combined with a gold map in a shifted "
+                                 "frame (coordinates above %g m given in fp64): pass it as fp64" % LARGE_COORDINATE_M)
+            xyz_p = C.cast(C.c_void_p(dev[0]), C.POINTER(C.c_double) if f64 else fp)
+            n, keep = dev[1][0], dev[3]
         else:
             raw = _check_cloud(comparison_cloud, "comparison_cloud")
             f64 = raw.dtype == np.float64 and raw.shape[0] > 0
@@ -283,7 +294,7 @@ class MapAligner:
                 w_p, nw = w.ctypes.data_as(fp), w.shape[0]
             if nw != n:
                 raise ValueError("weights must have one entry per comparison point")
-        if dev is None and f64:
+        if f64:
             self._chk(self._lib.ma_set_source_f64(self._ctx, xyz_p, w_p, n, _f64p(np.ascontiguousarray(self._shift))))
         else:
             self._chk(self._lib.ma_set_source(self._ctx, xyz_p, w_p, n))

@@ -442,6 +442,16 @@ def test_device_resident_inputs_match_host_inputs(engine):
     engine.set_source(comp)
     assert not shift.any() and np.array_equal(raw64.T, engine.icp(max_iter=30, tol=0.0, max_corr_dist=0.10).T)
 
+    # georeferenced fp64 tensors on the device: shifted and converted there, same bits as the host fp64 arrays
+    off = np.array([412_345.0, 5_234_567.0, 120.0])
+    gold_geo, comp_geo = gold.astype(np.float64) + off, comp.astype(np.float64) + off
+    R6, t6 = mapalign.align(torch.from_numpy(gold_geo).cuda(), torch.from_numpy(comp_geo).cuda(), max_iter=30)
+    R7, t7 = mapalign.align(gold_geo, comp_geo, max_iter=30)
+    assert np.array_equal(R6, R7) and np.array_equal(t6, t7)
+    with pytest.raises(ValueError):                      # an fp32 device scan cannot follow a gold map in a shifted frame
+        engine.set_gold(gold_geo)
+        engine.set_source(c_d)
+
     # depth frame on the device (float32 millimetres and uint16)
     depth, K, T = syn.make_depth_frame(0, width=320, height=240, fx=250.0, fy=250.0, cx=160.0, cy=120.0)
     engine.set_gold(gold)
