@@ -10,7 +10,8 @@ for k in range(4):
     g, c, R0, t0 = syn.make_pair(k, n)
     e = mapalign.MapAligner(0); e.set_gold(g); e.set_source(c); e.icp(50, 0.0, 0.10); engs.append((e, R0))
 reps = 20
-for K in (1, 2, 3, 4, 1, 2):
+Ks = [int(a) for a in sys.argv[2:]] or [1, 2, 3, 4, 1, 2]
+for K in Ks:
     errs = [0.0] * K
     def work(i):
         e, R0 = engs[i]
