@@ -162,4 +162,37 @@ inline void rank_groups_model(const uint32_t* cost, uint32_t ngroups, uint32_t* 
   }
 }
 
+// N4: the voxels of a map's bounding box.  The voxel of a point is floor(p * inv_voxel) per axis; keys
+// number the box's voxels z-major with indices relative to its first voxel, so the radix sort only looks at
+// `key_bits` bits.  Returns false when an index or the voxel count does not fit 63 bits.
+struct VoxelBox {
+  long long q0[3];              // first voxel index per axis
+  unsigned long long d[3];      // voxels per axis
+};
+inline bool voxel_box(const float lo[3], const float hi[3], float inv_voxel, VoxelBox& box, int& key_bits) {
+  long double cells = 1.0L;
+  for (int a = 0; a < 3; ++a) {
+    if (!(std::fabs(lo[a] * inv_voxel) < 4.0e18f) || !(std::fabs(hi[a] * inv_voxel) < 4.0e18f)) return false;
+    const long long q0 = (long long)std::floor(lo[a] * inv_voxel), q1 = (long long)std::floor(hi[a] * inv_voxel);
+    if (q1 < q0) return false;
+    box.q0[a] = q0;
+    box.d[a] = (unsigned long long)(q1 - q0) + 1ull;
+    cells *= (long double)box.d[a];
+  }
+  if (cells >= 9.0e18L) return false;
+  const unsigned long long last = box.d[0] * box.d[1] * box.d[2] - 1ull;
+  key_bits = 0;
+  while (key_bits < 64 && (last >> key_bits) != 0ull) ++key_bits;
+  key_bits = std::max(key_bits, 1);
+  return true;
+}
+
+// fp64 clouds: georeferenced coordinates (any |coordinate| above `large`) lose centimetres in fp32, so an
+// integer-metre shift to the box centre (half-to-even, as numpy.round) is taken out in fp64 first.
+inline void choose_shift(const double lo[3], const double hi[3], double large, double shift[3]) {
+  double big = 0.0;
+  for (int a = 0; a < 3; ++a) big = std::max({big, std::fabs(lo[a]), std::fabs(hi[a])});
+  for (int a = 0; a < 3; ++a) shift[a] = big > large ? std::nearbyint(0.5 * (lo[a] + hi[a])) : 0.0;
+}
+
 }  // namespace ma

@@ -1532,10 +1532,7 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
 // (anchored at the map origin); the key numbers the voxels of the map's bounding box z-major,
 // (vz * dims.y + vy) * dims.x + vx with indices relative to the box's first voxel, so that the
 // radix sort only has to look at the ~30 bits a real map uses instead of 63.
-struct VoxelBox {
-  long long q0[3];              // first voxel index per axis
-  unsigned long long d[3];      // voxels per axis
-};
+using ma::VoxelBox;              // csrc/host_math.h (its arithmetic is host code, tested under sanitizers)
 __global__ __launch_bounds__(kBlock) void k_voxel_keys(const float4* __restrict__ pts, uint32_t n, float inv_voxel,
                                                        const VoxelBox box, unsigned long long* __restrict__ keys,
                                                        uint32_t* __restrict__ vals) {
@@ -2612,16 +2609,13 @@ static int stage_f64(ma_ctx* ctx, const double* xyz, uint32_t n, bool choose_shi
     std::vector<double> h((size_t)nb * 8);
     HIPCHK(hipMemcpyAsync(h.data(), ctx->misc.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, bad = 0, big = 0;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, bad = 0;
     for (int b = 0; b < nb; ++b) {
       for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], h[(size_t)b * 8 + a]); hi[a] = std::max(hi[a], h[(size_t)b * 8 + 3 + a]); }
       bad += h[(size_t)b * 8 + 6];
     }
     if (bad > 0) return ctx->fail(MA_ERR_INVALID, "cloud has non-finite coordinates (filter them first, as the reference's read_point_cloud(remove_nan_points=True, remove_infinite_points=True) does)");
-    for (int a = 0; a < 3; ++a) big = std::max({big, std::fabs(lo[a]), std::fabs(hi[a])});
-    // georeferenced coordinates lose centimetres in fp32: an integer-metre shift (half-to-even, as
-    // numpy.round) to the box centre is taken out in fp64 first
-    for (int a = 0; a < 3; ++a) shift[a] = big > MA_LARGE_COORDINATE_M ? std::nearbyint(0.5 * (lo[a] + hi[a])) : 0.0;
+    ma::choose_shift(lo, hi, MA_LARGE_COORDINATE_M, shift);   // integer-metre shift for georeferenced coordinates
   }
   const uint64_t n3 = 3ull * n;
   hipLaunchKernelGGL(k_f64_to_raw, dim3((uint32_t)((n3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
@@ -2766,21 +2760,8 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
   const float inv_voxel = 1.0f / ctx->map_voxel;
   VoxelBox box;
   int key_bits = 0;
-  {
-    long double cells = 1.0L;
-    for (int a = 0; a < 3; ++a) {
-      if (!(std::fabs(lo[a] * inv_voxel) < 4.0e18f) || !(std::fabs(hi[a] * inv_voxel) < 4.0e18f))
-        return ctx->fail(MA_ERR_TOO_LARGE, "voxel indices of the map do not fit 63 bits (coordinates / voxel too large)");
-      const long long q0 = (long long)floorf(lo[a] * inv_voxel), q1 = (long long)floorf(hi[a] * inv_voxel);
-      box.q0[a] = q0;
-      box.d[a] = (unsigned long long)(q1 - q0 + 1);
-      cells *= (long double)box.d[a];
-    }
-    if (cells >= 9.0e18L) return ctx->fail(MA_ERR_TOO_LARGE, "the map's bounding box holds 2^63 or more voxels");
-    const unsigned long long last = box.d[0] * box.d[1] * box.d[2] - 1ull;
-    while (key_bits < 64 && (last >> key_bits) != 0ull) ++key_bits;
-    key_bits = std::max(key_bits, 1);
-  }
+  if (!ma::voxel_box(lo, hi, inv_voxel, box, key_bits))
+    return ctx->fail(MA_ERR_TOO_LARGE, "the voxel indices of the map's bounding box do not fit 63 bits (coordinates / voxel too large)");
   hipLaunchKernelGGL(k_voxel_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->map_pts.as<float4>(), n,
                      inv_voxel, box, ctx->map_keys_a.as<unsigned long long>(), ctx->vals_a.as<uint32_t>());
   HIPCHK(hipGetLastError());

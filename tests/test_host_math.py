@@ -131,6 +131,31 @@ int main() {
     std::printf("kabsch %d %d %d %.6f %.6f %.6f %.3e\n", rc_empty, rc_one, rc_w, dt[0], dt[1], dt[2],
                 std::fabs(dR[0] - 1) + std::fabs(dR[4] - 1) + std::fabs(dR[8] - 1));
   }
+  // ---- N4 voxel box: key width, negative coordinates, a single voxel, and the 63-bit refusals
+  {
+    const float lo[3] = {-3.2f, 0.01f, -0.7f}, hi[3] = {17.4f, 2.99f, 2.41f};
+    ma::VoxelBox b; int bits = 0;
+    const bool ok = ma::voxel_box(lo, hi, 1.0f / 0.02f, b, bits);
+    std::printf("voxbox %d %lld %lld %lld %llu %llu %llu %d\n", ok ? 1 : 0, b.q0[0], b.q0[1], b.q0[2], b.d[0], b.d[1], b.d[2], bits);
+    const float p[3] = {1.234f, 1.234f, 1.234f};
+    ma::VoxelBox b1; int bits1 = 0;
+    const bool ok1 = ma::voxel_box(p, p, 50.0f, b1, bits1);
+    const float big_lo[3] = {-3e30f, 0.f, 0.f}, big_hi[3] = {3e30f, 1.f, 1.f};
+    const float wide_lo[3] = {-4e6f, -4e6f, -4e6f}, wide_hi[3] = {4e6f, 4e6f, 4e6f};
+    ma::VoxelBox b2; int bits2 = 0;
+    const bool refuse_index = !ma::voxel_box(big_lo, big_hi, 50.0f, b2, bits2);
+    const bool refuse_count = !ma::voxel_box(wide_lo, wide_hi, 1.0f, b2, bits2);   // 8e6^3 = 5.1e20 voxels
+    std::printf("voxedge %d %llu %d %d %d\n", ok1 ? 1 : 0, b1.d[0] * b1.d[1] * b1.d[2], bits1, refuse_index ? 1 : 0, refuse_count ? 1 : 0);
+  }
+  // ---- large-coordinate shift of fp64 clouds: none below the threshold, box centre rounded half-to-even above it
+  {
+    const double lo_s[3] = {-10.0, 2.0, 0.0}, hi_s[3] = {999.0, 3.0, 1.0};
+    const double lo_g[3] = {412340.0, 5234560.5, 118.0}, hi_g[3] = {412351.0, 5234574.5, 123.0};
+    double s0[3], s1[3];
+    ma::choose_shift(lo_s, hi_s, 1000.0, s0);
+    ma::choose_shift(lo_g, hi_g, 1000.0, s1);
+    std::printf("shift %.1f %.1f %.1f %.1f %.1f %.1f\n", s0[0], s0[1], s0[2], s1[0], s1[1], s1[2]);
+  }
   return 0;
 }
 """
@@ -192,3 +217,17 @@ def test_kabsch_degeneracy_is_rank_not_weight_sum(report):
     assert int(rc_empty) == 1 and int(rc_one) == 1      # no weight / a single pair: degenerate
     assert int(rc_w) == 0                                # 1000 pairs whose weights sum to 1e-3: fine
     assert np.allclose([float(tx), float(ty), float(tz)], [0.5, -0.25, 0.125], atol=1e-9) and float(rot) < 1e-9
+
+
+def test_voxel_box_and_large_coordinate_shift(report):
+    ok, q0x, q0y, q0z, dx, dy, dz, bits = (int(v) for v in report["voxbox"][0])
+    inv = np.float32(1.0) / np.float32(0.02)
+    lo, hi = np.float32([-3.2, 0.01, -0.7]), np.float32([17.4, 2.99, 2.41])
+    q0, q1 = np.floor(lo * inv).astype(np.int64), np.floor(hi * inv).astype(np.int64)
+    assert ok == 1 and [q0x, q0y, q0z] == list(q0) and [dx, dy, dz] == list(q1 - q0 + 1)
+    assert bits == int(dx * dy * dz - 1).bit_length()
+    one_ok, one_cells, one_bits, refuse_index, refuse_count = (int(v) for v in report["voxedge"][0])
+    assert (one_ok, one_cells, one_bits, refuse_index, refuse_count) == (1, 1, 1, 1, 1)
+    s = [float(v) for v in report["shift"][0]]
+    assert s[:3] == [0.0, 0.0, 0.0]
+    assert s[3:] == [float(np.round(0.5 * (412340.0 + 412351.0))), float(np.round(0.5 * (5234560.5 + 5234574.5))), float(np.round(120.5))]
