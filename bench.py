@@ -10,13 +10,19 @@ and the gold grid are resident in HBM before the timed region (grid build and th
 PCIe-inclusive end-to-end time are reported separately in ``config``).  ``value`` =
 iterations of all ranks / wall time.
 
-N > 1 (launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py
---gpus N``): pair-per-GPU, the way the path shards — every rank aligns its
-own 1M-point pair (seed = rank) with no collective inside the loop; weak scaling.  The
-timed region is bracketed by barrier + synchronize and the MAX over ranks is taken (RCCL).
-``--mode sharded`` instead spreads ONE pair over the ranks: the per-iteration all-reduce of
-the 17-double accumulator runs INSIDE libmapalign (``ma_icp_sharded``: ncclAllReduce on the
-library's stream, loop in C; strong scaling; not the driver's default).
+N > 1: pair-per-GPU, the way the path shards — every rank aligns its own
+1M-point pair (seed = rank) with no collective inside the loop; weak scaling.  The timed
+region is bracketed by barrier + synchronize and the MAX over ranks is taken (RCCL).  Either
+launch it as ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` or
+just as ``python bench.py --gpus N``: without WORLD_SIZE in the environment the script starts
+that launcher itself as a CHILD process (before anything touches a GPU), relays rank 0's JSON
+line and exits with the child's return code.
+The same N > 1 run then times a second region in the same processes and reports it as
+``"sharded"`` beside the headline: ONE 1M-point pair spread over the ranks (gold map
+replicated, comparison cloud block-partitioned), the per-iteration all-reduce of the 17-double
+accumulator INSIDE libmapalign (``ma_icp_sharded``: ncclAllReduce on the library's stream, loop
+in C; strong scaling) — the second curve of SURVEY.md §8e.  ``--mode sharded`` makes that
+region the headline instead.
 
 Extra objects on the JSON line (all measured in this run, outside the timed region):
   roofline       k_nn_accum (the NN-correspondence kernel): algorithmic bytes per launch
@@ -76,6 +82,44 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--force-device", type=int, default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def launcher_command(args_list, n_gpus, port):
+    """The driver's own spelling of an N-GPU run (one rank per GPU over RCCL)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(args_list)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args_list, n_gpus, command=None):
+    """``python bench.py --gpus N`` from a plain shell: run the N ranks as a child process (never
+    an exec: this process may not replace itself once anything has touched the GPU, and a child
+    keeps the rule simple), relay the ONE JSON line of rank 0 and return the child's code."""
+    import subprocess
+
+    cmd = command or launcher_command(args_list, n_gpus, free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL across processes)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in proc.stdout.decode("utf-8", "replace").splitlines():
+        if raw.startswith("{") and '"metric"' in raw:
+            line = raw
+        else:
+            print(raw, file=sys.stderr)
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    elif proc.returncode == 0:
+        print("bench.py: the ranks ended without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
 
 
 def kernel_source_sha():
@@ -351,8 +395,67 @@ def config_c5(eng, seed=0):
             "final_error_vs_truth": {"R_fro": float(np.linalg.norm(res.R - R0)), "t_m": float(np.linalg.norm(res.t - t0))}}
 
 
+def sharded_region(args, world, rank, local_rank, barrier, dist, torch):
+    """ONE 1M-point pair (seed 0 on every rank) over all ranks through ma_icp_sharded, timed like
+    the headline region.  Every rank returns the same dict; a failure anywhere is agreed on by all
+    ranks BEFORE anyone enters a collective of the library, so no rank is left waiting."""
+    import mapalign
+    from mapalign import dist as mdist
+    from mapalign import synthetic as syn
+
+    dev = f"cuda:{local_rank}"
+
+    def all_ok(flag):
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item()) >= 1.0
+
+    if args.backend != "nccl":
+        return {"skipped": "single-GPU rehearsal over gloo: RCCL cannot join two ranks that share one device"}
+    eng, err = None, None
+    try:
+        gold, comp, R0, t0 = syn.make_pair(0, args.points)
+        lo, hi = mdist.shard_bounds(len(comp), world, rank)
+        eng = mapalign.MapAligner(local_rank)
+        eng.set_gold(gold, args.cell)
+        eng.set_source(comp[lo:hi])
+        eng.comm_unique_id()                 # can this rank reach librccl at all?
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    if not all_ok(err is None):
+        if eng is not None:
+            eng.close()
+        return {"error": err or "another rank could not stage its shard / load librccl"}
+    try:
+        mdist.bootstrap_comm(eng)
+        for _ in range(args.warmup):
+            out = eng.icp_sharded(ITERS, 0.0, GATE)
+        barrier()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            out = eng.icp_sharded(ITERS, 0.0, GATE)
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        res = {"value": args.steps * ITERS / elapsed, "unit": "ICP iterations/s", "ms_per_step": elapsed / args.steps * 1e3,
+               "scaling": "strong", "workload": f"ONE {args.points}-point pair, comparison cloud block-partitioned over {world} GPUs, "
+                                               f"gold map replicated, 50 iterations",
+               "library_rccl": "ma_icp_sharded: ncclAllReduce(17 x f64) per iteration inside libmapalign",
+               "final_error_vs_truth": {"R_fro": float(np.linalg.norm(out.R - R0)), "t_m": float(np.linalg.norm(out.t - t0))}}
+        eng.comm_destroy()
+    except Exception as e:       # pragma: no cover - depends on the node
+        res = {"error": f"{type(e).__name__}: {e}"}
+    eng.close()
+    return res
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher's parent before torch or libmapalign is loaded
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes its version
     # banner to stdout when a communicator is created), so everything but that line is sent to
     # stderr: fd 1 is pointed at fd 2 for the run and the line goes to the saved descriptor.
@@ -363,9 +466,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node "
-                             f"{args.gpus} --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus {args.gpus}")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
@@ -479,6 +579,11 @@ def main():
         else:
             err = eng.comm_allreduce(err, "max")
 
+    # ---- the second curve of SURVEY.md 8e in the same run: one pair sharded over all ranks ----
+    sharded_leg = None
+    if world > 1 and not sharded:
+        sharded_leg = sharded_region(args, world, rank, local_rank, barrier, dist, torch)
+
     line = None
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live (untimed extra passes) -----
@@ -551,6 +656,8 @@ def main():
         }
         if e2e:
             line["config"].update(e2e)
+        if sharded_leg is not None:
+            line["sharded"] = sharded_leg
         if cpu:
             line["speedup_vs_cpu_baseline"] = value / cpu["value"]
         if extra:

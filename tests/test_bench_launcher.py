@@ -1,0 +1,49 @@
+"""`python bench.py --gpus N` from a plain shell starts the N ranks itself:
+command construction and return-code / result-line relay of the launcher, on the CPU."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+import bench
+
+
+def test_launcher_command_is_the_drivers_spelling():
+    cmd = bench.launcher_command(["--gpus", "8", "--steps", "5", "--warmup", "1"], 8, 29555)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "1"]      # the caller's arguments, unchanged
+    assert 0 < bench.free_port() < 65536
+
+
+def test_self_launch_relays_one_line_and_the_childs_return_code(capfd):
+    child = [sys.executable, "-c",
+             "import sys; print('RCCL banner'); print('{\"metric\": \"m\", \"n_gpus\": 2}'); sys.exit(0)"]
+    assert bench.self_launch([], 2, command=child) == 0
+    out, err = capfd.readouterr()
+    assert out.count("\n") == 1 and json.loads(out)["n_gpus"] == 2      # exactly ONE line on stdout
+    assert "RCCL banner" in err                                         # everything else goes to stderr
+    failing = [sys.executable, "-c", "import sys; sys.exit(7)"]
+    assert bench.self_launch([], 2, command=failing) == 7
+    silent = [sys.executable, "-c", "pass"]
+    assert bench.self_launch([], 2, command=silent) == 1               # rc 0 without a result line is a failure
+
+
+def test_plain_shell_run_with_gpus_2_goes_through_the_launcher_before_any_gpu_use():
+    """End to end on the CPU box: the child ranks start (gloo rendezvous), find no GPU and stop with the
+    product's own message; the parent reports their failure instead of raising the old
+    'launch with: python -m torch.distributed.run' SystemExit."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--force-device", "0",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra-configs", "--points", "2000"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    err = p.stderr.decode("utf-8", "replace")
+    assert "launch with: python -m torch.distributed.run" not in err
+    if p.returncode != 0:            # no GPU here: the ranks say so themselves
+        assert "needs an MI355X" in err or "no HIP device" in err or "No HIP GPUs" in err, err[-2000:]
+    else:                            # on a GPU box the same command yields the line
+        assert json.loads(p.stdout.decode().strip().splitlines()[-1])["n_gpus"] == 2
