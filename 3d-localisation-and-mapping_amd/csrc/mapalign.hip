@@ -1812,6 +1812,7 @@ struct ma_ctx {
   uint32_t last_gshift = 0;
   std::vector<hipEvent_t> kev;   // MA_FLAG_TIME_KERNELS
   double ktimes[4] = {0, 0, 0, 0};
+  std::vector<float> iter_ms;    // MA_FLAG_TIME_KERNELS: per iteration {search launch, reduce + solve launch}
 
   int fail(int code, const std::string& msg) {
     err = msg;
@@ -2939,10 +2940,13 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   if (timek) {
     ctx->ktimes[0] = ctx->ktimes[1] = ctx->ktimes[2] = ctx->ktimes[3] = 0;
+    ctx->iter_ms.clear();
     for (int k = 0; k < s.iter && k < params->max_iter; ++k) {   // launches after `done` are no-ops: skip them
       float a = 0, b = 0;
       HIPCHK(hipEventElapsedTime(&a, ctx->kev[2 * k], ctx->kev[2 * k + 1]));
       HIPCHK(hipEventElapsedTime(&b, ctx->kev[2 * k + 1], ctx->kev[2 * k + 2]));
+      ctx->iter_ms.push_back(a);
+      ctx->iter_ms.push_back(b);
       ctx->ktimes[0] += a; ctx->ktimes[1] += 1;
       ctx->ktimes[2] += b; ctx->ktimes[3] += 1;
     }
@@ -2996,6 +3000,13 @@ int ma_get_kernel_times(ma_ctx* ctx, double out[4]) {
   if (!ctx || !out) return MA_ERR_INVALID;
   for (int i = 0; i < 4; ++i) out[i] = ctx->ktimes[i];
   return MA_OK;
+}
+
+int ma_get_iteration_times(ma_ctx* ctx, float* out, int max_iterations) {
+  if (!ctx || !out || max_iterations < 0) return MA_ERR_INVALID;
+  const int n = std::min<int>(max_iterations, (int)(ctx->iter_ms.size() / 2));
+  for (int i = 0; i < 2 * n; ++i) out[i] = ctx->iter_ms[(size_t)i];
+  return n;
 }
 
 int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16], double acc_out[MA_ACC_LEN],

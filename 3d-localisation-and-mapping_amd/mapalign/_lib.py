@@ -98,6 +98,7 @@ ABI = {
     "ma_icp": (C.c_int, [_ctx_p, C.POINTER(ma_params), _f64p, _f64p, C.POINTER(ma_stats)]),
     "ma_get_trace": (C.c_int, [_ctx_p, _f64p, C.c_int]),
     "ma_get_kernel_times": (C.c_int, [_ctx_p, _f64p]),
+    "ma_get_iteration_times": (C.c_int, [_ctx_p, _f32p, C.c_int]),
     "ma_icp_step": (C.c_int, [_ctx_p, C.POINTER(ma_params), _f64p, _f64p, _f64p]),
     "ma_nn": (C.c_int, [_ctx_p, _f64p, C.c_double, _u32p, _f32p]),
     "ma_state_set": (C.c_int, [_ctx_p, _f64p]),

@@ -444,6 +444,12 @@ class MapAligner:
         self._chk(self._lib.ma_get_kernel_times(self._ctx, _f64p(out)))
         return {"nn_ms": out[0], "nn_launches": int(out[1]), "solve_ms": out[2], "solve_launches": int(out[3])}
 
+    def iteration_times(self, max_iterations=4096):
+        """[iterations, 2] milliseconds of the last icp(time_kernels=True): search launch, reduce + solve launch."""
+        buf = np.zeros((max(int(max_iterations), 1), 2), dtype=np.float32)
+        n = self._chk(self._lib.ma_get_iteration_times(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.shape[0]))
+        return buf[:n].astype(np.float64)
+
     def trace(self, max_rows=4096):
         buf = np.zeros((max(int(max_rows), 1), MA_TRACE_STRIDE), dtype=np.float64)
         rows = self._chk(self._lib.ma_get_trace(self._ctx, _f64p(buf), buf.shape[0]))

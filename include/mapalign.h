@@ -211,6 +211,9 @@ int ma_get_trace(ma_ctx* ctx, double* out, int max_rows);
 /* Per-kernel device time of the last ma_icp run with MA_FLAG_TIME_KERNELS:
  * out = {nn_accum total ms, nn_accum launches, reduce_solve total ms, reduce_solve launches}. */
 int ma_get_kernel_times(ma_ctx* ctx, double out[4]);
+/* The same run, per iteration: out[2k] = ms of iteration k's search launch, out[2k+1] = ms of its
+ * reduce + solve launch.  Returns the number of iterations written (<= max_iterations). */
+int ma_get_iteration_times(ma_ctx* ctx, float* out, int max_iterations);
 
 /* One iteration at transform T_in (NULL = identity): accumulators (world frame) and the
  * updated transform.  For parity tests (rows a4-a6). */
