@@ -1687,6 +1687,21 @@ __global__ __launch_bounds__(kBlock) void k_uncentre(const float4* __restrict__ 
   xyz[3 * (size_t)i + 2] = (float)((double)s.z + o2);
 }
 
+// The stored coordinates as the search sees them, exactly: world = fp32 (centred) + origin, evaluated in
+// fp64 (exact: both terms are fp32 numbers), written in the CALLER's order (perm: sorted position ->
+// original index; null = storage order is the caller's order).
+__global__ __launch_bounds__(kBlock) void k_export_f64(const float4* __restrict__ pts, const uint32_t* __restrict__ perm,
+                                                       uint32_t n, double o0, double o1, double o2,
+                                                       double* __restrict__ xyz) {
+  const uint32_t pos = blockIdx.x * kBlock + threadIdx.x;
+  if (pos >= n) return;
+  const float4 p = pts[pos];
+  const size_t i = perm ? perm[pos] : pos;
+  xyz[3 * i] = (double)p.x + o0;
+  xyz[3 * i + 1] = (double)p.y + o1;
+  xyz[3 * i + 2] = (double)p.z + o2;
+}
+
 // out[perm[pos]] = in[pos] (undo the source cell sort for ma_nn)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_unpermute(const T* __restrict__ in,
@@ -2881,6 +2896,36 @@ int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   *n = ctx->n;
   return MA_OK;
+  });
+}
+
+static int export_stored(ma_ctx* ctx, const float4* pts, const uint32_t* perm, uint32_t count, double* xyz_out, uint64_t* n) {
+  if (!xyz_out) { *n = count; return MA_OK; }
+  if (*n < count) { *n = count; return ctx->fail(MA_ERR_INVALID, "output capacity too small"); }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(ctx->raw64.ensure((size_t)count * 24));
+  hipLaunchKernelGGL(k_export_f64, dim3(div_up(count, kBlock)), dim3(kBlock), 0, ctx->stream, pts, perm, count,
+                     ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->raw64.as<double>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(xyz_out, ctx->raw64.p, (size_t)count * 24, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *n = count;
+  return MA_OK;
+}
+
+int ma_get_gold(ma_ctx* ctx, double* xyz_out, uint64_t* n) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx || !n) return MA_ERR_INVALID;
+  if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "gold map not set");
+  return export_stored(ctx, ctx->gold[0].as<float4>(), ctx->perm0.as<uint32_t>(), ctx->m, xyz_out, n);
+  });
+}
+
+int ma_get_source_stored(ma_ctx* ctx, double* xyz_out, uint64_t* n) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx || !n) return MA_ERR_INVALID;
+  if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set");
+  return export_stored(ctx, ctx->src.as<float4>(), ctx->src_sorted ? ctx->src_perm.as<uint32_t>() : nullptr, ctx->n, xyz_out, n);
   });
 }
 

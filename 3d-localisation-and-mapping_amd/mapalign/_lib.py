@@ -95,6 +95,8 @@ ABI = {
     "ma_lift_boxes": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p, _f64p, C.c_float, _f32p,
                                 C.c_uint64, _f64p, C.POINTER(C.c_uint8)]),
     "ma_get_source": (C.c_int, [_ctx_p, _f32p, _u64p]),
+    "ma_get_gold": (C.c_int, [_ctx_p, _f64p, _u64p]),
+    "ma_get_source_stored": (C.c_int, [_ctx_p, _f64p, _u64p]),
     "ma_icp": (C.c_int, [_ctx_p, C.POINTER(ma_params), _f64p, _f64p, C.POINTER(ma_stats)]),
     "ma_get_trace": (C.c_int, [_ctx_p, _f64p, C.c_int]),
     "ma_get_kernel_times": (C.c_int, [_ctx_p, _f64p]),

@@ -145,7 +145,8 @@ def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0, bas
         scores.append(float(np.hypot(cloud, traj)))
     best = int(np.argmin(scores))
     R = cands[best]
-    stages = [(R, cc), transforms.rt_to_matrix(np.eye(3), cg - cc)]
+    # (a stage next to a half turn becomes two of half the angle: the visualiser's logm needs the principal branch)
+    stages = transforms.split_half_turns([(R, cc)]) + [transforms.rt_to_matrix(np.eye(3), cg - cc)]
     return stages, transforms.compose(stages), {"scores": scores, "cloud_scores": cloud_scores,
                                                 "trajectory_scores": traj_scores if use_traj else None,
                                                 "chosen": best, "truncate_m": truncate}

@@ -425,6 +425,22 @@ class MapAligner:
         self._chk(self._lib.ma_get_source(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
         return out if not np.any(self._shift != 0.0) else out.astype(np.float64) + self._shift
 
+    def _stored(self, fn):
+        n = C.c_uint64(0)
+        self._chk(fn(self._ctx, None, C.byref(n)))
+        out = np.empty((int(n.value), 3), dtype=np.float64)
+        self._chk(fn(self._ctx, _f64p(out), C.byref(n)))
+        return out + self._shift
+
+    def get_gold(self):
+        """The gold map as the device stores it (fp32 about the centring origin), exactly, in fp64 and
+        in the caller's order: what the nearest-neighbour search compares against."""
+        return self._stored(self._lib.ma_get_gold)
+
+    def get_source_stored(self):
+        """The comparison cloud as stored (see :meth:`get_gold`), caller's order."""
+        return self._stored(self._lib.ma_get_source_stored)
+
     # -- the loop -------------------------------------------------------------------
     def icp(self, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None, count_work=False, with_trace=False,
             time_kernels=False):

@@ -43,6 +43,58 @@ def compose(transformations):
     return T
 
 
+def axis_angle(R):
+    """Rotation matrix -> (unit axis, angle in [0, pi]).  Robust at both ends: the skew part gives
+    the axis while sin(angle) is not tiny; next to a half turn, where it vanishes, the symmetric
+    part does (R + I = 2 n n^T at angle pi)."""
+    R = np.asarray(R, dtype=np.float64)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s, c = 0.5 * np.linalg.norm(v), 0.5 * (np.trace(R) - 1.0)
+    angle = float(np.arctan2(s, c))
+    if s > 1e-6:
+        return v / (2.0 * s), angle
+    if c > 0.0:                                   # (almost) the identity: any axis
+        return np.array([0.0, 0.0, 1.0]), angle
+    M = 0.5 * (R + np.eye(3))                     # ~ n n^T
+    n = M[:, int(np.argmax(np.diag(M)))]
+    n = n / np.linalg.norm(n)
+    if np.dot(n, v) < 0.0:                        # keep the sense of rotation the skew part still shows
+        n = -n
+    return n, angle
+
+
+def rotation_from_axis_angle(axis, angle):
+    a = np.asarray(axis, dtype=np.float64)
+    a = a / np.linalg.norm(a)
+    K = np.array([[0.0, -a[2], a[1]], [a[2], 0.0, -a[0]], [-a[1], a[0], 0.0]])
+    return np.eye(3) + np.sin(angle) * K + (1.0 - np.cos(angle)) * (K @ K)
+
+
+HALF_TURN_MARGIN = 1e-3     # radians
+
+
+def split_half_turns(transformations, margin=HALF_TURN_MARGIN):
+    """The reference's visualiser replays a ``(R, centre)`` stage as 20 steps of
+    ``expm(logm(R) / 20)`` (``src/map_alignment/visualise.py:109-126``).  The matrix logarithm of a
+    rotation by pi is not real (eigenvalue -1 twice; scipy returns a complex matrix), and a coarse
+    stage built from principal axes produces exact half turns whenever the two frames differ by a
+    sign pattern only.  A stage within ``margin`` of a half turn is therefore emitted as TWO tuples of
+    half the angle about the same axis and centre — same composition, and each logarithm on the
+    principal branch with room to spare."""
+    out = []
+    for tr in transformations:
+        if isinstance(tr, tuple):
+            R, c = tr
+            axis, angle = axis_angle(R)
+            if angle > np.pi - margin:
+                Rh = rotation_from_axis_angle(axis, 0.5 * angle)
+                # second half = R Rh^T, so that the two compose to R exactly as given (not to a re-derived rotation)
+                out.extend([(Rh, np.array(c, dtype=np.float64)), (np.asarray(R, dtype=np.float64) @ Rh.T, np.array(c, dtype=np.float64))])
+                continue
+        out.append(tr)
+    return out
+
+
 def apply(T, points):
     """Row-vector form of ``(T @ [p,1])[:3]`` (``pose_processor.py:254-260``)."""
     T = to_matrix(T)

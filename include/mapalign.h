@@ -198,6 +198,17 @@ int ma_lift_boxes_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int wi
  * points, out = points written.  For parity tests of the unprojection kernel. */
 int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n);
 
+/* The clouds AS STORED — what the nearest-neighbour search (row a4) actually compares: every coordinate
+ * is kept as fp32 relative to the centring origin of the gold map, so the stored point is
+ * world = fp32(x - origin) + origin, returned here in fp64 (exact) and in the CALLER's order (the
+ * order of the arrays given to ma_set_gold / ma_set_source; pixel order of the valid pixels for a cloud
+ * made from a depth frame).  An oracle run on these arrays sees bit for bit the device's inputs, so its
+ * nearest-neighbour indices must equal ma_nn's except between candidates whose fp32 distances tie
+ * (tests/test_gpu_parity.py: assert_nn_exact_on_stored).  xyz_out == NULL only queries the count;
+ * *n: in = capacity in points, out = points written. */
+int ma_get_gold(ma_ctx* ctx, double* xyz_out, uint64_t* n);
+int ma_get_source_stored(ma_ctx* ctx, double* xyz_out, uint64_t* n);
+
 /* Rows a4-a7: the whole ICP loop on the device.  init = NULL means identity.
  * T_out receives the composed comparison->gold transform. */
 int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16],

@@ -38,8 +38,59 @@ def assert_nn_matches(idx, d2, oidx, od2, gate=np.inf):
     m = matched & (idx != NO_MATCH)
     differ = m & (idx.astype(np.int64) != oidx)
     if m.any():
+        # second, tolerance-based check against the oracle on the CALLER's fp64 inputs (which the device
+        # rounds to fp32 about the centring origin): distances to 5 um, and the few indices that differ are
+        # near-ties at that precision.  The exact index check is assert_nn_exact_on_stored.
         assert np.abs(np.sqrt(d2[m].astype(np.float64)) - np.sqrt(od2[m])).max() <= DIST_ATOL_M
-        assert differ.mean() < 1e-3      # ties only (already distance-checked above)
+        assert differ.mean() < 1e-3
+
+
+def assert_nn_exact_on_stored(engine, T, gate, idx, d2, use_tree=False):
+    """EXACT index parity (bar 1: bit-exact index work) on the coordinates the device actually stores.
+
+    ``ma_get_gold`` / ``ma_get_source_stored`` return both clouds as stored (fp32 about the centring
+    origin), so the oracle below works on bit for bit the device's inputs: the query is the fp32 image
+    of the fp64 transform of the stored point (what k_nn_accum forms), the candidates are the stored
+    gold points, distances in fp64.  Every index must then equal the device's.  The only admissible
+    difference is a TIE IN THE DEVICE'S OWN ARITHMETIC: the device compares fp32 distances, so where the
+    oracle's neighbour and the device's are closer than 4 ulp(fp32) in squared distance either may win;
+    each such case is checked individually (no percentage of free mismatches)."""
+    gi = engine.grid_info()
+    o = gi["origin"]
+    G = engine.get_gold() - o                     # exact: the stored fp32 values
+    S = engine.get_source_stored() - o
+    assert np.array_equal(G, G.astype(np.float32).astype(np.float64)) and np.array_equal(S, S.astype(np.float32).astype(np.float64))
+    R, t = (np.eye(3), np.zeros(3)) if T is None else (np.asarray(T)[:3, :3], np.asarray(T)[:3, 3])
+    tc = R @ o + t - o                              # host_math.h: world_to_centred
+    P = (S @ R.T + tc).astype(np.float32)           # the fp32 image the search runs on
+    P64 = P.astype(np.float64)
+    if use_tree:
+        oidx, od2 = orc.GoldIndex(G, n_jobs=-1).query(P64)
+    else:
+        oidx, od2 = orc.nn_bruteforce(G, P64)
+    g2 = np.float32(gate) ** 2 if np.isfinite(gate) else np.float32(np.inf)
+
+    def d2_f32(j):                                  # the device's arithmetic: fp32 differences, fp32 sum of squares
+        d = P - G[j].astype(np.float32)
+        return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(np.float32)
+
+    od2_dev = d2_f32(oidx)
+    ulp4 = 4.0 * np.spacing(np.maximum(od2_dev, np.float32(1e-30)))
+    near_gate = np.abs(od2_dev.astype(np.float64) - float(g2)) <= ulp4 if np.isfinite(gate) else np.zeros(len(P), bool)
+    matched = od2_dev <= g2
+    # the gate decision agrees except within 4 ulp of the gate itself
+    assert (((idx != NO_MATCH) == matched) | near_gate).all()
+    m = matched & (idx != NO_MATCH)
+    differ = np.flatnonzero(m & (idx.astype(np.int64) != oidx))
+    if len(differ):
+        mine = d2_f32(idx.astype(np.int64).clip(0, len(G) - 1))[differ]
+        assert (np.abs(mine.astype(np.float64) - od2_dev[differ]) <= ulp4[differ]).all(), \
+            f"{len(differ)} indices differ from the oracle on the stored coordinates and are not fp32 ties"
+    # reported squared distances: the device's fp32 value of its own winner (1 ulp of contraction freedom)
+    if m.any():
+        own = d2_f32(idx.astype(np.int64).clip(0, len(G) - 1))
+        assert (np.abs(d2[m].astype(np.float64) - own[m]) <= ulp4[m] + 4.0 * np.spacing(own[m])).all()
+    return len(differ)
 
 
 def acc_close(a, b):
@@ -57,8 +108,10 @@ def test_nn_exact_vs_bruteforce(engine, n_gold, n_comp):
     oidx, od2 = orc.nn_bruteforce(gold, comp)
     idx, d2 = engine.nn(None, np.inf)               # ungated: ring expansion to the whole grid
     assert_nn_matches(idx, d2, oidx, od2)
+    assert_nn_exact_on_stored(engine, None, np.inf, idx, d2)
     idx, d2 = engine.nn(None, 0.10)                 # gated
     assert_nn_matches(idx, d2, oidx, od2, gate=0.10)
+    assert_nn_exact_on_stored(engine, None, 0.10, idx, d2)
 
 
 @pytest.mark.parametrize("cell", [0.0, 0.01, 0.1, 1.0, 50.0])
@@ -72,8 +125,10 @@ def test_nn_independent_of_cell_size(engine, cell):
     oidx, od2 = orc.GoldIndex(gold, n_jobs=4).query(p_t)
     idx, d2 = engine.nn(T, 0.25)
     assert_nn_matches(idx, d2, oidx, od2, gate=0.25)
+    assert_nn_exact_on_stored(engine, T, 0.25, idx, d2, use_tree=True)
     idx, d2 = engine.nn(T, np.inf)
     assert_nn_matches(idx, d2, oidx, od2)
+    assert_nn_exact_on_stored(engine, T, np.inf, idx, d2, use_tree=True)
 
 
 def test_nn_far_outside_the_grid_and_duplicates(engine):
@@ -133,6 +188,7 @@ def test_nn_fuzz_shapes_sizes_gates_cells(engine):
         oidx, od2 = orc.nn_bruteforce(gold, p_t)
         idx, d2 = engine.nn(T, gate)
         assert_nn_matches(idx, d2, oidx, od2, gate=gate)
+        assert_nn_exact_on_stored(engine, T, gate, idx, d2)        # exact on the stored coordinates, every case
 
 
 # ----------------------------------------------------------------------------- rows a4-a6
@@ -541,6 +597,9 @@ def test_full_size_1m_resampled_pair_one_step_vs_oracle(engine):
     assert eR <= 1e-7 and et <= 1e-6
     idx, d2 = engine.nn(T0, 0.10)
     assert_nn_matches(idx, d2, oidx, od2, gate=0.10)
+    # ... and EXACTLY, index by index, on the coordinates as stored (1M queries against the KD-tree)
+    ties = assert_nn_exact_on_stored(engine, T0, 0.10, idx, d2, use_tree=True)
+    print(f"1M one-step: {ties} of {len(idx)} indices differ from the oracle on the stored coordinates, all fp32 ties")
 
 
 # ----------------------------------------------------------------------------- adaptor (a1-a3, N1-N3)
@@ -579,6 +638,10 @@ def test_alignment_adaptor_far_start_with_ply_and_pickle(tmp_path):
     tr = al.transformations
     assert isinstance(tr[0], tuple) and tr[1].shape == (4, 4) and tr[2].shape == (4, 4)
     assert np.allclose(transforms.compose(tr), T, atol=1e-9) and transforms.is_rigid(T, 1e-8)
+    # ... and through the only reference code that consumes the list (visualise.py:82-130, restated in
+    # tests/visualiser_replay.py): 20 log-map steps per stage end on the composed transform, all increments real
+    from visualiser_replay import assert_replayable
+    assert_replayable(tr, comp[::500].astype(np.float64), T, atol=1e-6)
     with open(pkl, "rb") as f:
         state = pickle.load(f)
     assert set(state) >= {"transformations", "base_map_filepath", "comparison_map_filepath", "pose_df"}

@@ -355,6 +355,10 @@ def test_coarse_stage_uses_trajectories_on_a_half_turn_symmetric_shell(lib_built
     assert cs[1] - cs[0] < 0.25 * cs[0] + 1e-3
     ts = np.array(info["trajectory_scores"])
     assert ts.min() < 0.1 and np.sort(ts)[1] > 0.4
+    # the emitted list replays through the visualiser's log-map interpolation (visualise.py:82-130)
+    from visualiser_replay import assert_replayable
+    assert all(isinstance(st, tuple) or np.shape(st) == (4, 4) for st in stages)
+    assert_replayable(stages, comp[::500].astype(np.float64), T, atol=1e-6)
     mapalign.release_cached_engines()
 
 
