@@ -14,7 +14,7 @@
 //                       on the device, so the loop never synchronises with the host
 //   k_reduce19, k_solve the same two halves as separate launches (sharded-source stepping)
 //   k_unproject  a8     depth image -> world points written straight into the source
-//                       cloud buffer (order-preserving compaction of valid pixels)
+//                       cloud buffer, pixel i in slot i (invalid pixels leave a hole the search skips)
 // Everything is written for 64-wide wavefronts; there is no MFMA because the path is a
 // gather + reduction (<0.5 flop/B), and no CPU fallback.
 //
@@ -56,6 +56,7 @@ constexpr int kNNBlock = ma::kSearchBlock;  // workgroup of the search kernel (M
 constexpr int kWave = 64;
 constexpr int kNAcc = 19;             // 17 accumulators + rows visited + candidates
 constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
+constexpr uint32_t kHoleBitsEarly = 0x7FC00000u;   // = kHoleBits (k_unproject): x of a hole, a quiet NaN
 
 // plain structs and host arithmetic shared with the CPU-side sanitizer test (host_math.h)
 using ma::DevState;
@@ -119,11 +120,12 @@ __device__ __forceinline__ uint32_t cell_of(float x, float y, float z, const Gri
 // STRIDE floats per point: 3 for raw clouds, 4 for the float4 buffers.
 template <int STRIDE>
 __global__ __launch_bounds__(kBlock) void k_minmax(const float* __restrict__ xyz, uint32_t n,
-                                                   float* __restrict__ out /*[grid][8]*/) {
+                                                   float* __restrict__ out /*[grid][8]*/, const int holes_ok) {
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   float bad = 0.f;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const float x = xyz[STRIDE * (size_t)i], y = xyz[STRIDE * (size_t)i + 1], z = xyz[STRIDE * (size_t)i + 2];
+    if (holes_ok && __float_as_uint(x) == kHoleBitsEarly) continue;     // a hole of the in-place unprojection (float4 buffers)
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
       lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
       lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
@@ -1356,176 +1358,85 @@ struct Pinhole {
   double T[12];  // camera->world rows 0..2, translation already minus the centring origin
 };
 
-// ONE pass over the depth image: every workgroup loads its 1024 pixels once, counts the valid
-// ones, and learns how many valid pixels lie in front of it from the counts its predecessors
-// publish (write-through, agent scope) — no separate counting pass, scan and second read of the
-// image.  Two forms, chosen by the host:
-//   DIRECT  the whole grid is resident at once (<= 8 workgroups per CU), so every predecessor is
-//           running whatever the dispatch order: each workgroup publishes its count and then
-//           sums ALL its predecessors' counts itself, its 256 threads loading them side by side
-//           (<= 8 coherent loads per thread, one memory round trip; O(grid^2) words in total,
-//           2.9 MB for a 1280 x 960 frame).  No dependent chain between workgroups.
-//   CHAINED larger images: decoupled look-back (aggregate / inclusive-prefix status words, 256
-//           predecessors per trip); workgroups take their logical index from an atomic ticket,
-//           so every predecessor a workgroup waits for has already started.
-// Every spin is bounded; a timeout raises an error word instead of hanging the device.
-constexpr unsigned long long kScanAggregate = 1ull << 32, kScanPrefix = 2ull << 32;
-constexpr uint32_t kScanSpinLimit = 1u << 22;
-constexpr uint32_t kDirectMaxBlocks = 2048;     // also bounded by the device's resident capacity (host)
+// ONE streaming pass, no exchange between workgroups (round 3).  Every pixel is written IN PLACE:
+// slot i of the output holds the point of pixel i, or a hole — x = quiet NaN, w = 0 — where the
+// depth is <= 0 / NaN / inf.  The search kernel skips non-finite queries (wave_search: `finite`),
+// the map builder's voxel sort sends holes behind every real key, and the calls that hand points
+// back to the caller (ma_get_source, ma_nn, ...) compact lazily through a rank map (src_map).
+// The only other output is one count of valid pixels per workgroup, written with a plain store and
+// added up by the host: an atomic on one address completes every ~200 ns on this chip
+// (profiles/r03_variants_ab.txt, call 1), so 1200 of them would cost ten times the kernel.
+// Rounds 1-2 compacted in the kernel (order-preserving, first with a scan between two passes, then
+// single-pass with a decoupled look-back / all-predecessors exchange): 18-24 us for a 1280 x 960
+// frame, all of it waiting for other workgroups' counts (~2 us per coherent load, O(grid^2) of
+// them) to keep 99.9999 % valid pixels where they already were.
+// Algorithmic bytes: w h sizeof(depth) read + 16 w h written (24.6 MB for configs[2]).
+constexpr uint32_t kHoleBits = 0x7FC00000u;      // quiet NaN
 
-template <typename T, bool DIRECT>
+template <typename T>
 __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ depth, const int width,
                                                       const uint32_t npx, const Pinhole cam,
-                                                      uint32_t* __restrict__ ticket /*[0] ticket, [1] total, [2] error*/,
-                                                      unsigned long long* __restrict__ status,
-                                                      float4* __restrict__ out, const uint32_t epoch) {
-  __shared__ uint32_t sh_block, sh_prefix;
-  __shared__ uint32_t wsum[kBlock / kWave], psum[kBlock / kWave];
-  uint32_t blk = blockIdx.x;
-  if (!DIRECT) {
-    if (threadIdx.x == 0) sh_block = atomicAdd(&ticket[0], 1u);
-    __syncthreads();
-    blk = sh_block;
-  }
-  const uint32_t first = blk * kPxPerBlock + threadIdx.x * kPxPerThread;
+                                                      uint32_t* __restrict__ counts, float4* __restrict__ out) {
+  const uint32_t first = blockIdx.x * kPxPerBlock + threadIdx.x * kPxPerThread;
   double z[kPxPerThread];
+  if (first + kPxPerThread <= npx && (reinterpret_cast<uintptr_t>(depth + first) & (sizeof(T) * kPxPerThread - 1)) == 0) {
+    // the thread's four pixels in one load (16 B of float32 / 8 B of uint16)
+    struct alignas(sizeof(T) * kPxPerThread) Quad { T v[kPxPerThread]; };
+    const Quad q = *reinterpret_cast<const Quad*>(depth + first);
+#pragma unroll
+    for (int k = 0; k < kPxPerThread; ++k) z[k] = (double)q.v[k] * cam.inv_scale;
+  } else {
+#pragma unroll
+    for (int k = 0; k < kPxPerThread; ++k) z[k] = first + k < npx ? depth_z(depth, first + k, cam.inv_scale) : 0.0;
+  }
   uint32_t cnt = 0;
+  // (u, v) of the first pixel by one division; the others step along the row
+  uint32_t u = first % (uint32_t)width, v = first / (uint32_t)width;
 #pragma unroll
   for (int k = 0; k < kPxPerThread; ++k) {
     const uint32_t i = first + k;
-    z[k] = i < npx ? depth_z(depth, i, cam.inv_scale) : 0.0;
-    if (!(isfinite(z[k]) && z[k] > 0.0)) z[k] = 0.0;
-    cnt += z[k] > 0.0;
-  }
-  // exclusive scan of cnt over the workgroup (wavefront shuffles + LDS)
-  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-  uint32_t incl = cnt;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const uint32_t u = __shfl_up(incl, off, kWave);
-    if (lane >= off) incl += u;
-  }
-  if (lane == kWave - 1) wsum[wv] = incl;
-  __syncthreads();
-  uint32_t wbase = 0, total = 0;
-  for (int w = 0; w < kBlock / kWave; ++w) {
-    if (w < wv) wbase += wsum[w];
-    total += wsum[w];
-  }
-  if (DIRECT) {
-    // status word = (epoch << 32) | count: a word of another call's epoch reads as "not published
-    // yet", so the array needs no clearing between calls (a fill kernel costs ~5 us, a quarter
-    // of this kernel); the host bumps the epoch per call and clears the array when it wraps
-    if (threadIdx.x == 0)
-      __hip_atomic_store(&status[blk], ((unsigned long long)epoch << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // every thread sums its share of the predecessors' counts: predecessors t, t+256, ...
-    uint32_t mine = 0, spins = 0;
-    constexpr int kPer = kDirectMaxBlocks / kBlock;       // <= 8 loads in flight per thread
-    unsigned long long st[kPer];
-    bool pending = true;
-    while (pending) {
-#pragma unroll
-      for (int j = 0; j < kPer; ++j) {
-        const uint32_t idx = threadIdx.x + (uint32_t)j * kBlock;
-        st[j] = idx < blk ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                          : (unsigned long long)epoch << 32;
-      }
-      pending = false;
-      mine = 0;
-#pragma unroll
-      for (int j = 0; j < kPer; ++j) {
-        pending = pending || (uint32_t)(st[j] >> 32) != epoch;
-        mine += (uint32_t)st[j];
-      }
-      if (pending) {
-        if (++spins > kScanSpinLimit) { atomicExch(&ticket[2], epoch); break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) mine += __shfl_xor(mine, off, kWave);
-    if (lane == 0) psum[wv] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t prefix = 0;
-#pragma unroll
-      for (int w = 0; w < kBlock / kWave; ++w) prefix += psum[w];
-      sh_prefix = prefix;
-      if (blk == gridDim.x - 1) { ticket[1] = prefix + total; ticket[3] = epoch; }   // valid pixels of the image, and of which call
-    }
-  } else if (wv == 0) {
-    if (lane == 0)
-      __hip_atomic_store(&status[blk], (blk == 0 ? kScanPrefix : kScanAggregate) | total, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t prefix = 0;
-    if (blk > 0) {
-      // look-back, 256 predecessors per trip (a coherent load costs ~2 us on an idle chip and
-      // the walk is a dependent chain of them): lane l inspects workgroups base - l - 64 j,
-      // j = 0..3, the four loads in flight together; sub-window j is consumed only if no nearer
-      // one ended the walk
-      int base = (int)blk - 1;
-      uint32_t spins = 0;
-      bool done = false;
-      while (!done) {
-        unsigned long long st[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int idx = base - lane - kWave * j;
-          st[j] = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                           : kScanPrefix;     // in front of workgroup 0: prefix 0
-        }
-        uint32_t add = 0;
-        int consumed = 0;        // leading sub-windows summed in full (all ready, no prefix among them)
-        bool retry = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (done || retry) continue;                      // (wave-uniform)
-          const uint32_t flag = (uint32_t)(st[j] >> 32);
-          const unsigned long long not_ready = __ballot(flag == 0u), is_prefix = __ballot(flag == 2u);
-          // the nearest predecessor that already knows its inclusive prefix ends the walk
-          const int stop = is_prefix ? __builtin_ctzll(is_prefix) : kWave;
-          const unsigned long long window = stop >= kWave - 1 ? ~0ull : ((2ull << stop) - 1ull);
-          if (not_ready & window) { retry = true; continue; }   // reload from this sub-window on
-          uint32_t v = lane <= stop ? (uint32_t)st[j] : 0u;
-#pragma unroll
-          for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-          add += v;
-          if (is_prefix) done = true;
-          else consumed = j + 1;
-        }
-        prefix += add;
-        base -= kWave * consumed;
-        if (retry) {
-          if (++spins > kScanSpinLimit) { if (lane == 0) atomicExch(&ticket[2], 1u); break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      if (lane == 0)
-        __hip_atomic_store(&status[blk], kScanPrefix | (unsigned long long)(prefix + total), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (lane == 0) {
-      sh_prefix = prefix;
-      if (blk == gridDim.x - 1) ticket[1] = prefix + total;   // number of valid pixels of the image
-    }
-  }
-  __syncthreads();
-  uint32_t pos = sh_prefix + wbase + (incl - cnt);
-#pragma unroll
-  for (int k = 0; k < kPxPerThread; ++k) {
-    if (z[k] > 0.0) {
-      const uint32_t i = first + k;
-      const double u = (double)(i % (uint32_t)width), v = (double)(i / (uint32_t)width);
-      const double X = (u - cam.cx) * z[k] * cam.fx_inv;
-      const double Y = (v - cam.cy) * z[k] * cam.fy_inv;
+    const bool ok = isfinite(z[k]) && z[k] > 0.0;
+    if (i < npx) {
       float4 p;
-      p.x = (float)(cam.T[0] * X + cam.T[1] * Y + cam.T[2] * z[k] + cam.T[3]);
-      p.y = (float)(cam.T[4] * X + cam.T[5] * Y + cam.T[6] * z[k] + cam.T[7]);
-      p.z = (float)(cam.T[8] * X + cam.T[9] * Y + cam.T[10] * z[k] + cam.T[11]);
-      p.w = 1.0f;
-      out[pos++] = p;
+      if (ok) {
+        const double X = ((double)u - cam.cx) * z[k] * cam.fx_inv;
+        const double Y = ((double)v - cam.cy) * z[k] * cam.fy_inv;
+        p.x = (float)(cam.T[0] * X + cam.T[1] * Y + cam.T[2] * z[k] + cam.T[3]);
+        p.y = (float)(cam.T[4] * X + cam.T[5] * Y + cam.T[6] * z[k] + cam.T[7]);
+        p.z = (float)(cam.T[8] * X + cam.T[9] * Y + cam.T[10] * z[k] + cam.T[11]);
+        p.w = 1.0f;
+        ++cnt;
+      } else {
+        p = make_float4(__uint_as_float(kHoleBits), 0.f, 0.f, 0.f);
+      }
+      out[i] = p;
     }
+    if (++u == (uint32_t)width) { u = 0; ++v; }
   }
+  __shared__ uint32_t wsum[kBlock / kWave];
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) t += wsum[w];
+    counts[blockIdx.x] = t;
+  }
+}
+
+// Lazy compaction of a cloud with holes: map[i] = number of real points in front of slot i (its
+// index in the caller's view: valid pixels in row-major order), kNoMatch for a hole.  flags -> scan
+// (hipCUB) -> this kernel; built only when a call has to hand points or per-point results back.
+__global__ __launch_bounds__(kBlock) void k_hole_flags(const float4* __restrict__ pts, uint32_t n, uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) flags[i] = isfinite(pts[i].x) ? 1u : 0u;
+}
+__global__ __launch_bounds__(kBlock) void k_rank_map(const uint32_t* __restrict__ flags, const uint32_t* __restrict__ scan,
+                                                     uint32_t n, uint32_t* __restrict__ map) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) map[i] = flags[i] ? scan[i] : kNoMatch;
 }
 
 // N4: voxel keys of the accumulated map points.  The voxel of a point is floor(p / voxel) per axis
@@ -1534,11 +1445,17 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
 // radix sort only has to look at the ~30 bits a real map uses instead of 63.
 using ma::VoxelBox;              // csrc/host_math.h (its arithmetic is host code, tested under sanitizers)
 __global__ __launch_bounds__(kBlock) void k_voxel_keys(const float4* __restrict__ pts, uint32_t n, float inv_voxel,
-                                                       const VoxelBox box, unsigned long long* __restrict__ keys,
+                                                       const VoxelBox box, const unsigned long long hole_key,
+                                                       unsigned long long* __restrict__ keys,
                                                        uint32_t* __restrict__ vals) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float4 p = pts[i];
+  if (!isfinite(p.x)) {            // a hole of the in-place unprojection: sorts behind every voxel of the box
+    keys[i] = hole_key;
+    vals[i] = i;
+    return;
+  }
   auto q = [&](float v, int a) -> unsigned long long {
     long long c = (long long)floorf(v * inv_voxel) - box.q0[a];
     c = c < 0 ? 0 : (c > (long long)box.d[a] - 1 ? (long long)box.d[a] - 1 : c);
@@ -1676,15 +1593,17 @@ __global__ __launch_bounds__(kBlock) void k_lift_boxes_batch(const T* __restrict
   if (valid) valid[i] = ok ? 1 : 0;
 }
 
-__global__ __launch_bounds__(kBlock) void k_uncentre(const float4* __restrict__ src, uint32_t n,
-                                                     double o0, double o1, double o2,
+__global__ __launch_bounds__(kBlock) void k_uncentre(const float4* __restrict__ src, const uint32_t* __restrict__ map,
+                                                     uint32_t n, double o0, double o1, double o2,
                                                      float* __restrict__ xyz) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const float4 s = src[i];
-  xyz[3 * (size_t)i] = (float)((double)s.x + o0);
-  xyz[3 * (size_t)i + 1] = (float)((double)s.y + o1);
-  xyz[3 * (size_t)i + 2] = (float)((double)s.z + o2);
+  const uint32_t pos = blockIdx.x * kBlock + threadIdx.x;
+  if (pos >= n) return;
+  const size_t i = map ? map[pos] : pos;
+  if (map && map[pos] == kNoMatch) return;       // a hole
+  const float4 s = src[pos];
+  xyz[3 * i] = (float)((double)s.x + o0);
+  xyz[3 * i + 1] = (float)((double)s.y + o1);
+  xyz[3 * i + 2] = (float)((double)s.z + o2);
 }
 
 // The stored coordinates as the search sees them, exactly: world = fp32 (centred) + origin, evaluated in
@@ -1697,6 +1616,7 @@ __global__ __launch_bounds__(kBlock) void k_export_f64(const float4* __restrict_
   if (pos >= n) return;
   const float4 p = pts[pos];
   const size_t i = perm ? perm[pos] : pos;
+  if (perm && perm[pos] == kNoMatch) return;     // a hole
   xyz[3 * i] = (double)p.x + o0;
   xyz[3 * i + 1] = (double)p.y + o1;
   xyz[3 * i + 2] = (double)p.z + o2;
@@ -1709,6 +1629,7 @@ __global__ __launch_bounds__(kBlock) void k_unpermute(const T* __restrict__ in,
                                                       T* __restrict__ out) {
   const uint32_t pos = blockIdx.x * kBlock + threadIdx.x;
   if (pos >= n) return;
+  if (perm && perm[pos] == kNoMatch) return;     // a hole
   out[perm ? perm[pos] : pos] = in[pos];
 }
 
@@ -1784,15 +1705,18 @@ struct ma_ctx {
   // source cloud
   bool have_src = false;
   bool src_sorted = false;
-  uint32_t n = 0;
-  DevBuf src, src_perm;
+  uint32_t n = 0;                // slots of the source buffer the search kernel covers
+  uint32_t n_pts = 0;            // points the caller sees (= n, or the valid pixels of a depth frame: its slots may be holes)
+  bool src_holes = false;        // src has holes (x = NaN): per-point results are compacted through src_perm, built on demand
+  bool src_map_ready = false;
+  DevBuf src, src_perm;          // src_perm: slot -> caller's index (the sort's permutation, or the rank map of a cloud with holes)
 
   // last uploaded depth frame (ma_set_source_from_depth / ma_lift_boxes)
   int depth_w = 0, depth_h = 0, depth_dtype = -1;
 
   // map builder (N4)
   DevBuf map_pts, map_keys_a, map_keys_b, map_flags, map_seg, map_acc, map_pre, map_heads;
-  uint64_t map_n = 0, map_cap = 0;
+  uint64_t map_n = 0, map_cap = 0, map_valid = 0;   // slots used / capacity / real points among the slots
   float map_voxel = 0.f;
   double map_origin[3] = {0, 0, 0};
   bool map_has_origin = false;
@@ -1802,10 +1726,7 @@ struct ma_ctx {
 
   // batched box lifting (a10 over many frames)
   DevBuf lift_poses, lift_frames;
-  // single-pass unprojection: ticket / total / error words and the per-workgroup status words
-  DevBuf scan_words, scan_status;
-  uint32_t scan_epoch = 0;
-  bool scan_was_direct = false;
+  DevBuf unproj_cnt;             // valid pixels per workgroup of the last k_unproject launch
 
   // loop state
   DevBuf state, partials, trace, acc19, ticket, wg_cost, seg_order, nn_idx, nn_d2, nn_tmp, prev;
@@ -1836,7 +1757,7 @@ struct ma_ctx {
   std::vector<DevBuf*> all_bufs() {
     std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b,
                               &src, &src_perm, &raw, &raw64, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
-                              &depth_in, &lift_poses, &lift_frames, &scan_words, &scan_status, &state, &partials, &trace, &acc19, &ticket,
+                              &depth_in, &lift_poses, &lift_frames, &unproj_cnt, &state, &partials, &trace, &acc19, &ticket,
                               &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
     for (int l = 0; l < kLevels; ++l) { v.push_back(&gold[l]); v.push_back(&cstart[l]); }
     return v;
@@ -1929,11 +1850,11 @@ int need_ready(ma_ctx* ctx) {
 }
 
 // bounding box (and finiteness check) of a device-resident n x 3 cloud
-int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3], int stride = 3) {
+int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3], int stride = 3, bool holes_ok = false) {
   const int nb = std::min<uint32_t>(div_up(n, kBlock), 1024);
   HIPCHK(ctx->misc.ensure((size_t)nb * 8 * sizeof(float)));
-  if (stride == 4) hipLaunchKernelGGL(k_minmax<4>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, ctx->misc.as<float>());
-  else hipLaunchKernelGGL(k_minmax<3>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, ctx->misc.as<float>());
+  if (stride == 4) hipLaunchKernelGGL(k_minmax<4>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, ctx->misc.as<float>(), holes_ok ? 1 : 0);
+  else hipLaunchKernelGGL(k_minmax<3>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, ctx->misc.as<float>(), 0);
   HIPCHK(hipGetLastError());
   std::vector<float> h((size_t)nb * 8);
   HIPCHK(hipMemcpyAsync(h.data(), ctx->misc.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -2115,51 +2036,56 @@ void fill_stats(const DevState& s, double gpu_ms, ma_stats* st) {
   st->gpu_ms = gpu_ms;
 }
 
-// Depth frame already in ctx->depth_in -> world points appended at `out` (single-pass
-// k_unproject).  *total receives the number of valid pixels; ev0/ev1 bracket the device work.
+// Depth frame already in ctx->depth_in -> one slot per pixel at `out` (k_unproject: points and holes).
+// *total receives the number of valid pixels; ev0/ev1 bracket the device work.
 int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinhole& cam, float4* out, uint32_t* total) {
   const uint32_t nb = div_up(npx, kPxPerBlock);
-  // DIRECT form only while the whole grid is resident at once (its workgroups wait for each
-  // other): the kernel's 86 SGPRs allow 7 workgroups per CU (SGPRs are granted in blocks of 16
-  // plus 16: floor(800 / 112) = 7 wavefronts per SIMD); 6 per CU leaves a margin
-  const bool direct = nb <= std::min<uint32_t>(kDirectMaxBlocks, (uint32_t)ctx->n_cus * 6u);
-  const void* scan_words_before = ctx->scan_words.p;
-  const void* scan_status_before = ctx->scan_status.p;
-  HIPCHK(ctx->scan_words.ensure(64));
-  HIPCHK(ctx->scan_status.ensure((size_t)nb * 8));
+  HIPCHK(ctx->unproj_cnt.ensure((size_t)nb * 4));
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-  // epoch-tagged status words (direct form): cleared only when the buffers are new or the epoch wraps
-  if (!direct || !ctx->scan_was_direct || ctx->scan_words.p != scan_words_before ||
-      ctx->scan_status.p != scan_status_before || ctx->scan_epoch >= 0x7FFFFFF0u) {
-    HIPCHK(hipMemsetAsync(ctx->scan_words.p, 0, 16, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->scan_status.p, 0, ctx->scan_status.cap, ctx->stream));
-    ctx->scan_epoch = 0;
-  }
-  ctx->scan_was_direct = direct;      // (the chained form leaves flag words behind that an epoch could collide with)
-  const uint32_t epoch = ++ctx->scan_epoch;
-  auto launch = [&](auto kern, auto* d) {
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(kBlock), 0, ctx->stream, d, width, npx, cam, ctx->scan_words.as<uint32_t>(),
-                       ctx->scan_status.as<unsigned long long>(), out, epoch);
-  };
-  if (dtype == 0) {
-    if (direct) launch(k_unproject<float, true>, ctx->depth_in.as<float>());
-    else launch(k_unproject<float, false>, ctx->depth_in.as<float>());
-  } else {
-    if (direct) launch(k_unproject<uint16_t, true>, ctx->depth_in.as<uint16_t>());
-    else launch(k_unproject<uint16_t, false>, ctx->depth_in.as<uint16_t>());
-  }
+  if (dtype == 0)
+    hipLaunchKernelGGL(k_unproject<float>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(), width, npx, cam,
+                       ctx->unproj_cnt.as<uint32_t>(), out);
+  else
+    hipLaunchKernelGGL(k_unproject<uint16_t>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<uint16_t>(), width, npx,
+                       cam, ctx->unproj_cnt.as<uint32_t>(), out);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-  uint32_t h[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(h, ctx->scan_words.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<uint32_t> h(nb);
+  HIPCHK(hipMemcpyAsync(h.data(), ctx->unproj_cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->last_op_ms = ms;
-  if (h[2] != 0u && (!direct || h[2] == epoch))
-    return ctx->fail(MA_ERR_HIP, "k_unproject: timed out waiting for a predecessor workgroup's count");
-  if (direct && h[3] != epoch) return ctx->fail(MA_ERR_HIP, "k_unproject: the last workgroup did not report a total");
-  *total = h[1];
+  uint64_t t = 0;
+  for (uint32_t c : h) t += c;
+  *total = (uint32_t)t;
+  return MA_OK;
+}
+
+// slot -> caller's index for everything that hands per-point data back: the sort's permutation, the rank
+// map of a cloud with holes (built here, once per cloud, when first needed), or null (identity).
+int source_map(ma_ctx* ctx, const uint32_t** map) {
+  *map = nullptr;
+  if (ctx->src_sorted) { *map = ctx->src_perm.as<uint32_t>(); return MA_OK; }
+  if (!ctx->src_holes) return MA_OK;
+  if (!ctx->src_map_ready) {
+    const uint32_t n = ctx->n;
+    HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
+    HIPCHK(ctx->keys_b.ensure((size_t)n * 4));
+    HIPCHK(ctx->src_perm.ensure((size_t)n * 4));
+    hipLaunchKernelGGL(k_hole_flags, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->src.as<float4>(), n,
+                       ctx->keys_a.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    size_t tmp_bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), (int)n, ctx->stream));
+    HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), (int)n, ctx->stream));
+    hipLaunchKernelGGL(k_rank_map, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->keys_a.as<uint32_t>(),
+                       ctx->keys_b.as<uint32_t>(), n, ctx->src_perm.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    ctx->src_map_ready = true;
+  }
+  *map = ctx->src_perm.as<uint32_t>();
   return MA_OK;
 }
 
@@ -2606,7 +2532,10 @@ static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights) 
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->n = n;
+  ctx->n_pts = n;
   ctx->src_sorted = true;
+  ctx->src_holes = false;
+  ctx->src_map_ready = true;
   ctx->have_src = true;
   return MA_OK;
 }
@@ -2701,8 +2630,11 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   if (rc) return rc;
   if (n_valid) *n_valid = total;
   if (total == 0) return ctx->fail(MA_ERR_EMPTY, "depth image has no valid pixel");
-  ctx->n = total;
+  ctx->n = npx;                       // one slot per pixel; the invalid ones are holes the search skips
+  ctx->n_pts = total;
   ctx->src_sorted = false;
+  ctx->src_holes = total != npx;
+  ctx->src_map_ready = false;
   ctx->have_src = true;
   return MA_OK;
   });
@@ -2717,6 +2649,7 @@ int ma_map_begin(ma_ctx* ctx, float voxel, uint64_t capacity_points) {
   HIPCHK(ctx->map_pts.ensure(capacity_points * sizeof(float4)));
   ctx->map_cap = capacity_points;
   ctx->map_n = 0;
+  ctx->map_valid = 0;
   ctx->map_voxel = voxel;
   ctx->map_has_origin = false;
   return MA_OK;
@@ -2748,7 +2681,8 @@ int ma_map_add_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int h
   uint32_t total = 0;
   int rc = unproject_frame(ctx, dtype, width, npx, cam, ctx->map_pts.as<float4>() + ctx->map_n, &total);
   if (rc) return rc;
-  ctx->map_n += total;
+  ctx->map_n += npx;                  // one slot per pixel (holes included: the voxel sort drops them)
+  ctx->map_valid += total;
   if (n_added) *n_added = total;
   return MA_OK;
   });
@@ -2758,37 +2692,41 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
   return guarded(ctx, [&]() -> int {
   if (!ctx || !n_io) return MA_ERR_INVALID;
   if (ctx->map_cap == 0) return ctx->fail(MA_ERR_STATE, "ma_map_begin first");
-  if (ctx->map_n == 0) return ctx->fail(MA_ERR_EMPTY, "the map holds no point");
+  if (ctx->map_valid == 0) return ctx->fail(MA_ERR_EMPTY, "the map holds no point");
   if (std::isnan(cell) || std::isinf(cell)) return ctx->fail(MA_ERR_INVALID, "cell must be finite");
   HIPCHK(hipSetDevice(ctx->device));
-  const uint32_t n = (uint32_t)ctx->map_n;
-  HIPCHK(ctx->map_keys_a.ensure((size_t)n * 8));
-  HIPCHK(ctx->map_keys_b.ensure((size_t)n * 8));
-  HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
-  HIPCHK(ctx->vals_b.ensure((size_t)n * 4));
+  const uint32_t nslots = (uint32_t)ctx->map_n;       // slots: points and holes
+  const uint32_t n = (uint32_t)ctx->map_valid;        // real points: the first n entries after the sort
+  HIPCHK(ctx->map_keys_a.ensure((size_t)nslots * 8));
+  HIPCHK(ctx->map_keys_b.ensure((size_t)nslots * 8));
+  HIPCHK(ctx->vals_a.ensure((size_t)nslots * 4));
+  HIPCHK(ctx->vals_b.ensure((size_t)nslots * 4));
   HIPCHK(ctx->map_flags.ensure((size_t)(n + 1) * 4));
   HIPCHK(ctx->map_seg.ensure((size_t)(n + 1) * 4));
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-  // voxel box of the map (points are finite: k_unproject drops everything else) and the key width
+  // voxel box of the map (holes skipped) and the key width; a hole's key is one past the box's last voxel
   float lo[3], hi[3];
-  int rc = cloud_bounds(ctx, ctx->map_pts.as<float>(), n, lo, hi, 4);
+  int rc = cloud_bounds(ctx, ctx->map_pts.as<float>(), nslots, lo, hi, 4, /*holes_ok=*/true);
   if (rc) return rc;
   const float inv_voxel = 1.0f / ctx->map_voxel;
   VoxelBox box;
   int key_bits = 0;
   if (!ma::voxel_box(lo, hi, inv_voxel, box, key_bits))
     return ctx->fail(MA_ERR_TOO_LARGE, "the voxel indices of the map's bounding box do not fit 63 bits (coordinates / voxel too large)");
-  hipLaunchKernelGGL(k_voxel_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->map_pts.as<float4>(), n,
-                     inv_voxel, box, ctx->map_keys_a.as<unsigned long long>(), ctx->vals_a.as<uint32_t>());
+  const bool holes = nslots != n;
+  const unsigned long long hole_key = key_bits >= 64 ? ~0ull : (1ull << key_bits);     // (voxel_box keeps real keys below 9e18 < 2^63)
+  const int sort_bits = holes ? std::min(key_bits + 1, 64) : key_bits;
+  hipLaunchKernelGGL(k_voxel_keys, dim3(div_up(nslots, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->map_pts.as<float4>(), nslots,
+                     inv_voxel, box, hole_key, ctx->map_keys_a.as<unsigned long long>(), ctx->vals_a.as<uint32_t>());
   HIPCHK(hipGetLastError());
   size_t tmp_bytes = 0;
   HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->map_keys_a.as<unsigned long long>(),
                                             ctx->map_keys_b.as<unsigned long long>(), ctx->vals_a.as<uint32_t>(),
-                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, key_bits, ctx->stream));
+                                            ctx->vals_b.as<uint32_t>(), (int)nslots, 0, sort_bits, ctx->stream));
   HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
   HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp_bytes, ctx->map_keys_a.as<unsigned long long>(),
                                             ctx->map_keys_b.as<unsigned long long>(), ctx->vals_a.as<uint32_t>(),
-                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, key_bits, ctx->stream));
+                                            ctx->vals_b.as<uint32_t>(), (int)nslots, 0, sort_bits, ctx->stream));
   hipLaunchKernelGGL(k_voxel_heads, dim3(div_up((uint64_t)n + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
                      ctx->map_keys_b.as<unsigned long long>(), n, ctx->map_flags.as<uint32_t>());
   HIPCHK(hipGetLastError());
@@ -2885,26 +2823,29 @@ int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n) {
   return guarded(ctx, [&]() -> int {
   if (!ctx || !n) return MA_ERR_INVALID;
   if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set");
-  if (!xyz_out) { *n = ctx->n; return MA_OK; }
-  if (*n < ctx->n) { *n = ctx->n; return ctx->fail(MA_ERR_INVALID, "output capacity too small"); }
+  if (!xyz_out) { *n = ctx->n_pts; return MA_OK; }
+  if (*n < ctx->n_pts) { *n = ctx->n_pts; return ctx->fail(MA_ERR_INVALID, "output capacity too small"); }
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(ctx->raw.ensure((size_t)ctx->n * 12));
-  hipLaunchKernelGGL(k_uncentre, dim3(div_up(ctx->n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->src.as<float4>(),
+  const uint32_t* map = nullptr;      // storage order; a cloud from a depth frame is compacted (valid pixels, row-major)
+  if (ctx->src_holes) { int rc = source_map(ctx, &map); if (rc) return rc; }
+  HIPCHK(ctx->raw.ensure((size_t)ctx->n_pts * 12));
+  hipLaunchKernelGGL(k_uncentre, dim3(div_up(ctx->n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->src.as<float4>(), map,
                      ctx->n, ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->raw.as<float>());
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(xyz_out, ctx->raw.p, (size_t)ctx->n * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(xyz_out, ctx->raw.p, (size_t)ctx->n_pts * 12, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  *n = ctx->n;
+  *n = ctx->n_pts;
   return MA_OK;
   });
 }
 
-static int export_stored(ma_ctx* ctx, const float4* pts, const uint32_t* perm, uint32_t count, double* xyz_out, uint64_t* n) {
+static int export_stored(ma_ctx* ctx, const float4* pts, const uint32_t* perm, uint32_t slots, uint32_t count, double* xyz_out,
+                         uint64_t* n) {
   if (!xyz_out) { *n = count; return MA_OK; }
   if (*n < count) { *n = count; return ctx->fail(MA_ERR_INVALID, "output capacity too small"); }
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(ctx->raw64.ensure((size_t)count * 24));
-  hipLaunchKernelGGL(k_export_f64, dim3(div_up(count, kBlock)), dim3(kBlock), 0, ctx->stream, pts, perm, count,
+  hipLaunchKernelGGL(k_export_f64, dim3(div_up(slots, kBlock)), dim3(kBlock), 0, ctx->stream, pts, perm, slots,
                      ctx->origin[0], ctx->origin[1], ctx->origin[2], ctx->raw64.as<double>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(xyz_out, ctx->raw64.p, (size_t)count * 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -2917,7 +2858,7 @@ int ma_get_gold(ma_ctx* ctx, double* xyz_out, uint64_t* n) {
   return guarded(ctx, [&]() -> int {
   if (!ctx || !n) return MA_ERR_INVALID;
   if (!ctx->have_gold) return ctx->fail(MA_ERR_STATE, "gold map not set");
-  return export_stored(ctx, ctx->gold[0].as<float4>(), ctx->perm0.as<uint32_t>(), ctx->m, xyz_out, n);
+  return export_stored(ctx, ctx->gold[0].as<float4>(), ctx->perm0.as<uint32_t>(), ctx->m, ctx->m, xyz_out, n);
   });
 }
 
@@ -2925,7 +2866,9 @@ int ma_get_source_stored(ma_ctx* ctx, double* xyz_out, uint64_t* n) {
   return guarded(ctx, [&]() -> int {
   if (!ctx || !n) return MA_ERR_INVALID;
   if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set");
-  return export_stored(ctx, ctx->src.as<float4>(), ctx->src_sorted ? ctx->src_perm.as<uint32_t>() : nullptr, ctx->n, xyz_out, n);
+  const uint32_t* map = nullptr;
+  if (xyz_out) { HIPCHK(hipSetDevice(ctx->device)); int rc = source_map(ctx, &map); if (rc) return rc; }
+  return export_stored(ctx, ctx->src.as<float4>(), map, ctx->n, ctx->n_pts, xyz_out, n);
   });
 }
 
@@ -3088,24 +3031,25 @@ int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_o
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = ensure_levels_for(ctx, max_corr_dist))) return rc;
   if ((rc = upload_state(ctx, T))) return rc;
-  const size_t n = ctx->n;
+  const size_t n = ctx->n, n_out = ctx->n_pts;     // slots searched; points reported (holes of a depth frame are not)
   HIPCHK(ctx->nn_idx.ensure(n * 4));
   HIPCHK(ctx->nn_d2.ensure(n * 4));
   HIPCHK(ctx->nn_tmp.ensure(n * 4));
   if ((rc = launch_nn<1>(ctx, false, open_gate2(max_corr_dist), ctx->nn_idx.as<uint32_t>(), ctx->nn_d2.as<float>()))) return rc;
-  const uint32_t* perm = ctx->src_sorted ? ctx->src_perm.as<uint32_t>() : nullptr;
+  const uint32_t* perm = nullptr;
+  if ((rc = source_map(ctx, &perm))) return rc;
   if (idx_out) {
     hipLaunchKernelGGL(k_unpermute<uint32_t>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream,
                        ctx->nn_idx.as<uint32_t>(), perm, (uint32_t)n, ctx->nn_tmp.as<uint32_t>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(idx_out, ctx->nn_tmp.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(idx_out, ctx->nn_tmp.p, n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   if (d2_out) {
     hipLaunchKernelGGL(k_unpermute<float>, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream,
                        ctx->nn_d2.as<float>(), perm, (uint32_t)n, ctx->nn_tmp.as<float>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(d2_out, ctx->nn_tmp.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d2_out, ctx->nn_tmp.p, n_out * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   return MA_OK;

@@ -275,14 +275,14 @@ def config_c3(eng, gold):
         r = eng.icp(ITERS, 0.0, GATE)
         icp_ms.append(r.gpu_ms)
     res_c = eng.icp(ITERS, 0.0, GATE, count_work=True, with_trace=True)
-    unproj_bytes = depth.size * depth.itemsize + 16.0 * n          # depth read once + float4 per valid pixel written
+    unproj_bytes = depth.size * depth.itemsize + 16.0 * depth.size   # depth read once + one float4 slot per pixel written (in place)
     k_us = float(np.min(kern[1:])) * 1e3
     return {"workload": "configs[2]: 1280x960 float32 depth frame -> k_unproject -> 50 ICP iterations against the 1M-point gold map",
             "valid_pixels": int(n), "upload_plus_unproject_ms_host_wall": float(np.median(walls[1:])),
             "unproject_device_us": k_us, "icp_ms": float(np.median(icp_ms[1:])),
             "it_per_s": ITERS / (float(np.median(icp_ms[1:])) * 1e-3),
             "rmse_mm": float(r.rmse * 1e3), "inliers": float(r.inliers),
-            "roofline_unproject": {"bound": "hbm", "kernel": "k_unproject (single pass)", "bytes": unproj_bytes,
+            "roofline_unproject": {"bound": "hbm", "kernel": "k_unproject (one streaming pass, in place)", "bytes": unproj_bytes,
                                    "achieved": unproj_bytes / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": unproj_bytes / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS},
             "table_words_per_point": float(res_c.trace[:, 18].mean() / n), "candidates_per_point": float(res_c.trace[:, 19].mean() / n)}

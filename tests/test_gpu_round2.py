@@ -362,12 +362,13 @@ def test_coarse_stage_uses_trajectories_on_a_half_turn_symmetric_shell(lib_built
     mapalign.release_cached_engines()
 
 
-# ----------------------------------------------------------------------------- a8, both scan forms
-def test_unprojection_direct_and_chained_forms_and_switching(engine):
-    """k_unproject reads the depth image once.  Frames whose grid is resident at once use the
-    direct form (epoch-tagged status words, no clearing between calls); larger images use the
-    chained look-back form.  Both must give the oracle's points in row-major pixel order, and
-    switching between them (stale words of the other form in the status array) must be safe."""
+# ----------------------------------------------------------------------------- a8: in-place unprojection, holes
+def test_unprojection_in_place_with_holes_sizes_and_switching(engine):
+    """k_unproject writes pixel i into slot i — a point or a hole — in one streaming pass with no exchange
+    between workgroups (round 3).  What the caller sees is unchanged: the number of valid pixels, and through
+    ma_get_source / ma_get_source_stored / ma_nn the valid pixels in row-major order (compacted lazily through
+    a rank map).  Small and large frames, ragged last workgroups, 30-55 % holes, whole invalid rows, a frame
+    without holes, and switching between sizes on one context."""
     gold, _, _, _ = syn.make_pair(2, 50_000)
     engine.set_gold(gold)
     rng = np.random.default_rng(11)
@@ -379,14 +380,27 @@ def test_unprojection_direct_and_chained_forms_and_switching(engine):
         d[rng.random((h, w)) < holes] = 0.0
         return d
 
-    small = [frame(320, 240, 0.3) for _ in range(3)]          # 75 workgroups: direct form
-    big = frame(2048, 1200, 0.55)                             # 2400 workgroups: chained form
-    for depth, K in ((small[0], K_small), (small[1], K_small), (big, K_big), (small[2], K_small), (big, K_big), (small[0], K_small)):
+    small = [frame(320, 240, 0.3) for _ in range(3)]
+    small[1][100:140] = np.nan                                # forty invalid rows
+    odd = frame(333, 17, 0.4)                                 # 5661 pixels: ragged last workgroup, rows not a multiple of 4
+    full = frame(320, 240, 0.0)                               # no hole at all: no rank map is ever built
+    big = frame(2048, 1200, 0.55)
+    for depth, K in ((small[0], K_small), (small[1], K_small), (big, K_big), (odd, K_small), (small[2], K_small), (full, K_small),
+                     (big, K_big), (small[0], K_small)):
         n = engine.set_source_from_depth(depth, K, T, 1000.0)
         ref, mask = orc.unproject_oracle(depth, K, T, 1000.0)
         assert n == int(mask.sum()) == len(ref)
         got = engine.get_source()
-        assert np.abs(got - ref).max() < 2e-5                  # fp32 storage of coordinates up to ~10 m
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-5      # fp32 storage of coordinates up to ~10 m
+        stored = engine.get_source_stored()
+        assert stored.shape == ref.shape and np.abs(stored - ref).max() < 2e-5
+        idx, d2 = engine.nn(None, 0.5)                          # per-point results come back for the valid pixels only, in order
+        assert idx.shape == (n,) and d2.shape == (n,)
+        oidx, od2 = orc.GoldIndex(gold, n_jobs=4).query(ref)
+        m = od2 <= 0.25 - 1e-4
+        assert ((idx != 0xFFFFFFFF) | ~m).all() and np.abs(d2[m] - od2[m]).max() < 2e-4
+        res = engine.icp(3, 0.0, 0.5)                           # holes contribute nothing: W counts matched valid pixels only
+        assert res.inliers <= n
     # an image without any valid pixel is an error, not an empty cloud
     with pytest.raises(mapalign.MapAlignError) as e:
         engine.set_source_from_depth(np.zeros((240, 320), np.float32), K_small, T, 1000.0)
