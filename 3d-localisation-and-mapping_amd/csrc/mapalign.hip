@@ -1540,11 +1540,86 @@ __global__ __launch_bounds__(kBlock) void k_voxel_finish(const VoxelSum* __restr
   xyz[3 * (size_t)v + 2] = (float)(s.z / s.n + o2);
 }
 
+// a10, depth rule 1 (MA_Z_MEDIAN): the comment at pose_processor.py:183 says the corners' z comes "from median
+// over bbox (x, y) range"; the body that would say how (Transforms._depth_to_3d) is absent.  This is that
+// reading: z = median of the valid depths (finite, > 0) over the box's pixel rectangle
+// [int(x1) .. int(x2)] x [int(y1) .. int(y2)] (ends included, clamped into the image), the same z for all
+// four corners; an even count averages the two middle values (numpy.median).  No valid pixel -> NaN.
+// One workgroup per box: radix select over the depth's bit pattern (positive floats and uint16 order
+// like unsigned integers), four 8-bit passes with a 256-bin LDS histogram each; exact, deterministic.
+template <typename T> __device__ __forceinline__ uint32_t depth_key(T v);
+template <> __device__ __forceinline__ uint32_t depth_key<float>(float v) { return (isfinite(v) && v > 0.f) ? __float_as_uint(v) : 0u; }
+template <> __device__ __forceinline__ uint32_t depth_key<uint16_t>(uint16_t v) { return (uint32_t)v; }
+template <typename T> __device__ __forceinline__ double key_depth(uint32_t k);
+template <> __device__ __forceinline__ double key_depth<float>(uint32_t k) { return (double)__uint_as_float(k); }
+template <> __device__ __forceinline__ double key_depth<uint16_t>(uint32_t k) { return (double)k; }
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_box_median(const T* __restrict__ depth, const int width, const int height,
+                                                       const uint32_t n_frames, const float* __restrict__ boxes,
+                                                       const uint32_t* __restrict__ box_frame, const double inv_scale,
+                                                       double* __restrict__ zmed) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t f = box_frame ? min(box_frame[b], n_frames - 1u) : 0u;
+  const T* __restrict__ img = depth + (size_t)f * width * height;
+  const float x1 = boxes[4 * b], y1 = boxes[4 * b + 1], x2 = boxes[4 * b + 2], y2 = boxes[4 * b + 3];
+  const int ua = min(max((int)x1, 0), width - 1), ub = min(max((int)x2, 0), width - 1);     // int(x), clamped: the corner pixels
+  const int va = min(max((int)y1, 0), height - 1), vb = min(max((int)y2, 0), height - 1);
+  const int u0 = min(ua, ub), u1 = max(ua, ub), v0 = min(va, vb), v1 = max(va, vb);
+  const uint32_t rw = (uint32_t)(u1 - u0 + 1), npx = rw * (uint32_t)(v1 - v0 + 1);
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh_prefix, sh_rank, sh_count;
+  uint32_t result[2] = {0u, 0u};
+  uint32_t count = 0;
+  for (int which = 0; which < 2; ++which) {         // lower and upper middle element (the same one for an odd count)
+    uint32_t prefix = 0, mask = 0, rank = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      hist[threadIdx.x] = 0u;
+      __syncthreads();
+      for (uint32_t t = threadIdx.x; t < npx; t += kBlock) {
+        const uint32_t key = depth_key<T>(img[(size_t)(v0 + (int)(t / rw)) * width + (u0 + (int)(t % rw))]);
+        if (key != 0u && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        if (shift == 24) {                          // first pass: every valid pixel is in the histogram
+          uint32_t c = 0;
+          for (int k = 0; k < 256; ++k) c += hist[k];
+          sh_count = c;
+          rank = c ? (which == 0 ? (c - 1u) / 2u : c / 2u) : 0u;
+        } else {
+          rank = sh_rank;
+        }
+        uint32_t cum = 0;
+        int bin = 0;
+        for (; bin < 255; ++bin) {
+          if (cum + hist[bin] > rank) break;
+          cum += hist[bin];
+        }
+        sh_prefix = prefix | ((uint32_t)bin << shift);
+        sh_rank = rank - cum;
+      }
+      __syncthreads();
+      prefix = sh_prefix;
+      mask |= 255u << shift;
+      count = sh_count;
+      if (count == 0u) break;
+    }
+    result[which] = prefix;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    zmed[b] = count ? 0.5 * (key_depth<T>(result[0]) * inv_scale + key_depth<T>(result[1]) * inv_scale) : (double)NAN;
+}
+
 // a10: one thread per box corner.  cam.T here is the plain camera->world matrix (world frame).
+// zmed == null: depth rule 0, the corner pixel's own depth (the call shape of pose_processor.py:184-196:
+// _depth_to_3d(int(x), int(y), depth_image, ...)); otherwise the box's median depth (k_box_median).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_lift_boxes(const T* __restrict__ depth, const int width,
                                                        const int height, const Pinhole cam,
                                                        const float* __restrict__ boxes, const uint32_t ncorners,
+                                                       const double* __restrict__ zmed,
                                                        double* __restrict__ out, uint8_t* __restrict__ valid) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= ncorners) return;
@@ -1552,7 +1627,7 @@ __global__ __launch_bounds__(kBlock) void k_lift_boxes(const T* __restrict__ dep
   const float bx = boxes[4 * b + ((k == 1u || k == 2u) ? 2 : 0)];   // x1 x2 x2 x1
   const float by = boxes[4 * b + ((k >= 2u) ? 3 : 1)];               // y1 y1 y2 y2
   const int u = min(max((int)bx, 0), width - 1), v = min(max((int)by, 0), height - 1);  // int(x), int(y)
-  double z = (double)depth[(size_t)v * width + u] * cam.inv_scale;
+  double z = zmed ? zmed[b] : (double)depth[(size_t)v * width + u] * cam.inv_scale;
   const bool ok = isfinite(z) && z > 0.0;
   if (!ok) z = NAN;
   const double X = ((double)u - cam.cx) * z * cam.fx_inv, Y = ((double)v - cam.cy) * z * cam.fy_inv;
@@ -1573,8 +1648,8 @@ __global__ __launch_bounds__(kBlock) void k_lift_boxes_batch(const T* __restrict
                                                              const double* __restrict__ poses,
                                                              const float* __restrict__ boxes,
                                                              const uint32_t* __restrict__ box_frame,
-                                                             const uint32_t ncorners, double* __restrict__ out,
-                                                             uint8_t* __restrict__ valid) {
+                                                             const uint32_t ncorners, const double* __restrict__ zmed,
+                                                             double* __restrict__ out, uint8_t* __restrict__ valid) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= ncorners) return;
   const uint32_t b = i >> 2, k = i & 3u;
@@ -1582,7 +1657,7 @@ __global__ __launch_bounds__(kBlock) void k_lift_boxes_batch(const T* __restrict
   const float bx = boxes[4 * b + ((k == 1u || k == 2u) ? 2 : 0)];   // x1 x2 x2 x1
   const float by = boxes[4 * b + ((k >= 2u) ? 3 : 1)];               // y1 y1 y2 y2
   const int u = min(max((int)bx, 0), width - 1), v = min(max((int)by, 0), height - 1);  // int(x), int(y)
-  double z = (double)depth[(size_t)f * width * height + (size_t)v * width + u] * inv_scale;
+  double z = zmed ? zmed[b] : (double)depth[(size_t)f * width * height + (size_t)v * width + u] * inv_scale;
   const bool ok = isfinite(z) && z > 0.0;
   if (!ok) z = NAN;
   const double* __restrict__ T12 = poses + 12 * (size_t)f;
@@ -2770,10 +2845,11 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
 }
 
 int ma_lift_boxes(ma_ctx* ctx, const void* depth, int dtype, int width, int height, const float K[4],
-                  const double T[16], float depth_scale, const float* boxes_xyxy, uint64_t n_boxes,
+                  const double T[16], float depth_scale, const float* boxes_xyxy, uint64_t n_boxes, int z_rule,
                   double* corners_out, uint8_t* valid_out) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
+  if (z_rule != MA_Z_CORNER && z_rule != MA_Z_MEDIAN) return ctx->fail(MA_ERR_INVALID, "z_rule must be MA_Z_CORNER or MA_Z_MEDIAN");
   if (!K || !T || (!boxes_xyxy && n_boxes) || (!corners_out && n_boxes)) return ctx->fail(MA_ERR_INVALID, "NULL argument");
   if (n_boxes == 0) return MA_OK;
   if (n_boxes > (1ull << 28)) return ctx->fail(MA_ERR_TOO_LARGE, "too many boxes");
@@ -2800,16 +2876,22 @@ int ma_lift_boxes(ma_ctx* ctx, const void* depth, int dtype, int width, int heig
     for (int c = 0; c < 4; ++c) cam.T[4 * r + c] = T[4 * r + c];
   const uint32_t nc = (uint32_t)n_boxes * 4u;
   HIPCHK(ctx->raw.ensure((size_t)n_boxes * 16));
-  HIPCHK(ctx->misc.ensure((size_t)nc * 24 + nc));
+  HIPCHK(ctx->misc.ensure((size_t)nc * 24 + nc + 8 + (size_t)n_boxes * 8));
   HIPCHK(hipMemcpyAsync(ctx->raw.p, boxes_xyxy, (size_t)n_boxes * 16, hipMemcpyHostToDevice, ctx->stream));
   double* d_out = ctx->misc.as<double>();
-  uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_out + (size_t)nc * 3);
+  double* d_zmed = d_out + (size_t)nc * 3;                               // one median depth per box (depth rule 1)
+  uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_zmed + n_boxes);
+  const double* zmed = z_rule == MA_Z_MEDIAN ? d_zmed : nullptr;
   if (ctx->depth_dtype == 0) {
+    if (zmed) hipLaunchKernelGGL(k_box_median<float>, dim3((uint32_t)n_boxes), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
+                                 ctx->depth_w, ctx->depth_h, 1u, ctx->raw.as<float>(), (const uint32_t*)nullptr, cam.inv_scale, d_zmed);
     hipLaunchKernelGGL(k_lift_boxes<float>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(),
-                       ctx->depth_w, ctx->depth_h, cam, ctx->raw.as<float>(), nc, d_out, d_valid);
+                       ctx->depth_w, ctx->depth_h, cam, ctx->raw.as<float>(), nc, zmed, d_out, d_valid);
   } else {
+    if (zmed) hipLaunchKernelGGL(k_box_median<uint16_t>, dim3((uint32_t)n_boxes), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<uint16_t>(),
+                                 ctx->depth_w, ctx->depth_h, 1u, ctx->raw.as<float>(), (const uint32_t*)nullptr, cam.inv_scale, d_zmed);
     hipLaunchKernelGGL(k_lift_boxes<uint16_t>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream,
-                       ctx->depth_in.as<uint16_t>(), ctx->depth_w, ctx->depth_h, cam, ctx->raw.as<float>(), nc, d_out, d_valid);
+                       ctx->depth_in.as<uint16_t>(), ctx->depth_w, ctx->depth_h, cam, ctx->raw.as<float>(), nc, zmed, d_out, d_valid);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(corners_out, d_out, (size_t)nc * 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -3128,9 +3210,10 @@ int ma_last_device_ms(const ma_ctx* ctx, double* ms) {
 
 int ma_lift_boxes_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int width, int height, uint32_t n_frames,
                         const float K[4], const double* T_cam_to_world, float depth_scale, const float* boxes_xyxy,
-                        const uint32_t* box_frame, uint64_t n_boxes, double* corners_out, uint8_t* valid_out) {
+                        const uint32_t* box_frame, uint64_t n_boxes, int z_rule, double* corners_out, uint8_t* valid_out) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
+  if (z_rule != MA_Z_CORNER && z_rule != MA_Z_MEDIAN) return ctx->fail(MA_ERR_INVALID, "z_rule must be MA_Z_CORNER or MA_Z_MEDIAN");
   if (!depth_frames || !K || !T_cam_to_world || (!boxes_xyxy && n_boxes) || (!box_frame && n_boxes) || (!corners_out && n_boxes))
     return ctx->fail(MA_ERR_INVALID, "NULL argument");
   if (dtype != 0 && dtype != 1) return ctx->fail(MA_ERR_INVALID, "dtype must be 0 (float32) or 1 (uint16)");
@@ -3150,7 +3233,7 @@ int ma_lift_boxes_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int wi
   HIPCHK(ctx->lift_frames.ensure(frame_bytes * n_frames));
   HIPCHK(ctx->lift_poses.ensure(poses.size() * 8 + n_boxes * 4));
   HIPCHK(ctx->raw.ensure((size_t)n_boxes * 16));
-  HIPCHK(ctx->misc.ensure((size_t)nc * 24 + nc));
+  HIPCHK(ctx->misc.ensure((size_t)nc * 24 + nc + 8 + (size_t)n_boxes * 8));
   // ONE upload of the whole batch of frames, one of the poses + frame indices, one of the boxes
   HIPCHK(hipMemcpyAsync(ctx->lift_frames.p, depth_frames, frame_bytes * n_frames, hipMemcpyDefault, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->lift_poses.p, poses.data(), poses.size() * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -3158,16 +3241,22 @@ int ma_lift_boxes_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int wi
   HIPCHK(hipMemcpyAsync(d_frame, box_frame, n_boxes * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->raw.p, boxes_xyxy, (size_t)n_boxes * 16, hipMemcpyHostToDevice, ctx->stream));
   double* d_out = ctx->misc.as<double>();
-  uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_out + (size_t)nc * 3);
+  double* d_zmed = d_out + (size_t)nc * 3;                               // one median depth per box (depth rule 1)
+  uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_zmed + n_boxes);
+  const double* zmed = z_rule == MA_Z_MEDIAN ? d_zmed : nullptr;
   const double fx_inv = 1.0 / (double)K[0], fy_inv = 1.0 / (double)K[1], inv_scale = 1.0 / (double)depth_scale;
   if (dtype == 0) {
+    if (zmed) hipLaunchKernelGGL(k_box_median<float>, dim3((uint32_t)n_boxes), dim3(kBlock), 0, ctx->stream, ctx->lift_frames.as<float>(),
+                                 width, height, n_frames, ctx->raw.as<float>(), d_frame, inv_scale, d_zmed);
     hipLaunchKernelGGL(k_lift_boxes_batch<float>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream,
                        ctx->lift_frames.as<float>(), width, height, n_frames, fx_inv, fy_inv, (double)K[2], (double)K[3],
-                       inv_scale, ctx->lift_poses.as<double>(), ctx->raw.as<float>(), d_frame, nc, d_out, d_valid);
+                       inv_scale, ctx->lift_poses.as<double>(), ctx->raw.as<float>(), d_frame, nc, zmed, d_out, d_valid);
   } else {
+    if (zmed) hipLaunchKernelGGL(k_box_median<uint16_t>, dim3((uint32_t)n_boxes), dim3(kBlock), 0, ctx->stream, ctx->lift_frames.as<uint16_t>(),
+                                 width, height, n_frames, ctx->raw.as<float>(), d_frame, inv_scale, d_zmed);
     hipLaunchKernelGGL(k_lift_boxes_batch<uint16_t>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream,
                        ctx->lift_frames.as<uint16_t>(), width, height, n_frames, fx_inv, fy_inv, (double)K[2], (double)K[3],
-                       inv_scale, ctx->lift_poses.as<double>(), ctx->raw.as<float>(), d_frame, nc, d_out, d_valid);
+                       inv_scale, ctx->lift_poses.as<double>(), ctx->raw.as<float>(), d_frame, nc, zmed, d_out, d_valid);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(corners_out, d_out, (size_t)nc * 24, hipMemcpyDeviceToHost, ctx->stream));

@@ -31,6 +31,8 @@ MA_ERR_TOO_LARGE = -7
 MA_ERR_COMM = -8
 MA_ERR_NO_MEMORY = -9
 MA_COMM_ID_BYTES = 128
+MA_Z_CORNER = 0
+MA_Z_MEDIAN = 1
 
 
 class MapAlignError(RuntimeError):
@@ -93,7 +95,7 @@ ABI = {
     "ma_map_add_depth": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p, _f64p, C.c_float, _u64p]),
     "ma_map_finish": (C.c_int, [_ctx_p, C.c_int, C.c_float, _f32p, _u64p]),
     "ma_lift_boxes": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p, _f64p, C.c_float, _f32p,
-                                C.c_uint64, _f64p, C.POINTER(C.c_uint8)]),
+                                C.c_uint64, C.c_int, _f64p, C.POINTER(C.c_uint8)]),
     "ma_get_source": (C.c_int, [_ctx_p, _f32p, _u64p]),
     "ma_get_gold": (C.c_int, [_ctx_p, _f64p, _u64p]),
     "ma_get_source_stored": (C.c_int, [_ctx_p, _f64p, _u64p]),
@@ -110,7 +112,7 @@ ABI = {
     "ma_mem_info_get": (C.c_int, [_ctx_p, C.POINTER(ma_mem_info)]),
     "ma_last_device_ms": (C.c_int, [_ctx_p, _f64p]),
     "ma_lift_boxes_batch": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, _f32p, _f64p,
-                                      C.c_float, _f32p, _u32p, C.c_uint64, _f64p, C.POINTER(C.c_uint8)]),
+                                      C.c_float, _f32p, _u32p, C.c_uint64, C.c_int, _f64p, C.POINTER(C.c_uint8)]),
     "ma_comm_unique_id": (C.c_int, [C.c_void_p]),
     "ma_comm_init": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int]),
     "ma_comm_destroy": (C.c_int, [_ctx_p]),

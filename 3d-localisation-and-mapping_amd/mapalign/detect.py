@@ -167,10 +167,30 @@ class Detector:
 
     ``model(images [B,3,H,W] in 0..1) -> [B, K, 6]`` rows ``x1 y1 x2 y2 conf cls`` in input
     pixels (YOLOv10's NMS-free output).  ``damage_classifier`` (optional) maps crops
-    ``[N,3,224,224]`` to logits (or an object with ``.logits``)."""
+    ``[N,3,224,224]`` to logits (or an object with ``.logits``).
+
+    ``crop`` — what the damage classifier is shown for a box:
+
+    * ``"box"``: the box's pixels resized straight to ``crop_size`` (one bilinear resample);
+    * ``"full_frame"``: the reference's geometry (``src/detector/detector.py:197-231`` then
+      ``src/damage/classifier.py:69-88``).  ``_perform_homography`` maps the box corners
+      ``(x1,y1) (x1,y2) (x2,y2) (x2,y1)`` onto the FRAME's corners ``(0,0) (0,H-1) (W-1,H-1) (W-1,0)``
+      and ``cv2.warpPerspective`` resamples the whole frame to ``W x H`` (bilinear, pixels from outside
+      the frame are 0) — for an axis-aligned box that homography is the scale-and-shift
+      ``x = x1 + X (x2-x1)/(W-1)``, ``y = y1 + Y (y2-y1)/(H-1)``; the written image is then read back
+      and the BEiT image processor resizes it to ``crop_size`` (PIL bilinear, i.e. with the
+      anti-aliasing triangle filter of a reduction; ``microsoft/beit-*`` preprocessor configs:
+      ``resample = 2``, no centre crop) and normalises with mean = std = 0.5.  Two resamples, not one:
+      a 60-pixel sign is first blown up to the frame and then reduced again.
+      (The reference writes ``(tf_img * 255).astype(np.uint8)`` of an image that is already uint8,
+      which wraps every value v to (256 - v) mod 256; ``pixel_wrap=True`` reproduces that too —
+      a fine-tuned model that was trained through the same code expects it.)"""
 
     def __init__(self, model, damage_classifier=None, batch_size=32, conf_thresh=0.25, device="cuda:0",
-                 half=True, crop_size=224):
+                 half=True, crop_size=224, crop="box", pixel_wrap=False):
+        if crop not in ("box", "full_frame"):
+            raise ValueError("crop must be 'box' or 'full_frame'")
+        self.crop, self.pixel_wrap = crop, bool(pixel_wrap)
         torch = _torch()
         self.device = torch.device(device)
         self.dtype = torch.float16 if (half and self.device.type == "cuda") else torch.float32
@@ -196,6 +216,33 @@ class Detector:
                 outs.append(self.model(x[s:s + self.batch_size]).float())
         return torch.cat(outs, 0), x
 
+    def full_frame_crops(self, frames, boxes):
+        """The reference's two-step resample for ``n`` boxes: ``frames`` [n,3,H,W] float32 in 0..1 (the
+        frame each box was detected in), ``boxes`` [n,4] float ``x1 y1 x2 y2`` ->
+        [n,3,crop_size,crop_size], normalised as the BEiT processor does (``(v - 0.5) / 0.5``).
+        Step 1 = detector.py:197-231 (warp of the box onto the whole frame), step 2 = the image
+        processor's resize inside classifier.py:76."""
+        torch = _torch()
+        F = torch.nn.functional
+        n, _, H, W = frames.shape
+        S = self.crop_size
+        dev = frames.device
+        x1, y1, x2, y2 = (boxes[:, k].to(torch.float32) for k in range(4))
+        X = torch.arange(W, device=dev, dtype=torch.float32) / max(W - 1, 1)
+        Y = torch.arange(H, device=dev, dtype=torch.float32) / max(H - 1, 1)
+        sx = x1[:, None] + X[None, :] * (x2 - x1)[:, None]            # source column of output column X
+        sy = y1[:, None] + Y[None, :] * (y2 - y1)[:, None]
+        gx = sx * (2.0 / max(W - 1, 1)) - 1.0                          # align_corners=True: integer coordinates are pixel centres
+        gy = sy * (2.0 / max(H - 1, 1)) - 1.0
+        grid = torch.stack([gx[:, None, :].expand(n, H, W), gy[:, :, None].expand(n, H, W)], dim=-1)
+        # cv2.warpPerspective(..., INTER_LINEAR, BORDER_CONSTANT 0): neighbours outside the frame count as 0
+        warped = F.grid_sample(frames, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+        if self.pixel_wrap:                                            # (tf_img * 255).astype(np.uint8) of a uint8 image
+            v = torch.round(warped * 255.0)
+            warped = torch.remainder(256.0 - v, 256.0) / 255.0
+        small = F.interpolate(warped, size=(S, S), mode="bilinear", antialias=True, align_corners=False)
+        return (small - 0.5) / 0.5
+
     def _damage(self, x, det, keep):
         """BEiT-style damage class of every kept box: crop, resize to crop_size, classify (classifier.py:69-88)."""
         torch = _torch()
@@ -205,6 +252,17 @@ class Detector:
         b_idx, k_idx = keep.nonzero(as_tuple=True)
         H, W = x.shape[2], x.shape[3]
         S = self.crop_size
+        if self.crop == "full_frame":
+            box = det[b_idx, k_idx, :4]
+            labels = []
+            with torch.no_grad():
+                for s in range(0, box.shape[0], self.batch_size):
+                    e = min(s + self.batch_size, box.shape[0])
+                    crops = self.full_frame_crops(x[b_idx[s:e]].float(), box[s:e])
+                    out = self.damage_classifier(crops.to(self.dtype))
+                    logits = out.logits if hasattr(out, "logits") else out
+                    labels.append(logits.argmax(-1))
+            return torch.cat(labels)
         # crop rectangles in whole pixels, as slicing image[y1:y2, x1:x2] gives them (at least 1 x 1)
         box = det[b_idx, k_idx, :4]
         xa = box[:, 0].clamp(0, W - 1).floor()
@@ -254,7 +312,7 @@ class Detector:
     __call__ = forward
 
 
-def lift_batch(engine, predictions, depth_frames, camera_intrinsics, poses, scale_depth=1000.0):
+def lift_batch(engine, predictions, depth_frames, camera_intrinsics, poses, scale_depth=1000.0, z_rule=lifting.Z_CORNER):
     """Rows of ALL frames -> global 3-D boxes in ONE device call (``ma_lift_boxes_batch``).
 
     ``predictions``: the dict :meth:`Detector.forward` returns (frame index -> rows);
@@ -277,7 +335,7 @@ def lift_batch(engine, predictions, depth_frames, camera_intrinsics, poses, scal
     scale = np.array([wd / size_img[0], hd / size_img[1], wd / size_img[0], hd / size_img[1]], dtype=np.float64)
     boxes = (np.array([row[:4] for row in rows], dtype=np.float64) * scale).astype(np.float32)
     frame_of = np.repeat(np.asarray(frames, dtype=np.uint32), counts)
-    corners, _ = engine.lift_boxes_batch(boxes, frame_of, d, K, T, scale_depth)
+    corners, _ = engine.lift_boxes_batch(boxes, frame_of, d, K, T, scale_depth, z_rule=z_rule)
     out, i = {}, 0
     for f, k in zip(frames, counts):
         out[f] = [[corners[i + r, 0], corners[i + r, 1], corners[i + r, 2], corners[i + r, 3]] + list(predictions[f][r][-3:])

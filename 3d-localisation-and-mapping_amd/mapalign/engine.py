@@ -354,11 +354,13 @@ class MapAligner:
             self.n_source = 0
         return out
 
-    def lift_boxes(self, boxes_xyxy, K, T_cam_to_world, depth=None, depth_scale=1000.0):
+    def lift_boxes(self, boxes_xyxy, K, T_cam_to_world, depth=None, depth_scale=1000.0, z_rule=0):
         """Row a10: corners (x1,y1) (x2,y1) (x2,y2) (x1,y2) of each box -> global 3-D points.
 
         ``boxes_xyxy`` [B,4] in depth-image pixels; ``depth=None`` reuses the frame uploaded by the
-        last set_source_from_depth / lift_boxes call.  Returns (corners f64 [B,4,3], valid bool [B,4])."""
+        last set_source_from_depth / lift_boxes call.  ``z_rule``: 0 = depth at the corner pixel,
+        1 = median of the valid depths over the box rectangle (``include/mapalign.h``: MA_Z_CORNER /
+        MA_Z_MEDIAN).  Returns (corners f64 [B,4,3], valid bool [B,4])."""
         b = np.ascontiguousarray(boxes_xyxy, dtype=np.float32).reshape(-1, 4)
         Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
         T = np.array(T_cam_to_world, dtype=np.float64).reshape(4, 4)
@@ -376,10 +378,10 @@ class MapAligner:
             dptr, w, h = d.ctypes.data_as(C.c_void_p), d.shape[1], d.shape[0]
         self._chk(self._lib.ma_lift_boxes(self._ctx, dptr, dtype, w, h, Kf.ctypes.data_as(C.POINTER(C.c_float)),
                                           _f64p(T), float(depth_scale), b.ctypes.data_as(C.POINTER(C.c_float)),
-                                          b.shape[0], _f64p(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
+                                          b.shape[0], int(z_rule), _f64p(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out + self._shift, valid.astype(bool)
 
-    def lift_boxes_batch(self, boxes_xyxy, box_frame, depth_frames, K, T_cam_to_world, depth_scale=1000.0):
+    def lift_boxes_batch(self, boxes_xyxy, box_frame, depth_frames, K, T_cam_to_world, depth_scale=1000.0, z_rule=0):
         """Row a10 for a whole detector batch in ONE device call: ``depth_frames`` [F,H,W]
         (float32 or uint16), ``T_cam_to_world`` [F,4,4], ``boxes_xyxy`` [B,4] in depth-resolution
         pixels, ``box_frame`` [B] = frame index of each box.  Returns (corners f64 [B,4,3], valid bool [B,4])."""
@@ -402,7 +404,7 @@ class MapAligner:
         self._chk(self._lib.ma_lift_boxes_batch(
             self._ctx, d.ctypes.data_as(C.c_void_p), dtype, w, h, F, Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T),
             float(depth_scale), b.ctypes.data_as(C.POINTER(C.c_float)), bf.ctypes.data_as(C.POINTER(C.c_uint32)),
-            b.shape[0], _f64p(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
+            b.shape[0], int(z_rule), _f64p(out), valid.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out + self._shift, valid.astype(bool)
 
     def last_device_ms(self):

@@ -12,8 +12,22 @@ for the part that touches the registered cloud: per frame
 
 The ``Transforms`` bodies are absent from the snapshot; the arithmetic follows the call
 shapes above (linear box scaling, the four corners in (x1,y1) (x2,y1) (x2,y2) (x1,y2)
-order, pinhole unprojection at the integer corner pixel).  The unprojection + pose
+order, pinhole unprojection through the integer corner pixel).  The unprojection + pose
 transform of all corners runs on the GPU (``ma_lift_boxes``).
+
+WHICH DEPTH a corner gets is the one thing the surviving lines do not settle, so it is a switch
+(``z_rule``, ``include/mapalign.h``):
+
+* ``Z_CORNER`` (default) — the depth at the corner pixel: ``_depth_to_3d`` is called with
+  ``int(x), int(y)`` and the whole depth image, once per corner (``:184-196``), and is handed no box;
+* ``Z_MEDIAN`` — the comment right above that call, "Generate 3D corners with z-values from median
+  over bbox (x, y) range" (``:183``): the median of the valid depths over the box's pixel rectangle,
+  the same z for its four corners (a sign is flat; a corner pixel often falls just OFF the sign, on the
+  wall metres behind it).
+
+``bbox_to_3d(scaled_bbox, self.img_size)`` (``:181``) also receives ``img_size``; its only use
+consistent with the following ``int(x), int(y)`` pixel reads is clamping the corners into the image,
+which both rules do (at the depth image's size, the array those pixels index).
 
 Detector rows (``src/detector/detector.py:155`` then ``:126-127``):
 ``[x1, y1, x2, y2, conf, label]`` -> after the damage classifier ``[x1, y1, x2, y2, damage_cls, conf, label]``.
@@ -22,7 +36,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .synthetic import pose_to_matrix
+from .transforms import pose_to_matrix
 
 
 def insert_damage_class(pred_row, damage_cls):
@@ -58,8 +72,11 @@ def rescaled_intrinsics(camera_intrinsics, depth_width):
             camera_intrinsics["cx"] / s, camera_intrinsics["cy"] / s)
 
 
+Z_CORNER, Z_MEDIAN = 0, 1      # include/mapalign.h: MA_Z_CORNER / MA_Z_MEDIAN
+
+
 def lift_frame_bboxes(engine, bboxes, depth_image, camera_intrinsics, pose_data, depth_width, depth_height,
-                      scale_depth=1000.0, reuse_uploaded_depth=False):
+                      scale_depth=1000.0, reuse_uploaded_depth=False, z_rule=Z_CORNER):
     """One frame of ``_3d_processing``: list of detector rows -> list of
     ``[g0, g1, g2, g3, damage_cls, conf, label]`` (corners as float64 xyz arrays).
 
@@ -72,6 +89,6 @@ def lift_frame_bboxes(engine, bboxes, depth_image, camera_intrinsics, pose_data,
     T = T if T.shape == (4, 4) else pose_to_matrix(T.reshape(-1)[:7])
     size_img = (camera_intrinsics["image_width"], camera_intrinsics["image_height"])
     scaled = np.array([scale_bounding_box(b[:4], size_img, (depth_width, depth_height)) for b in bboxes], dtype=np.float32)
-    corners, _ = engine.lift_boxes(scaled, K, T, None if reuse_uploaded_depth else depth_image, scale_depth)
+    corners, _ = engine.lift_boxes(scaled, K, T, None if reuse_uploaded_depth else depth_image, scale_depth, z_rule=z_rule)
     return [[corners[i, 0].copy(), corners[i, 1].copy(), corners[i, 2].copy(), corners[i, 3].copy()] + list(b[-3:])
             for i, b in enumerate(bboxes)]

@@ -120,25 +120,7 @@ def make_pair(seed, n_gold, n_comp=None, *, resample=True, angle_deg=GT_ANGLE_DE
     return gold.astype(np.float32), comp.astype(np.float32), R0, t
 
 
-def quat_to_rot(q):
-    """Hamilton unit quaternion (qx,qy,qz,qw) -> 3x3, the pose layout of
-    ``src/mapper/database_query.py:22`` (tx ty tz qx qy qz qw)."""
-    x, y, z, w = (float(v) for v in q)
-    n = np.sqrt(x * x + y * y + z * z + w * w)
-    x, y, z, w = x / n, y / n, z / n, w / n
-    return np.array([
-        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
-    ])
-
-
-def pose_to_matrix(pose7):
-    """[tx,ty,tz,qx,qy,qz,qw] -> 4x4 camera->world (``pose_processor.py:242-260``)."""
-    T = np.eye(4)
-    T[:3, :3] = quat_to_rot(pose7[3:7])
-    T[:3, 3] = pose7[:3]
-    return T
+from .transforms import pose_to_matrix, quat_to_rot  # noqa: E402,F401  (the pose math lives with the other transform helpers)
 
 
 def default_camera_pose():

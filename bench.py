@@ -324,13 +324,36 @@ def config_c4(eng, device):
     preds2 = det(imgs)
     detect.lift_batch(eng, preds2, depth, intr, poses)
     e2e_ms = (time.perf_counter() - t0) * 1e3
+    # the damage leg (detector.py:119-127 -> classifier.py:69-88): BEiT of the reference's architecture (random init)
+    # on every kept box, seen through the reference's crop geometry (box warped onto the frame, processor resize)
+    damage = {"skipped": "transformers has no BeitForImageClassification here"}
+    beit = detect.build_beit_like(num_labels=3)
+    if beit is not None:
+        det_d = detect.Detector(model, beit, batch_size=n_frames, conf_thresh=det.conf_thresh, device=f"cuda:{device}", half=True,
+                                crop="full_frame")
+        raw_d, x_d = det_d.infer(imgs)
+        keep = raw_d[:, :, 4] >= det_d.conf_thresh
+        for _ in range(2):
+            det_d._damage(x_d, raw_d, keep)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            labels = det_d._damage(x_d, raw_d, keep)
+        torch.cuda.synchronize()
+        dmg_ms = (time.perf_counter() - t0) / 3 * 1e3
+        n_crops = int(keep.sum())
+        damage = {"classifier": "BeitForImageClassification (base, patch 16, 224; random init)", "crop": "full_frame (detector.py:197-231)",
+                  "crops_per_detector_batch": n_crops, "classifier_ms_per_detector_batch": dmg_ms,
+                  "classifier_ms_per_batch_of_32_crops": dmg_ms / max(n_crops / 32.0, 1e-9), "crops_per_s": n_crops / (dmg_ms * 1e-3),
+                  "classes_seen": sorted(set(int(v) for v in labels.cpu().numpy()))}
+        del det_d, beit
     return {"workload": "configs[3]: batch-32 3x640x640 detector inference (random-init YOLOv10-n-shaped stand-in, fp16, "
                         "PyTorch-ROCm; ultralytics / weights are not available here) + 2D->3D lift of all boxes of the "
                         "32 frames in one ma_lift_boxes_batch call (192x256 depth frames)",
             "model_parameters_M": sum(p.numel() for p in model.parameters()) / 1e6,
             "inference_ms_per_batch": infer_ms, "frames_per_s": n_frames / (infer_ms * 1e-3),
             "boxes_lifted": int(n_boxes), "lift_ms_per_batch_host_wall": lift_ms, "boxes_per_s": n_boxes / (lift_ms * 1e-3),
-            "detect_rows_plus_lift_ms_per_batch": e2e_ms, "device_calls_per_batch_for_the_lift": 1}
+            "detect_rows_plus_lift_ms_per_batch": e2e_ms, "device_calls_per_batch_for_the_lift": 1, "damage_leg": damage}
 
 
 def config_concurrent(gold, comp, device, R0):

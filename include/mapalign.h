@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MA_VERSION 202 /* 0.2.2 */
+#define MA_VERSION 300 /* 0.3.0: z_rule argument of ma_lift_boxes / ma_lift_boxes_batch */
 #define MA_ACC_LEN 17  /* W, s_p[3], s_q[3], S[9] row-major (S_ab = sum w p'_a q_b), E */
 #define MA_TRACE_STRIDE 20 /* per-iteration trace row: acc[17], rmse, table_words_read, candidates */
 #define MA_NO_MATCH 0xFFFFFFFFu
@@ -178,21 +178,36 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
  * moved to the global frame (_transform_to_global, pose_processor.py:242-260).
  * depth == NULL reuses the frame of the last ma_set_source_from_depth / ma_lift_boxes call.
  * corners_out: n_boxes x 4 x 3 doubles; valid_out (optional): n_boxes x 4 bytes, 0 where the
- * depth at the corner pixel is <= 0 / NaN / inf (the corner is then NaN). */
+ * depth used for the corner is <= 0 / NaN / inf (the corner is then NaN).
+ *
+ * z_rule — which depth a corner gets.  The reference's two statements disagree and the body that
+ * would settle it (Transforms._depth_to_3d) is absent from the snapshot:
+ *   MA_Z_CORNER (0)  the depth AT the corner pixel — what the call does: _depth_to_3d(int(x), int(y),
+ *                    depth_image_cv, fx, fy, cx, cy, scale_depth) is handed one pixel and no box
+ *                    (pose_processor.py:184-196);
+ *   MA_Z_MEDIAN (1)  what the comment above that call says, "z-values from median over bbox (x, y)
+ *                    range" (pose_processor.py:183): the median of the valid depths over the box's pixel
+ *                    rectangle [int(x1)..int(x2)] x [int(y1)..int(y2)] (clamped into the image), the
+ *                    SAME z for the four corners, each still unprojected through its own pixel (u, v);
+ *                    an even count averages the two middle values (numpy.median); a box without a
+ *                    valid pixel gives four invalid corners.
+ * An integrator picks the one their Transforms implemented; everything else of the row is identical. */
+#define MA_Z_CORNER 0
+#define MA_Z_MEDIAN 1
 int ma_lift_boxes(ma_ctx* ctx, const void* depth, int dtype, int width, int height, const float K[4],
                   const double T_cam_to_world[16], float depth_scale, const float* boxes_xyxy,
-                  uint64_t n_boxes, double* corners_out, uint8_t* valid_out);
+                  uint64_t n_boxes, int z_rule, double* corners_out, uint8_t* valid_out);
 
 /* Row a10 for a whole detector batch (BASELINE configs[3]: batch-32 inference, detector.py:82-90,
  * then pose_processor.py:172-208 per frame): n_frames depth images of the same size stored back
  * to back, one pose per frame (n_frames x 16 doubles), one intrinsics set, and n_boxes boxes
  * [x1,y1,x2,y2] (depth-resolution pixels) with box_frame[b] = index of the frame box b was
- * detected in.  One upload, ONE kernel launch and one synchronisation for the whole batch;
- * same corner order, truncation, clamping and validity rule as ma_lift_boxes. */
+ * detected in.  One upload, ONE kernel launch (two with MA_Z_MEDIAN) and one synchronisation for the
+ * whole batch; same corner order, truncation, clamping, z_rule and validity rule as ma_lift_boxes. */
 int ma_lift_boxes_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int width, int height,
                         uint32_t n_frames, const float K[4], const double* T_cam_to_world,
                         float depth_scale, const float* boxes_xyxy, const uint32_t* box_frame,
-                        uint64_t n_boxes, double* corners_out, uint8_t* valid_out);
+                        uint64_t n_boxes, int z_rule, double* corners_out, uint8_t* valid_out);
 
 /* Copy the current source cloud back (world frame, storage order); *n in = capacity in
  * points, out = points written.  For parity tests of the unprojection kernel. */

@@ -210,10 +210,12 @@ def voxel_centroids_oracle(points, voxel, origin):
     return out + np.asarray(origin, dtype=np.float64)
 
 
-def lift_boxes_oracle(boxes_xyxy, depth, K, T_cam_to_world, depth_scale=1000.0):
+def lift_boxes_oracle(boxes_xyxy, depth, K, T_cam_to_world, depth_scale=1000.0, z_rule=0):
     """Row a10: corners (x1,y1) (x2,y1) (x2,y2) (x1,y2) at int() pixels (clamped into the
-    image) -> global points; call shape of pose_processor.py:181-201.  Returns
-    (corners [B,4,3], valid [B,4])."""
+    image) -> global points; call shape of pose_processor.py:181-201.  ``z_rule`` 0: the depth at
+    the corner pixel (what the call at :184-196 is handed); 1: the median of the valid depths over
+    the box's pixel rectangle, ends included (the comment at :183), the same z for the four
+    corners.  Returns (corners [B,4,3], valid [B,4])."""
     depth = np.asarray(depth)
     h, w = depth.shape
     fx, fy, cx, cy = (float(v) for v in K)
@@ -222,9 +224,16 @@ def lift_boxes_oracle(boxes_xyxy, depth, K, T_cam_to_world, depth_scale=1000.0):
     out = np.full((len(b), 4, 3), np.nan)
     valid = np.zeros((len(b), 4), dtype=bool)
     for i, (x1, y1, x2, y2) in enumerate(b):
+        zmed = None
+        if z_rule == 1:
+            ua, ub = (min(max(int(x), 0), w - 1) for x in (x1, x2))
+            va, vb = (min(max(int(y), 0), h - 1) for y in (y1, y2))
+            patch = depth[min(va, vb):max(va, vb) + 1, min(ua, ub):max(ua, ub) + 1].astype(np.float64) / float(depth_scale)
+            ok = np.isfinite(patch) & (patch > 0)
+            zmed = float(np.median(patch[ok])) if ok.any() else float("nan")
         for k, (x, y) in enumerate(((x1, y1), (x2, y1), (x2, y2), (x1, y2))):
             u, v = min(max(int(x), 0), w - 1), min(max(int(y), 0), h - 1)
-            z = float(depth[v, u]) / float(depth_scale)
+            z = zmed if zmed is not None else float(depth[v, u]) / float(depth_scale)
             if np.isfinite(z) and z > 0:
                 cam = np.array([(u - cx) * z / fx, (v - cy) * z / fy, z])
                 out[i, k] = T[:3, :3] @ cam + T[:3, 3]

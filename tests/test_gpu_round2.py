@@ -244,6 +244,77 @@ def test_icp_sharded_one_rank_communicator_equals_icp_bitwise(lib_built):
     assert np.array_equal(R, ref.R) and np.array_equal(t, ref.t) and info["ranks"] == 1
 
 
+# ----------------------------------------------------------------------------- a10, depth rule 1 (median over the box)
+def test_lift_boxes_median_depth_rule_vs_oracle(engine):
+    """MA_Z_MEDIAN — the reading of the comment at pose_processor.py:183 ("z-values from median over bbox (x, y)
+    range"): one z per box = median of the valid depths over its pixel rectangle.  k_box_median (radix select,
+    one workgroup per box) against numpy.median in the oracle: boxes with holes, boxes clamped into the image,
+    one-pixel boxes, even and odd numbers of valid pixels, a box without any valid pixel, float32 and uint16
+    frames, the per-frame call and the batched one, and the default rule unchanged beside it."""
+    from mapalign import lifting
+    rng = np.random.default_rng(21)
+    w, h = 192, 256
+    depth = rng.uniform(500.0, 9000.0, size=(h, w)).astype(np.float32)
+    depth[rng.random((h, w)) < 0.2] = 0.0                       # holes everywhere
+    depth[40:60, 50:80] = 0.0                                   # a block without a single valid pixel
+    depth[5, 7] = np.nan
+    depth[100:103, 20:22] = [[1000.0, 2000.0], [3000.0, 0.0], [4000.0, 5000.0]]     # a 3 x 2 patch with 5 valid pixels
+    K = (150.0, 151.0, 95.5, 127.5)
+    T = syn.pose_to_matrix([1.0, -2.0, 0.5, 0.1, -0.2, 0.3, 0.9])
+    x1 = rng.uniform(-10, 170, 60); y1 = rng.uniform(-10, 230, 60)
+    boxes = np.stack([x1, y1, x1 + rng.uniform(0, 90, 60), y1 + rng.uniform(0, 90, 60)], 1).astype(np.float32)
+    boxes[0] = [50.2, 40.7, 79.9, 59.1]                         # inside the invalid block: no valid pixel -> four invalid corners
+    boxes[1] = [20.0, 100.0, 21.9, 102.9]                       # the 3 x 2 patch: 5 valid (odd) -> the middle one, 3000
+    boxes[2] = [20.0, 100.0, 21.9, 101.9]                       # its top 2 x 2: 3 valid
+    boxes[3] = [20.0, 100.0, 20.9, 102.5]                       # left column: 1000, 3000, 4000
+    boxes[4] = [20.0, 100.0, 21.5, 100.5]                       # top row: 1000, 2000 (even) -> 1500
+    boxes[5] = [30.3, 30.8, 30.9, 30.9]                         # one pixel
+    boxes[6] = [-50.0, -50.0, 900.0, 900.0]                     # the whole image (clamped): 49 152 pixels
+    boxes[7] = [100.0, 200.0, 60.0, 150.0]                      # corners given the other way round
+    depth[30, 30] = 1234.0
+    oc, ov = orc.lift_boxes_oracle(boxes, depth, K, T, 1000.0, z_rule=1)
+    assert not ov[0].any() and ov[1].all()
+    cam1 = np.linalg.inv(T) @ np.append(oc[1, 0], 1.0)
+    assert abs(cam1[2] - 3.0) < 1e-12                           # the oracle itself: median of {1,2,3,4,5} m
+    cam4 = np.linalg.inv(T) @ np.append(oc[4, 0], 1.0)
+    assert abs(cam4[2] - 1.5) < 1e-12                           # even count: mean of the two middle values
+    corners, valid = engine.lift_boxes(boxes, K, T, depth, 1000.0, z_rule=lifting.Z_MEDIAN)
+    assert np.array_equal(valid, ov)
+    assert np.allclose(corners[valid], oc[ov], atol=1e-9) and np.isnan(corners[~valid]).all()
+    # the four corners of a box share z in the camera frame
+    cam = (corners[1] - T[:3, 3]) @ T[:3, :3]
+    assert np.allclose(cam[:, 2], 3.0, atol=1e-12)
+    # default rule beside it: unchanged, and different where the corner pixel is not the median
+    c0, v0 = engine.lift_boxes(boxes, K, T, None, 1000.0)
+    o0, ov0 = orc.lift_boxes_oracle(boxes, depth, K, T, 1000.0)
+    assert np.array_equal(v0, ov0) and np.allclose(c0[v0], o0[ov0], atol=1e-9)
+    assert not np.allclose(np.nan_to_num(c0), np.nan_to_num(corners))
+    # uint16 frames
+    d16 = np.clip(np.round(np.nan_to_num(depth)), 0, 65535).astype(np.uint16)
+    oc16, ov16 = orc.lift_boxes_oracle(boxes, d16, K, T, 1000.0, z_rule=1)
+    c16, v16 = engine.lift_boxes(boxes, K, T, d16, 1000.0, z_rule=1)
+    assert np.array_equal(v16, ov16) and np.allclose(c16[v16], oc16[ov16], atol=1e-9)
+    # the batched call: three frames, boxes spread over them
+    frames = np.stack([depth, np.roll(depth, 17, axis=1), np.roll(depth, 31, axis=0)])
+    poses = np.stack([T, syn.pose_to_matrix([0.0, 1.0, 2.0, 0.3, 0.1, -0.2, 0.9]), np.eye(4)])
+    bf = (np.arange(len(boxes)) % 3).astype(np.uint32)
+    cb, vb = engine.lift_boxes_batch(boxes, bf, frames, K, poses, 1000.0, z_rule=1)
+    for f in range(3):
+        m = bf == f
+        of, ovf = orc.lift_boxes_oracle(boxes[m], frames[f], K, poses[f], 1000.0, z_rule=1)
+        assert np.array_equal(vb[m], ovf) and np.allclose(cb[m][ovf], of[ovf], atol=1e-9)
+    with pytest.raises(mapalign.MapAlignError) as e:
+        engine.lift_boxes(boxes, K, T, depth, 1000.0, z_rule=2)
+    assert e.value.status == _lib.MA_ERR_INVALID
+    # the per-frame helper passes the rule on
+    intr = {"image_width": 1920, "image_height": 2560, "fx": 1500.0, "fy": 1510.0, "cx": 955.0, "cy": 1275.0}
+    dets = [[400.0, 500.0, 900.0, 1500.0, 2, 0.9, "exit"]]
+    rows = lifting.lift_frame_bboxes(engine, dets, depth, intr, T, w, h, z_rule=lifting.Z_MEDIAN)
+    sb = np.array([lifting.scale_bounding_box(dets[0][:4], (1920, 2560), (w, h))])
+    om, _ = orc.lift_boxes_oracle(sb, depth, lifting.rescaled_intrinsics(intr, w), T, 1000.0, z_rule=1)
+    assert np.allclose(np.array(rows[0][:4]), om[0], atol=1e-9)
+
+
 # ----------------------------------------------------------------------------- configs[3]
 def _frames(n_frames, w, h, seed):
     rng = np.random.default_rng(seed)
@@ -327,6 +398,27 @@ def test_config4_batch32_detector_and_one_call_lift(engine):
     mid = engine.mem_info()["device_allocs"]
     detect.lift_batch(engine, preds, depth, intr, poses)
     assert engine.mem_info()["device_allocs"] == mid and mid >= before
+    # the damage leg on the GPU: a BEiT classifier of the reference's architecture
+    # (BeitForImageClassification, classifier.py:40-53; random init: the fine-tuned weights are not shipped) sees
+    # every kept box through the reference's crop geometry (detector.py:197-231: box warped onto the whole frame,
+    # then the processor's resize) and its class lands in column 4 of the rows (detector.py:126-127)
+    beit = detect.build_beit_like(num_labels=3)
+    if beit is None:
+        pytest.skip("transformers has no BeitForImageClassification here")
+    det2 = detect.Detector(model, beit, batch_size=32, conf_thresh=det.conf_thresh, device="cuda:0", half=True, crop="full_frame")
+    preds2 = det2(imgs[:4])
+    assert [len(preds2[b]) for b in range(4)] == [len(preds[b]) for b in range(4)]
+    rows2 = [r for b in range(4) for r in preds2[b]]
+    assert rows2 and all(len(r) == 7 and r[4] in (0, 1, 2) for r in rows2)
+    assert all(np.allclose(r2[:4], r1[:4], atol=1e-3) and r2[6] == r1[6] for r2, r1 in zip(preds2[0], preds[0]))
+    # the classes are those of the classifier run by hand on the same crops
+    raw4, x4 = det2.infer(imgs[:4])
+    keep = raw4[:, :, 4] >= det2.conf_thresh
+    b_idx, k_idx = keep.nonzero(as_tuple=True)
+    with torch.no_grad():
+        crops = det2.full_frame_crops(x4[b_idx[:32]].float(), raw4[b_idx[:32], k_idx[:32], :4])
+        want = beit(crops.to(det2.dtype)).logits.argmax(-1).cpu().numpy()
+    assert [r[4] for r in rows2[:len(want)]] == list(want)
 
 
 # ----------------------------------------------------------------------------- N1 with trajectories

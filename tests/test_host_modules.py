@@ -236,7 +236,7 @@ def test_detector_adaptor_rows_and_batched_lift_bookkeeping():
             k += 1
 
     class FakeEngine:   # records what lift_batch hands to the ONE device call
-        def lift_boxes_batch(self, b, bf, d, K, T, scale):
+        def lift_boxes_batch(self, b, bf, d, K, T, scale, z_rule=0):
             self.args = (b, bf, d.shape, K, T.shape, scale)
             return np.zeros((len(b), 4, 3)), np.ones((len(b), 4), bool)
 
@@ -301,3 +301,107 @@ def test_align_many_scheduling_with_stand_in_contexts(monkeypatch):
     with pytest.raises(ValueError, match="bad scan"):
         api.align_many(bad, workers=3)
     assert api.align_many([], workers=3) == []
+
+
+def _pil_bilinear_weights(n_in, n_out):
+    """PIL's ImagingResample coefficients for the triangle (bilinear) filter, which widens its support
+    by the reduction factor (anti-aliasing): row i of the [n_out, n_in] matrix."""
+    scale = n_in / n_out
+    fs = max(scale, 1.0)
+    Wm = np.zeros((n_out, n_in))
+    for i in range(n_out):
+        centre = (i + 0.5) * scale
+        lo, hi = max(int(centre - fs + 0.5), 0), min(int(centre + fs + 0.5), n_in)
+        k = np.arange(lo, hi)
+        w = np.clip(1.0 - np.abs((k + 0.5 - centre) / fs), 0.0, None)
+        Wm[i, lo:hi] = w / w.sum()
+    return Wm
+
+
+def _full_frame_crop_numpy(img, box, S):
+    """NumPy restatement of the reference's two-step resample for ONE box (detector.py:197-231, then the BEiT
+    processor's resize): img [3,H,W] in 0..1 -> [3,S,S] normalised to mean = std = 0.5."""
+    _, H, W = img.shape
+    x1, y1, x2, y2 = (float(v) for v in box)
+    sx = x1 + np.arange(W) / (W - 1) * (x2 - x1)
+    sy = y1 + np.arange(H) / (H - 1) * (y2 - y1)
+    pad = np.zeros((3, H + 2, W + 2))
+    pad[:, 1:-1, 1:-1] = img                                    # BORDER_CONSTANT 0: one ring of zeros is all bilinear can reach
+
+    def taps(s, n):
+        f = np.floor(s)
+        a = s - f
+        i0 = np.clip(f.astype(int) + 1, 0, n + 1)               # index into the padded axis
+        i1 = np.clip(f.astype(int) + 2, 0, n + 1)
+        inside0 = (f >= -1) & (f <= n - 1)
+        inside1 = (f + 1 >= -1) & (f + 1 <= n)
+        return i0, i1, np.where(inside0, 1.0 - a, 0.0), np.where(inside1, a, 0.0)
+
+    xi0, xi1, xw0, xw1 = taps(sx, W)
+    yi0, yi1, yw0, yw1 = taps(sy, H)
+    rows = pad[:, yi0, :] * yw0[None, :, None] + pad[:, yi1, :] * yw1[None, :, None]         # [3,H,W+2]
+    warped = rows[:, :, xi0] * xw0[None, None, :] + rows[:, :, xi1] * xw1[None, None, :]     # [3,H,W]
+    Wy, Wx = _pil_bilinear_weights(H, S), _pil_bilinear_weights(W, S)
+    small = np.einsum("ih,chw,jw->cij", Wy, warped, Wx)
+    return (small - 0.5) / 0.5
+
+
+def test_full_frame_crop_matches_a_numpy_restatement_of_the_references_two_step_resample():
+    """crop="full_frame" (detector.py:197-231 + the image processor of classifier.py:76): the box is warped onto
+    the WHOLE frame (bilinear, zeros outside) and that frame-sized image is reduced to 224 (PIL-style bilinear with
+    its anti-aliasing support) and normalised — against an independent NumPy restatement, on the CPU."""
+    import torch
+    from mapalign import detect
+
+    rng = np.random.default_rng(4)
+    H, W, S = 48, 64, 16
+    imgs = rng.random((3, 3, H, W)).astype(np.float32)
+    boxes = np.array([[10.3, 5.8, 40.9, 30.2],         # an ordinary box
+                      [-6.0, -4.0, 20.5, 18.0],        # reaches outside the frame: zeros come in
+                      [50.0, 40.0, 70.0, 55.0]],       # over the far corner
+                     dtype=np.float32)
+
+    class Identity(torch.nn.Module):
+        def forward(self, x):
+            return x
+
+    det = detect.Detector(Identity(), None, device="cpu", half=False, crop_size=S, crop="full_frame")
+    got = det.full_frame_crops(torch.from_numpy(imgs), torch.from_numpy(boxes)).numpy()
+    for k in range(3):
+        want = _full_frame_crop_numpy(imgs[k].astype(np.float64), boxes[k], S)
+        assert np.abs(got[k] - want).max() < 2e-5, (k, np.abs(got[k] - want).max())
+    # the reference's uint8 wrap-around, on request: v -> (256 - v) mod 256
+    detw = detect.Detector(Identity(), None, device="cpu", half=False, crop_size=S, crop="full_frame", pixel_wrap=True)
+    q = (np.round(rng.random((1, 3, H, W)) * 255) / 255).astype(np.float32)
+    full = np.array([[0.0, 0.0, W - 1.0, H - 1.0]], dtype=np.float32)            # the identity warp
+    gw = detw.full_frame_crops(torch.from_numpy(q), torch.from_numpy(full)).numpy()
+    wrapped = np.mod(256.0 - np.round(q[0].astype(np.float64) * 255), 256.0) / 255.0
+    Wy, Wx = _pil_bilinear_weights(H, S), _pil_bilinear_weights(W, S)
+    assert np.abs(gw[0] - (np.einsum("ih,chw,jw->cij", Wy, wrapped, Wx) - 0.5) / 0.5).max() < 2e-5
+    with pytest.raises(ValueError):
+        detect.Detector(Identity(), None, device="cpu", crop="centre")
+
+
+def test_damage_labels_through_the_full_frame_crop_with_a_toy_classifier():
+    """Detector.forward with crop="full_frame": rows keep the reference's schema, and the class comes from the
+    classifier's view of the warped box (a toy classifier that thresholds the mean of what it is shown)."""
+    import torch
+    from mapalign import detect
+
+    class OneBox(torch.nn.Module):                    # one fixed box per image, confidence 0.9, label 3
+        def forward(self, x):
+            b = x.shape[0]
+            row = torch.tensor([8.0, 8.0, 23.0, 23.0, 0.9, 3.0])
+            return row.repeat(b, 1, 1)
+
+    class Bright(torch.nn.Module):
+        def forward(self, crops):
+            m = crops.mean(dim=(1, 2, 3))
+            return torch.stack([-m, m], 1)            # class 1 if the (normalised) crop is bright
+
+    imgs = np.zeros((2, 32, 32, 3), dtype=np.uint8)
+    imgs[1, 8:24, 8:24] = 255                         # image 1: the box is white, everything else black
+    det = detect.Detector(OneBox(), Bright(), device="cpu", half=False, crop_size=8, crop="full_frame", conf_thresh=0.5)
+    preds = det(imgs)
+    assert [len(preds[0][0]), preds[0][0][4], preds[1][0][4]] == [7, 0, 1]
+    assert preds[1][0][:4] == [8.0, 8.0, 23.0, 23.0] and preds[1][0][5:] == [pytest.approx(0.9), 3]

@@ -220,3 +220,20 @@ def test_kabsch_weights_are_not_counts():
         wk = np.zeros(500)
         wk[:k] = 5.0
         assert not orc.kabsch_from_acc(orc.accumulate(p, q, wk, np.zeros(500)))[2]
+
+
+def test_lift_boxes_oracle_median_rule_known_answers():
+    """z_rule = 1 (the comment at pose_processor.py:183): median of the valid depths over the box's pixel
+    rectangle, ends included; even counts average the middle pair; no valid pixel -> invalid corners."""
+    depth = np.zeros((6, 8), dtype=np.float32)
+    depth[1:4, 2:4] = [[1000.0, 2000.0], [3000.0, 0.0], [4000.0, 5000.0]]
+    K, T = (10.0, 10.0, 4.0, 3.0), np.eye(4)
+    c, v = orc.lift_boxes_oracle([[2.2, 1.9, 3.9, 3.1]], depth, K, T, 1000.0, z_rule=1)
+    assert v.all() and np.allclose(c[0, :, 2], 3.0)                       # {1,2,3,4,5} m
+    assert np.allclose(c[0, 0], [(2 - 4.0) * 3.0 / 10.0, (1 - 3.0) * 3.0 / 10.0, 3.0])   # each corner through its own pixel
+    c, v = orc.lift_boxes_oracle([[2.0, 1.0, 3.5, 1.5]], depth, K, T, 1000.0, z_rule=1)
+    assert np.allclose(c[0, :, 2], 1.5)                                   # {1,2} m -> 1.5
+    c, v = orc.lift_boxes_oracle([[5.0, 4.0, 7.0, 5.0]], depth, K, T, 1000.0, z_rule=1)
+    assert not v.any() and np.isnan(c).all()
+    c0, v0 = orc.lift_boxes_oracle([[2.2, 1.9, 3.9, 3.1]], depth, K, T, 1000.0)      # rule 0 beside it: corner pixels
+    assert np.allclose(c0[0, :, 2][v0[0]], [1.0, 2.0, 5.0, 4.0][:int(v0[0].sum())]) or v0[0].sum() == 4
