@@ -25,7 +25,7 @@ import pickle
 import numpy as np
 
 from . import boxes, coarse, ply, transforms
-from ._lib import MapAlignError
+from ._lib import MA_ERR_DEGENERATE, MapAlignError
 from .api import cached_engine
 
 DATA_ROOT = os.path.join("src", "common", "data")     # visualise.py:241
@@ -85,8 +85,10 @@ class Alignment:
             for gate, iters in self.gate_schedule:          # wide gates first: pulls a rough start into the final gate's basin
                 try:
                     r = eng.icp(int(iters), 1e-5, float(gate), init=T)
-                except MapAlignError:                       # nothing inside this gate (or collinear): keep T, try the next one
-                    continue
+                except MapAlignError as e:
+                    if e.status != MA_ERR_DEGENERATE:       # only "nothing inside this gate (or collinear)" may be skipped
+                        raise
+                    continue                                # keep T, try the next gate
                 T, gpu_ms = r.T, gpu_ms + r.gpu_ms
                 widened.append((float(gate), r.iterations, r.rmse))
             res = eng.icp(self.max_iter, self.tol, self.max_corr_dist, init=T)

@@ -18,7 +18,7 @@ import threading
 
 import numpy as np
 
-from ._lib import MapAlignError
+from ._lib import MA_ERR_DEGENERATE, MapAlignError
 from .engine import MapAligner
 
 DEFAULT_MAX_ITER = 50
@@ -101,14 +101,17 @@ def align(gold_cloud, comparison_cloud, *, max_iter=DEFAULT_MAX_ITER, tol=DEFAUL
         grid = None
     with lock:
         if gold_cloud is not None:
-            grid = eng.set_gold(gold_cloud, cell)
-        eng.set_source(comparison_cloud, weights)
+            grid = eng.set_pair(gold_cloud, comparison_cloud, weights, cell)    # the scan crosses PCIe while the gold map is indexed
+        else:
+            eng.set_source(comparison_cloud, weights)
         widened = []
         for gate, iters in (gate_schedule or ()):
             try:
                 r = eng.icp(max_iter=int(iters), tol=1e-5, max_corr_dist=float(gate), init=init)
-            except MapAlignError:            # nothing inside this gate: keep the start, try the next one
-                continue
+            except MapAlignError as e:
+                if e.status != MA_ERR_DEGENERATE:    # a device fault or a call-order error is not "nothing inside this gate"
+                    raise
+                continue                             # nothing inside this gate: keep the start, try the next one
             init = r.T
             widened.append((float(gate), r.iterations, r.rmse))
         res = eng.icp(max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist, init=init,
@@ -158,7 +161,10 @@ def align_many(pairs, *, max_iter=DEFAULT_MAX_ITER, tol=DEFAULT_TOL, max_corr_di
 
     def run(slot):
         eng, lock = cached_engine(device, slot)
-        held = None          # the gold array this worker's context currently holds (kept alive, compared by identity)
+        # Which gold array the context holds is recorded ON THE ENGINE (eng.gold_token, cleared by every
+        # set_gold / set_pair / map_finish(as_gold), read and written under the engine's lock): the cached
+        # contexts are shared with align() and with other align_many() calls, which may install another
+        # gold map between two of this worker's jobs.
         while True:
             job = take()
             if job is None:
@@ -171,11 +177,11 @@ def align_many(pairs, *, max_iter=DEFAULT_MAX_ITER, tol=DEFAULT_TOL, max_corr_di
                         results[i] = g.engine.icp(max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist).T
                     continue
                 with lock:
-                    if g is not held:             # one gold map, many scans: every worker indexes it once
-                        held = None
-                        eng.set_gold(g, cell)
-                        held = g
-                    eng.set_source(c)
+                    if eng.gold_token is not g:   # one gold map, many scans: every worker indexes it once
+                        eng.set_pair(g, c, None, cell)
+                        eng.gold_token = g        # (kept alive by the engine, compared by identity)
+                    else:
+                        eng.set_source(c)
                     results[i] = eng.icp(max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist).T
             except BaseException as e:      # reported below, for the first failing pair
                 with guard:

@@ -46,6 +46,21 @@ def _world(group=None):
     return 1, 0
 
 
+def all_ranks_ready(ok, group=None, device=None):
+    """all-reduce(MIN) of a readiness flag over the torch group (any backend): True iff every rank passed True."""
+    import torch
+    import torch.distributed as dist
+
+    world, _ = _world(group)
+    if world == 1:
+        return bool(ok)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = (f"cuda:{torch.cuda.current_device() if device is None else device}") if on_gpu else "cpu"
+    flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return float(flag.item()) >= 1.0
+
+
 def bootstrap_comm(aligner, group=None):
     """Give ``aligner`` (a :class:`mapalign.MapAligner`) an RCCL communicator spanning the
     ranks of ``group``: rank 0 draws the ``ncclUniqueId`` in the library, the 128 bytes travel
@@ -130,13 +145,27 @@ def sharded_align(gold_cloud, comparison_cloud, *, max_iter=50, tol=0.0, max_cor
     world, rank = _world(group)
     device = torch.cuda.current_device() if device is None else device
     comp = np.asarray(comparison_cloud)
+    if len(comp) < world:            # the same on every rank (all pass the same cloud): nobody enters a collective
+        raise ValueError(f"more ranks ({world}) than comparison points ({len(comp)})")
     lo, hi = shard_bounds(len(comp), world, rank)
-    if hi <= lo:
-        raise ValueError("more ranks than comparison points")
     with MapAligner(device) as eng:
-        eng.set_gold(gold_cloud, cell)
-        eng.set_source(comp[lo:hi])
+        # Rank-local staging can fail on ONE rank (its shard, its device, its librccl).  The ranks agree that
+        # everybody is ready BEFORE anyone enters the communicator bootstrap or the loop's all-reduce, where a
+        # missing rank would leave the others waiting for ever.
+        err = None
+        try:
+            eng.set_gold(gold_cloud, cell)
+            eng.set_source(comp[lo:hi])
+            if rank != 0:
+                eng.comm_unique_id()     # can this rank load librccl at all?  (rank 0 finds out in bootstrap_comm)
+        except Exception as e:           # noqa: BLE001 - reported on every rank below
+            err = e
+        if not all_ranks_ready(err is None, group, device):
+            raise RuntimeError(f"sharded_align: staging failed on rank {rank}: {err}" if err is not None else
+                               "sharded_align: staging failed on another rank of the group")
         bootstrap_comm(eng, group)
+        # (an error returned from ma_icp_sharded mid-loop leaves the communicator unusable: its peers may still
+        # sit in an all-reduce; tear the process group down rather than retrying on it)
         res = eng.icp_sharded(max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist, init=init)
         eng.comm_destroy()
     if return_info:

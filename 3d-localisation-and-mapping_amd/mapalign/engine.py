@@ -169,6 +169,7 @@ class MapAligner:
         self._shift = np.zeros(3)
         self._map_shift = None
         self._comm_ranks = 0
+        self.gold_token = None          # set by callers that want to know whether "their" gold map is still installed (api.align_many)
 
     # -- lifetime -------------------------------------------------------------------
     def close(self):
@@ -214,6 +215,7 @@ class MapAligner:
     def set_gold(self, gold_cloud, cell=0.0):
         """``gold_cloud``: [M,3] host array-like, or a float32 / float64 array already in this GPU's
         memory (torch CUDA tensor / ``__cuda_array_interface__``) — then nothing crosses PCIe."""
+        self.gold_token = None
         dev = _device_array(gold_cloud, "gold_cloud", self.device, (3,), ("<f4", "<f8"))
         if dev is not None:
             ptr, shape, typestr, _keep = dev
@@ -300,6 +302,35 @@ class MapAligner:
             self._chk(self._lib.ma_set_source(self._ctx, xyz_p, w_p, n))
         self.n_source = n
 
+    def set_pair(self, gold_cloud, comparison_cloud, weights=None, cell=0.0):
+        """``set_gold`` + ``set_source`` of one pair.  Two float32 HOST arrays go through ``ma_set_pair``,
+        which uploads the comparison cloud while the gold map is being indexed (same state afterwards,
+        bitwise); anything else (fp64, device-resident, weights on the device) takes the two calls."""
+        def plain_f32_host(a):
+            return (_device_array(a, "cloud", self.device, None, ("<f4", "<f8")) is None
+                    and isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[1:] == (3,)
+                    and a.shape[0] > 0)
+        w_ok = weights is None or (isinstance(weights, np.ndarray) and weights.ndim == 1)
+        if not (plain_f32_host(gold_cloud) and plain_f32_host(comparison_cloud) and w_ok):
+            grid = self.set_gold(gold_cloud, cell)
+            self.set_source(comparison_cloud, weights)
+            return grid
+        g, c = np.ascontiguousarray(gold_cloud), np.ascontiguousarray(comparison_cloud)
+        fp = C.POINTER(C.c_float)
+        w_p = None
+        if weights is not None:
+            w = np.ascontiguousarray(weights, dtype=np.float32)
+            if w.shape[0] != c.shape[0]:
+                raise ValueError("weights must have one entry per comparison point")
+            w_p = w.ctypes.data_as(fp)
+        self._shift = np.zeros(3)
+        self.n_gold = self.n_source = 0
+        self.gold_token = None
+        self._chk(self._lib.ma_set_pair(self._ctx, g.ctypes.data_as(fp), g.shape[0], float(cell), c.ctypes.data_as(fp), w_p,
+                                        c.shape[0]))
+        self.n_gold, self.n_source = g.shape[0], c.shape[0]
+        return self.grid_info()
+
     def set_source_from_depth(self, depth, K, T_cam_to_world, depth_scale=1000.0):
         """Fused depth -> world unprojection into the source buffer (row a8).  Returns #valid pixels."""
         d_p, dtype, width, height, _keep = _depth_image(depth, self.device)
@@ -349,6 +380,7 @@ class MapAligner:
                                               arr.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)))
             out = arr if not np.any(shift != 0.0) else arr.astype(np.float64) + shift
         if as_gold:
+            self.gold_token = None
             self._shift = shift.copy()
             self.n_gold = int(n.value)
             self.n_source = 0

