@@ -40,7 +40,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -260,13 +262,17 @@ __global__ __launch_bounds__(kBlock) void k_mark_cells(const float* __restrict__
   mark[cell_of(x, y, z, g)] = 1;
 }
 
-// marks: 0 / 1 bytes, padded with zeros to a multiple of 16
-__global__ __launch_bounds__(kBlock) void k_count_marks(const uint4* __restrict__ mark16, uint32_t n16,
+// marks: 0 / 1 bytes, padded with zeros to a multiple of 16.  Counts them AND clears them (the next probe
+// marks the same table: no memset between probes — 5 of a probe's 25 us in round 2), with a few hundred
+// large workgroups: the count ends in one atomic add per workgroup on one address, and those queue
+// (859 workgroups: 12 us for 3.5 MB; 256: 4 us).
+__global__ __launch_bounds__(kBlock) void k_count_marks(uint4* __restrict__ mark16, uint32_t n16,
                                                         unsigned long long* __restrict__ out) {
   uint32_t c = 0;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n16; i += gridDim.x * kBlock) {
     const uint4 v = mark16[i];
     c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    if (v.x | v.y | v.z | v.w) mark16[i] = make_uint4(0u, 0u, 0u, 0u);
   }
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
@@ -305,22 +311,31 @@ __global__ __launch_bounds__(kBlock) void k_gather4(const float4* __restrict__ g
   out[pos] = v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_count_occupied(const uint32_t* __restrict__ counts,
-                                                           uint32_t ncells,
-                                                           unsigned long long* __restrict__ out) {
-  uint32_t c = 0;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ncells; i += gridDim.x * kBlock)
-    c += counts[i] != 0u;
-  // one atomic per workgroup (one per wavefront made this kernel atomic-bound: 155 us for 14 MB)
-  __shared__ double part[kBlock / kWave];
-  const double v = wave_sum((double)c);
-  if ((threadIdx.x & (kWave - 1)) == kSumLane) part[threadIdx.x / kWave] = v;
+// Cell table without a histogram (round 3).  Round 2 counted the points of every cell with one integer atomic
+// per point beside the key computation (k_cell_keys: 54 us with, 8 us without, for 1M points) and turned the
+// counts into starts with an exclusive sum.  The sorted keys already hold the same information: a run of equal
+// keys ENDS at position i iff keys[i + 1] differs, and cstart[c] = number of points with key < c = the largest
+// run end among the cells in front of c.  So: tails[key] = i + 1 at every run end (a scatter of one word per
+// OCCUPIED cell into a zeroed table), then an exclusive MAX-scan over the cells.  The number of occupied cells
+// (ma_grid_info: informational) is the number of run ends: one count per workgroup, summed on the host.
+__global__ __launch_bounds__(kBlock) void k_cell_tails(const uint32_t* __restrict__ sorted_keys, const uint32_t n,
+                                                       uint32_t* __restrict__ tails, uint32_t* __restrict__ ends_per_block) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  bool end = false;
+  if (i < n) {
+    const uint32_t k = sorted_keys[i];
+    end = i + 1 == n || sorted_keys[i + 1] != k;
+    if (end) tails[k] = i + 1u;
+  }
+  const uint32_t c = (uint32_t)__popcll(__ballot(end));
+  __shared__ uint32_t part[kBlock / kWave];
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double t = 0.0;
+    uint32_t t = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / kWave; ++w) t += part[w];
-    if (t > 0.0) atomicAdd(out, (unsigned long long)t);
+    ends_per_block[blockIdx.x] = t;
   }
 }
 
@@ -1806,6 +1821,7 @@ struct ma_ctx {
   // scratch for builds
   DevBuf raw, raw64, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
   DevBuf raw_src;                // ma_set_pair: the scan is uploaded here while the gold map is being built from `raw`
+  DevBuf akeys_a, akeys_b, avals_a, avals_b, acub_tmp, amisc;     // ... and sorted with its own scratch on its own stream
   hipStream_t aux_stream = nullptr;
 
   // batched box lifting (a10 over many frames)
@@ -1834,13 +1850,28 @@ struct ma_ctx {
   double ktimes[4] = {0, 0, 0, 0};
   std::vector<float> iter_ms;    // MA_FLAG_TIME_KERNELS: per iteration {search launch, reduce + solve launch}
 
+  std::mutex err_mu;             // ma_set_pair stages the scan on a helper thread: both threads may report
   int fail(int code, const std::string& msg) {
+    std::lock_guard<std::mutex> lock(err_mu);
     err = msg;
     return code;
   }
+  // ma_set_pair: the gold build tells the helper thread the cell edge as soon as it is chosen, so that the
+  // scan's own sort (which uses it) runs beside the rest of the gold build; state 0 waiting, 1 go, 2 abort
+  struct PairHandoff {
+    std::mutex m;
+    std::condition_variable cv;
+    int state = 0;
+    float cell = 0.f;
+    void set(int st, float c) {
+      { std::lock_guard<std::mutex> lock(m); if (state != 0) return; state = st; cell = c; }
+      cv.notify_all();
+    }
+  };
+  PairHandoff* pair_handoff = nullptr;
   std::vector<DevBuf*> all_bufs() {
     std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b,
-                              &src, &src_perm, &raw, &raw_src, &raw64, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
+                              &src, &src_perm, &raw, &raw_src, &akeys_a, &akeys_b, &avals_a, &avals_b, &acub_tmp, &amisc, &raw64, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
                               &depth_in, &lift_poses, &lift_frames, &unproj_cnt, &state, &partials, &trace, &acc19, &ticket,
                               &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
     for (int l = 0; l < kLevels; ++l) { v.push_back(&gold[l]); v.push_back(&cstart[l]); }
@@ -1933,16 +1964,29 @@ int need_ready(ma_ctx* ctx) {
   return MA_OK;
 }
 
+// A lane = one stream plus the scratch buffers the staging steps of a cloud use on it.  Everything runs on
+// the main lane (the context's stream) except the scan of ma_set_pair, which is staged on the aux lane by a
+// helper thread while the main lane builds the gold map.
+struct Lane {
+  hipStream_t stream;
+  DevBuf *keys_a, *keys_b, *vals_a, *vals_b, *cub_tmp, *misc;
+};
+Lane main_lane(ma_ctx* ctx) { return {ctx->stream, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc}; }
+Lane aux_lane(ma_ctx* ctx) { return {ctx->aux_stream, &ctx->akeys_a, &ctx->akeys_b, &ctx->avals_a, &ctx->avals_b, &ctx->acub_tmp, &ctx->amisc}; }
+
 // bounding box (and finiteness check) of a device-resident n x 3 cloud
-int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3], int stride = 3, bool holes_ok = false) {
+int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3], int stride = 3, bool holes_ok = false,
+                 const Lane* lane = nullptr) {
+  const Lane ml = main_lane(ctx);
+  const Lane& L = lane ? *lane : ml;
   const int nb = std::min<uint32_t>(div_up(n, kBlock), 1024);
-  HIPCHK(ctx->misc.ensure((size_t)nb * 8 * sizeof(float)));
-  if (stride == 4) hipLaunchKernelGGL(k_minmax<4>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, ctx->misc.as<float>(), holes_ok ? 1 : 0);
-  else hipLaunchKernelGGL(k_minmax<3>, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, ctx->misc.as<float>(), 0);
+  HIPCHK(L.misc->ensure((size_t)nb * 8 * sizeof(float)));
+  if (stride == 4) hipLaunchKernelGGL(k_minmax<4>, dim3(nb), dim3(kBlock), 0, L.stream, d_xyz, n, L.misc->as<float>(), holes_ok ? 1 : 0);
+  else hipLaunchKernelGGL(k_minmax<3>, dim3(nb), dim3(kBlock), 0, L.stream, d_xyz, n, L.misc->as<float>(), 0);
   HIPCHK(hipGetLastError());
   std::vector<float> h((size_t)nb * 8);
-  HIPCHK(hipMemcpyAsync(h.data(), ctx->misc.p, h.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpyAsync(h.data(), L.misc->p, h.size() * sizeof(float), hipMemcpyDeviceToHost, L.stream));
+  HIPCHK(hipStreamSynchronize(L.stream));
   double bad = 0;
   for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
   for (int b = 0; b < nb; ++b) {
@@ -1959,13 +2003,15 @@ int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float
 // keys/vals for `n` raw points + optional histogram; then a stable radix sort by cell id.
 // On return vals_b holds the permutation (sorted position -> original index).
 int sort_by_cell(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, const double o[3],
-                 uint32_t* d_counts, int brick = 0) {
-  HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
-  HIPCHK(ctx->keys_b.ensure((size_t)n * 4));
-  HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
-  HIPCHK(ctx->vals_b.ensure((size_t)n * 4));
-  hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0],
-                     o[1], o[2], g, brick, ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), d_counts);
+                 uint32_t* d_counts, int brick = 0, const Lane* lane = nullptr) {
+  const Lane ml = main_lane(ctx);
+  const Lane& L = lane ? *lane : ml;
+  HIPCHK(L.keys_a->ensure((size_t)n * 4));
+  HIPCHK(L.keys_b->ensure((size_t)n * 4));
+  HIPCHK(L.vals_a->ensure((size_t)n * 4));
+  HIPCHK(L.vals_b->ensure((size_t)n * 4));
+  hipLaunchKernelGGL(k_cell_keys, dim3(div_up(n, kBlock)), dim3(kBlock), 0, L.stream, d_xyz, n, o[0],
+                     o[1], o[2], g, brick, L.keys_a->as<uint32_t>(), L.vals_a->as<uint32_t>(), d_counts);
   HIPCHK(hipGetLastError());
   const int bm = (1 << kBrickShift) - 1;
   const uint64_t ncells = brick ? ((uint64_t)((g.nx + bm) >> kBrickShift) * ((g.ny + bm) >> kBrickShift) *
@@ -1974,13 +2020,13 @@ int sort_by_cell(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, co
   int bits = 1;
   while (bits < 32 && (1ull << bits) < ncells) ++bits;
   size_t tmp_bytes = 0;
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(),
-                                            ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
-                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, bits, ctx->stream));
-  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(),
-                                            ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
-                                            ctx->vals_b.as<uint32_t>(), (int)n, 0, bits, ctx->stream));
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, L.keys_a->as<uint32_t>(),
+                                            L.keys_b->as<uint32_t>(), L.vals_a->as<uint32_t>(),
+                                            L.vals_b->as<uint32_t>(), (int)n, 0, bits, L.stream));
+  HIPCHK(L.cub_tmp->ensure(tmp_bytes));
+  HIPCHK(hipcub::DeviceRadixSort::SortPairs(L.cub_tmp->p, tmp_bytes, L.keys_a->as<uint32_t>(),
+                                            L.keys_b->as<uint32_t>(), L.vals_a->as<uint32_t>(),
+                                            L.vals_b->as<uint32_t>(), (int)n, 0, bits, L.stream));
   return MA_OK;
 }
 
@@ -1995,14 +2041,14 @@ int occupied_cells_multi(ma_ctx* ctx, const float* d_xyz, uint32_t n, const Grid
   if (count > 16) return ctx->fail(MA_ERR_INVALID, "too many occupancy probes");
   HIPCHK(ctx->misc.ensure(128));
   HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 8 * (size_t)count, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->occ_b.p, 0, n16_max * 16, ctx->stream));     // once: every count clears what its probe marked
   for (int k = 0; k < count; ++k) {
     const GridP& g = grids[k];
     const uint64_t n16 = ((uint64_t)g.nx * g.ny * g.nz + 15) / 16;
-    HIPCHK(hipMemsetAsync(ctx->occ_b.p, 0, n16 * 16, ctx->stream));
     hipLaunchKernelGGL(k_mark_cells, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0], o[1], o[2], g,
                        ctx->occ_b.as<uint8_t>());
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_count_marks, dim3(std::min<uint32_t>(div_up(n16, kBlock), 2048)), dim3(kBlock), 0, ctx->stream,
+    hipLaunchKernelGGL(k_count_marks, dim3(std::min<uint32_t>(div_up(n16, kBlock), 256)), dim3(kBlock), 0, ctx->stream,
                        ctx->occ_b.as<uint4>(), (uint32_t)n16, ctx->misc.as<unsigned long long>() + k);
     HIPCHK(hipGetLastError());
   }
@@ -2265,7 +2311,8 @@ int guarded(ma_ctx* ctx, F&& body) noexcept {
 // Builds the gold map (grids of all levels, distance table) from the n x 3 fp32 world-frame
 // points already resident in ctx->raw; ev0 must have been recorded by the caller.
 static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell);
-static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const float* d_raw = nullptr);
+static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const float* d_raw = nullptr,
+                                 float gold_cell = 0.f, const Lane* lane = nullptr);
 
 extern "C" {
 
@@ -2434,6 +2481,7 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   }
   c = clamp_cell_to_budget(lo, hi, c, kMaxCells);
   if (!(c > 0.f) || !std::isfinite(c)) return ctx->fail(MA_ERR_INVALID, "could not choose a cell edge");
+  if (ctx->pair_handoff) ctx->pair_handoff->set(1, c);     // ma_set_pair: the scan's sort may start (origin and cell edge are final)
 
   // Grid phase: a surface that runs along a cell boundary (walls and floors of man-made
   // scenes are axis-aligned once the scan is levelled) puts its points into two layers of
@@ -2486,20 +2534,24 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     HIPCHK(hist.ensure((ncells + 8) * 4 + 64));
     uint32_t* d_hist = reinterpret_cast<uint32_t*>(static_cast<char*>(hist.p) + 64);
     HIPCHK(hipMemsetAsync(hist.p, 0, (ncells + 8) * 4 + 64, ctx->stream));
-    // histogram + stable radix sort by cell id -> vals_b = permutation (sorted pos -> original index)
-    if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, d_hist))) return rc;
+    // stable radix sort by cell id -> keys_b sorted, vals_b = permutation (sorted pos -> original index);
+    // run ends of the sorted keys -> cell table (k_cell_tails + exclusive max-scan)
+    if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, nullptr))) return rc;
+    const uint32_t nblk = div_up(n, kBlock);
+    HIPCHK(ctx->occ_b.ensure((size_t)nblk * 4));
+    hipLaunchKernelGGL(k_cell_tails, dim3(nblk), dim3(kBlock), 0, ctx->stream, ctx->keys_b.as<uint32_t>(), n, d_hist,
+                       ctx->occ_b.as<uint32_t>());
+    HIPCHK(hipGetLastError());
     size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(),
-                                            (int)(ncells + 8), ctx->stream));
+    HIPCHK(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), hipcub::Max(), 0u,
+                                             (int)(ncells + 8), ctx->stream));
     HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(),
-                                            (int)(ncells + 8), ctx->stream));
+    HIPCHK(hipcub::DeviceScan::ExclusiveScan(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), hipcub::Max(), 0u,
+                                             (int)(ncells + 8), ctx->stream));
     HIPCHK(ctx->gold[l].ensure(((size_t)n + 8) * sizeof(float4)));   // + 8 pad entries (level 0)
+    std::vector<uint32_t> ends(nblk);
     if (l == 0) {
-      hipLaunchKernelGGL(k_count_occupied, dim3(std::min<uint32_t>(div_up(ncells, kBlock), 2048)), dim3(kBlock),
-                         0, ctx->stream, d_hist, (uint32_t)ncells, static_cast<unsigned long long*>(hist.p));
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(&ctx->noccupied, hist.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ends.data(), ctx->occ_b.p, (size_t)nblk * 4, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx->perm0.ensure((size_t)n * 4));
       HIPCHK(hipMemcpyAsync(ctx->perm0.p, ctx->vals_b.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
@@ -2516,6 +2568,11 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
       HIPCHK(hipMemcpyAsync(ctx->gold[0].as<float4>() + n, kFar, sizeof(kFar), hipMemcpyHostToDevice, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));   // hist / sort scratch is reused by the next level
+    if (l == 0) {
+      uint64_t occ_cells = 0;
+      for (uint32_t e : ends) occ_cells += e;
+      ctx->noccupied = occ_cells;
+    }
     L.gold[l] = ctx->gold[l].as<float4>();
     L.cs[l] = ctx->cstart[l].as<uint32_t>();
     L.c[l] = g.c; L.inv_c[l] = g.inv_c;
@@ -2611,63 +2668,112 @@ int ma_set_pair(ma_ctx* ctx, const float* gold_xyz, uint64_t m, float cell, cons
   ctx->state_valid = false;
   const uint32_t mg = (uint32_t)m, n = (uint32_t)n64;
   if (!ctx->aux_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+  // every buffer the helper thread will touch is sized HERE, on the calling thread (allocation counters and
+  // hipMalloc stay single-threaded; a warm context allocates nothing)
   HIPCHK(ctx->raw.ensure((size_t)mg * 12));
   HIPCHK(ctx->raw_src.ensure((size_t)n * 12));
+  HIPCHK(ctx->akeys_a.ensure((size_t)n * 4));
+  HIPCHK(ctx->akeys_b.ensure((size_t)n * 4));
+  HIPCHK(ctx->avals_a.ensure((size_t)n * 4));
+  HIPCHK(ctx->avals_b.ensure((size_t)n * 4));
+  HIPCHK(ctx->amisc.ensure(1024 * 8 * sizeof(float)));
+  HIPCHK(ctx->src.ensure((size_t)n * sizeof(float4)));
+  HIPCHK(ctx->src_perm.ensure((size_t)n * 4));
+  if (weights) HIPCHK(ctx->wts.ensure((size_t)n * 4));
+  {
+    size_t tmp_bytes = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->akeys_a.as<uint32_t>(), ctx->akeys_b.as<uint32_t>(),
+                                              ctx->avals_a.as<uint32_t>(), ctx->avals_b.as<uint32_t>(), (int)n, 0, 32, ctx->aux_stream));
+    HIPCHK(ctx->acub_tmp.ensure(tmp_bytes));
+  }
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->raw.p, gold_xyz, (size_t)mg * 12, hipMemcpyDefault, ctx->stream));
-  hipError_t copy_err = hipSuccess;
-  std::thread uploader([&]() {
-    copy_err = hipSetDevice(ctx->device);
-    if (copy_err == hipSuccess) copy_err = hipMemcpyAsync(ctx->raw_src.p, src_xyz, (size_t)n * 12, hipMemcpyDefault, ctx->aux_stream);
-    if (copy_err == hipSuccess) copy_err = hipStreamSynchronize(ctx->aux_stream);
+  ma_ctx::PairHandoff handoff;
+  ctx->pair_handoff = &handoff;
+  int rc_src = MA_OK;
+  std::thread helper([&]() {
+    try {
+      hipError_t e = hipSetDevice(ctx->device);
+      if (e == hipSuccess) e = hipMemcpyAsync(ctx->raw_src.p, src_xyz, (size_t)n * 12, hipMemcpyDefault, ctx->aux_stream);
+      if (e != hipSuccess) { rc_src = ctx->fail(MA_ERR_HIP, std::string("upload of the source cloud: ") + hipGetErrorString(e)); return; }
+      float cell_edge = 0.f;
+      {
+        std::unique_lock<std::mutex> lock(handoff.m);
+        handoff.cv.wait(lock, [&] { return handoff.state != 0; });
+        if (handoff.state != 1) return;            // the gold build failed before it chose a cell edge
+        cell_edge = handoff.cell;
+      }
+      const Lane aux = aux_lane(ctx);
+      rc_src = build_source_from_raw(ctx, n, weights, ctx->raw_src.as<float>(), cell_edge, &aux);
+    } catch (const std::bad_alloc&) {
+      rc_src = MA_ERR_NO_MEMORY;
+    } catch (...) {
+      rc_src = MA_ERR_INVALID;
+    }
   });
-  struct Joiner {             // whatever ends the build below — a status or an exception — the helper is joined first
+  struct Joiner {             // whatever ends the build below — a status or an exception — the helper is released and joined
     std::thread& t;
-    ~Joiner() { if (t.joinable()) t.join(); }
-  } joiner{uploader};
-  const int rc_gold = build_gold_from_raw(ctx, mg, cell);
-  uploader.join();
-  if (rc_gold) return rc_gold;
-  if (copy_err != hipSuccess) return ctx->fail(MA_ERR_HIP, std::string("upload of the source cloud: ") + hipGetErrorString(copy_err));
-  return build_source_from_raw(ctx, n, weights, ctx->raw_src.as<float>());
+    ma_ctx* ctx;
+    ma_ctx::PairHandoff& h;
+    ~Joiner() {
+      h.set(2, 0.f);          // (no effect once the build has said "go")
+      if (t.joinable()) t.join();
+      ctx->pair_handoff = nullptr;
+    }
+  };
+  int rc_gold;
+  {
+    Joiner joiner{helper, ctx, handoff};
+    rc_gold = build_gold_from_raw(ctx, mg, cell);
+  }
+  if (rc_gold || rc_src) {
+    ctx->have_src = false;
+    if (rc_gold) ctx->have_gold = false;
+    return rc_gold ? rc_gold : rc_src;
+  }
+  return MA_OK;
   });
 }
 
 // d_raw (default ctx->raw) holds the n x 3 fp32 source points (relative to the host-side shift, if any)
-static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const float* d_raw) {
+static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const float* d_raw, float gold_cell,
+                                 const Lane* lane) {
+  const Lane ml = main_lane(ctx);
+  const Lane& L = lane ? *lane : ml;
   if (!d_raw) d_raw = ctx->raw.as<float>();
+  if (!(gold_cell > 0.f)) gold_cell = ctx->grid.c;
   const float* d_w = nullptr;
   if (weights) {
     HIPCHK(ctx->wts.ensure((size_t)n * 4));
-    HIPCHK(hipMemcpyAsync(ctx->wts.p, weights, (size_t)n * 4, hipMemcpyDefault, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->wts.p, weights, (size_t)n * 4, hipMemcpyDefault, L.stream));
     d_w = ctx->wts.as<float>();
-    HIPCHK(ctx->misc.ensure(64));
-    HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 8, ctx->stream));
+    HIPCHK(L.misc->ensure(64));
+    HIPCHK(hipMemsetAsync(L.misc->p, 0, 8, L.stream));
     hipLaunchKernelGGL(k_count_bad_weights, dim3(std::min<uint32_t>(div_up(n, kBlock), 1024)), dim3(kBlock), 0,
-                       ctx->stream, d_w, n, ctx->misc.as<unsigned long long>());
+                       L.stream, d_w, n, L.misc->as<unsigned long long>());
     HIPCHK(hipGetLastError());
     unsigned long long bad = 0;
-    HIPCHK(hipMemcpyAsync(&bad, ctx->misc.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyAsync(&bad, L.misc->p, 8, hipMemcpyDeviceToHost, L.stream));
+    HIPCHK(hipStreamSynchronize(L.stream));
     if (bad) return ctx->fail(MA_ERR_INVALID, "weights must be finite and >= 0");
   }
   float lo[3], hi[3];
-  int rc = cloud_bounds(ctx, d_raw, n, lo, hi);
+  int rc = cloud_bounds(ctx, d_raw, n, lo, hi, 3, false, &L);
   if (rc) return rc;
   // sort in the cloud's own frame with the gold map's cell edge (coarsened to fit 2^27
   // cells), brick-major: 256 consecutive points then form a compact patch, so that a
   // workgroup's queries share one small block of the gold grid under any rigid motion.
-  const float c = clamp_cell_to_budget(lo, hi, ctx->grid.c, kMaxCells);
+  const float c = clamp_cell_to_budget(lo, hi, gold_cell, kMaxCells);
   const GridP g = make_grid(lo, hi, ctx->origin, c);
-  if ((rc = sort_by_cell(ctx, d_raw, n, g, ctx->origin, nullptr, /*brick=*/1))) return rc;
+  if ((rc = sort_by_cell(ctx, d_raw, n, g, ctx->origin, nullptr, /*brick=*/1, &L))) return rc;
   HIPCHK(ctx->src.ensure((size_t)n * sizeof(float4)));
   HIPCHK(ctx->src_perm.ensure((size_t)n * 4));
-  HIPCHK(hipMemcpyAsync(ctx->src_perm.p, ctx->vals_b.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_raw, d_w,
+  HIPCHK(hipMemcpyAsync(ctx->src_perm.p, L.vals_b->p, (size_t)n * 4, hipMemcpyDeviceToDevice, L.stream));
+  hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, L.stream, d_raw, d_w,
                      ctx->src_perm.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1], ctx->origin[2], 0,
                      (const uint32_t*)nullptr, ctx->src.as<float4>());
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipStreamSynchronize(L.stream));
   ctx->n = n;
   ctx->n_pts = n;
   ctx->src_sorted = true;
