@@ -3361,6 +3361,14 @@ int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev) {
   });
 }
 
+int ma_search_geometry(const ma_ctx* ctx, uint32_t* n_workgroups, uint32_t* block_threads) {
+  if (!ctx || !n_workgroups || !block_threads) return MA_ERR_INVALID;
+  if (!ctx->have_src) return MA_ERR_STATE;
+  *n_workgroups = grid_for(ctx->n);
+  *block_threads = (uint32_t)kNNBlock;
+  return MA_OK;
+}
+
 int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out) {
   if (!ctx || !out) return MA_ERR_INVALID;
   out->device_allocs = ctx->mem.allocs;

@@ -452,6 +452,12 @@ class MapAligner:
         return {"device_allocs": int(mi.device_allocs), "device_frees": int(mi.device_frees),
                 "bytes_live": int(mi.bytes_live), "bytes_peak": int(mi.bytes_peak)}
 
+    def search_geometry(self):
+        """(workgroups per search launch, threads = points per workgroup) for the current source cloud."""
+        g, b = C.c_uint32(0), C.c_uint32(0)
+        self._chk(self._lib.ma_search_geometry(self._ctx, C.byref(g), C.byref(b)))
+        return int(g.value), int(b.value)
+
     def get_source(self):
         n = C.c_uint64(0)
         self._chk(self._lib.ma_get_source(self._ctx, None, C.byref(n)))

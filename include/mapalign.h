@@ -149,6 +149,10 @@ int ma_set_pair(ma_ctx* ctx, const float* gold_xyz, uint64_t m, float cell, cons
 int ma_set_gold_f64(ma_ctx* ctx, const double* xyz, uint64_t m, float cell, double shift_out[3]);
 int ma_set_source_f64(ma_ctx* ctx, const double* xyz, const float* weights, uint64_t n, const double shift[3]);
 int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out);
+/* Launch geometry of the search kernel (k_nn_accum) for the current source cloud: workgroups per launch
+ * (padded to whole XCD segments and scheduling groups) and threads (= points) per workgroup.  What a roofline
+ * computation needs for the per-workgroup terms (19 fp64 partials each). */
+int ma_search_geometry(const ma_ctx* ctx, uint32_t* n_workgroups, uint32_t* block_threads);
 
 /* Row a8: fused depth -> 3-D unprojection written straight into the source-cloud device
  * buffer.  Pinhole model of pose_processor.py:133-137,184-196,242-260:

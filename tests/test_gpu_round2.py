@@ -7,6 +7,7 @@
   with a 1-rank communicator, the batched box lift and the batch-32 detector leg (configs[3]),
   trajectory-aided coarse stage, weights that do not sum to a count.
 """
+import os
 import time
 
 import numpy as np
@@ -51,6 +52,13 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
     res = engine.icp(iters, 0.0, 0.10, with_trace=True)
     assert res.iterations == iters
     eR, et = orc.rt_error(res.R, res.t, R, t)
+    # (which comparison actually ran goes into the log: pytest -s / -rP shows it, and the warning is always listed)
+    msg = (f"config2 seed {seed}: compared after {iters} iterations ({(time.perf_counter() - t_start) / iters:.2f} s per oracle "
+           f"iteration on {len(os.sched_getaffinity(0))} host cores): |dR|_F = {eR:.2e}, |dt| = {et:.2e} m")
+    print(msg)
+    if iters != 50:
+        import warnings
+        warnings.warn(msg + " — SHORTENED from 50: this host is too slow for the full oracle run of seeds 1-2")
     assert eR <= R_TOL_FRO and et <= T_TOL_M, (eR, et)
     # measured: 1e-7 / 1e-6 m; keep a tighter regression bar than the contract
     assert eR <= 1e-5 and et <= 1e-4, (eR, et)
