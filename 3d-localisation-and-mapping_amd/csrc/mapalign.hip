@@ -1367,7 +1367,13 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
 // ---------------------------------------------------------------------------------------
 // a8: depth -> world points, order-preserving compaction
 // ---------------------------------------------------------------------------------------
-constexpr int kPxPerThread = 4;
+// pixels per thread of k_unproject: 1 / 2 / 4 / 8 -> 11.1 / 11.4 / 13.9 / 14.2 us for a 1280 x 960 frame and 160 / 163 / 196 us
+// for 8192 x 4096 (rocprofv3; more, lighter threads hide the load latency of a kernel that is one load and a few
+// stores long); non-temporal stores (four dword stores per point): 24 us.  2 keeps the per-workgroup count array half as long as 1.
+#ifndef MA_UNPROJ_PX
+#define MA_UNPROJ_PX 2
+#endif
+constexpr int kPxPerThread = MA_UNPROJ_PX;
 constexpr int kPxPerBlock = kBlock * kPxPerThread;
 
 template <typename T>
@@ -1402,7 +1408,7 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
   const uint32_t first = blockIdx.x * kPxPerBlock + threadIdx.x * kPxPerThread;
   double z[kPxPerThread];
   if (first + kPxPerThread <= npx && (reinterpret_cast<uintptr_t>(depth + first) & (sizeof(T) * kPxPerThread - 1)) == 0) {
-    // the thread's four pixels in one load (16 B of float32 / 8 B of uint16)
+    // the thread's pixels in one load
     struct alignas(sizeof(T) * kPxPerThread) Quad { T v[kPxPerThread]; };
     const Quad q = *reinterpret_cast<const Quad*>(depth + first);
 #pragma unroll
