@@ -808,3 +808,61 @@ def test_set_pair_equals_the_two_calls_bitwise_and_shared_context_users_do_not_m
     for T, ref in zip(first + second, want):
         assert np.array_equal(np.asarray(T), ref)
     mapalign.release_cached_engines()
+
+
+# ----------------------------------------------------------------------------- round 3: the device solve (a6) on crafted sums
+def test_device_solve_vs_numpy_svd_through_step_solve(lib_built):
+    """The device solve (kabsch.h: one-sided Jacobi SVD + Kabsch on one lane) through ma_step_solve: accumulators built from
+    exact correspondences — generic, planar (third singular value 0), reflected-looking (det(V U^T) < 0 without the
+    fix), nearly aligned, large rotations, weighted — must give the oracle's (numpy SVD) update; degenerate sums
+    (collinear points, one pair, W = 0, a NaN) must stop the state with the degenerate flag, not produce a transform."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    gold, comp, _, _ = syn.make_pair(3, 2000, 1500)
+    cases = []
+    for k in range(40):
+        n = int(rng.integers(3, 400))
+        p = rng.normal(size=(n, 3)) * rng.uniform(0.1, 20.0, size=3) + rng.normal(size=3) * 5
+        if k % 4 == 1:
+            p[:, int(rng.integers(0, 3))] = 0.7                      # planar cloud
+        R = syn.rotation_about_axis(rng.normal(size=3), rng.uniform(0, np.pi) if k % 3 else rng.uniform(0, 1e-4))
+        q = p @ R.T + rng.normal(size=3) + (rng.normal(0, 1e-3, size=p.shape) if k % 2 else 0.0)
+        if k % 8 == 5:
+            q = q * np.array([1.0, 1.0, -1.0])                       # mirrored target: the SVD alone would return a reflection
+        w = rng.uniform(0.1, 3.0, n) if k % 5 == 0 else np.ones(n)
+        cases.append(orc.accumulate(p, q, w, np.sum((p - q) ** 2, axis=1)))
+    line = np.outer(np.linspace(-1, 1, 50), [1.0, 2.0, -0.5])
+    bad = [orc.accumulate(line, line + 0.1, np.ones(50), np.zeros(50)),                  # collinear: rank 1
+           orc.accumulate(np.ones((1, 3)), np.zeros((1, 3)), np.ones(1), np.zeros(1)),   # a single pair
+           np.zeros(17), np.where(np.arange(17) == 9, np.nan, cases[0])]
+    with mapalign.MapAligner(0) as eng:
+        eng.set_gold(gold)
+        eng.set_source(comp)
+        origin = eng.grid_info()["origin"]
+        acc_dev = torch.zeros(17, dtype=torch.float64, device="cuda:0")
+
+        def centred(acc):          # the library's sums live in the frame centred on the gold map's origin (engine._acc_shift, inverted)
+            a = np.array(acc, dtype=np.float64)
+            W, sp, sq = a[0], a[1:4] - a[0] * origin, a[4:7] - a[0] * origin
+            S = a[7:16].reshape(3, 3) - np.outer(sp, origin) - np.outer(origin, sq) - W * np.outer(origin, origin)
+            return np.concatenate([[W], sp, sq, S.ravel(), [a[16]]])
+
+        for acc in cases:
+            dR, dt, ok = orc.kabsch_from_acc(acc)
+            assert ok
+            eng.state_set(None)
+            acc_dev.copy_(torch.from_numpy(centred(acc)))
+            torch.cuda.synchronize()
+            eng.step_solve(acc_dev.data_ptr())
+            T, info = eng.state_get()
+            assert info["iterations"] == 1 and not info["degenerate"]
+            assert np.abs(T[:3, :3] - dR).max() < 1e-9 and np.abs(T[:3, 3] - dt).max() < 1e-8 * max(1.0, np.abs(dt).max())
+            assert abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-12
+        for acc in bad:
+            eng.state_set(None)
+            acc_dev.copy_(torch.from_numpy(centred(acc) if np.isfinite(acc).all() else np.asarray(acc, dtype=np.float64)))
+            torch.cuda.synchronize()
+            eng.step_solve(acc_dev.data_ptr())
+            T, info = eng.state_get()
+            assert info["degenerate"] and np.array_equal(T, np.eye(4))
