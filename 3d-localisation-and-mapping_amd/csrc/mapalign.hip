@@ -1826,7 +1826,7 @@ struct ma_ctx {
 
   // scratch for builds
   DevBuf raw, raw64, wts, keys_a, keys_b, vals_a, vals_b, cub_tmp, misc, depth_in;
-  DevBuf raw_src;                // ma_set_pair: the scan is uploaded here while the gold map is being built from `raw`
+  DevBuf raw_src, raw64_src;     // ma_set_pair{,_f64}: the scan is uploaded here while the gold map is being built from `raw`
   DevBuf akeys_a, akeys_b, avals_a, avals_b, acub_tmp, amisc;     // ... and sorted with its own scratch on its own stream
   hipStream_t aux_stream = nullptr;
 
@@ -1877,7 +1877,7 @@ struct ma_ctx {
   PairHandoff* pair_handoff = nullptr;
   std::vector<DevBuf*> all_bufs() {
     std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b,
-                              &src, &src_perm, &raw, &raw_src, &akeys_a, &akeys_b, &avals_a, &avals_b, &acub_tmp, &amisc, &raw64, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
+                              &src, &src_perm, &raw, &raw_src, &raw64_src, &akeys_a, &akeys_b, &avals_a, &avals_b, &acub_tmp, &amisc, &raw64, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
                               &depth_in, &lift_poses, &lift_frames, &unproj_cnt, &state, &partials, &trace, &acc19, &ticket,
                               &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
     for (int l = 0; l < kLevels; ++l) { v.push_back(&gold[l]); v.push_back(&cstart[l]); }
@@ -2319,6 +2319,7 @@ int guarded(ma_ctx* ctx, F&& body) noexcept {
 static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell);
 static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const float* d_raw = nullptr,
                                  float gold_cell = 0.f, const Lane* lane = nullptr);
+static int stage_f64(ma_ctx* ctx, const double* xyz, uint32_t n, bool choose_shift, double shift[3]);
 
 extern "C" {
 
@@ -2658,11 +2659,9 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
 // so the scan's upload is issued from a helper thread on a second stream; the gold build's kernels and host
 // round trips (ctx->stream) run beside it, and the scan's sort follows once both are done.  Same state afterwards
 // as ma_set_gold + ma_set_source (bitwise: the same kernels on the same data), 0.3-0.4 ms sooner for a 1M-point pair.
-int ma_set_pair(ma_ctx* ctx, const float* gold_xyz, uint64_t m, float cell, const float* src_xyz, const float* weights,
-                uint64_t n64) {
-  return guarded(ctx, [&]() -> int {
-  if (!ctx) return MA_ERR_INVALID;
-  if ((!gold_xyz && m) || (!src_xyz && n64)) return ctx->fail(MA_ERR_INVALID, "xyz is NULL");
+static int set_pair_impl(ma_ctx* ctx, const void* gold_xyz, uint64_t m, float cell, const void* src_xyz, const float* weights,
+                         uint64_t n64, const bool f64, double shift_out[3]) {
+  if ((!gold_xyz && m) || (!src_xyz && n64) || (f64 && !shift_out)) return ctx->fail(MA_ERR_INVALID, "NULL argument");
   if (m == 0) return ctx->fail(MA_ERR_EMPTY, "gold cloud is empty");
   if (n64 == 0) return ctx->fail(MA_ERR_EMPTY, "source cloud is empty");
   if (m >= (1ull << 28)) return ctx->fail(MA_ERR_TOO_LARGE, "gold cloud has 2^28 or more points (32-bit byte offsets into the cell-sorted arrays)");
@@ -2673,11 +2672,16 @@ int ma_set_pair(ma_ctx* ctx, const float* gold_xyz, uint64_t m, float cell, cons
   ctx->have_src = false;
   ctx->state_valid = false;
   const uint32_t mg = (uint32_t)m, n = (uint32_t)n64;
+  const size_t in_bytes = f64 ? 24 : 12;
   if (!ctx->aux_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
   // every buffer the helper thread will touch is sized HERE, on the calling thread (allocation counters and
   // hipMalloc stay single-threaded; a warm context allocates nothing)
   HIPCHK(ctx->raw.ensure((size_t)mg * 12));
   HIPCHK(ctx->raw_src.ensure((size_t)n * 12));
+  if (f64) {
+    HIPCHK(ctx->raw64.ensure((size_t)mg * 24));
+    HIPCHK(ctx->raw64_src.ensure((size_t)n * 24));
+  }
   HIPCHK(ctx->akeys_a.ensure((size_t)n * 4));
   HIPCHK(ctx->akeys_b.ensure((size_t)n * 4));
   HIPCHK(ctx->avals_a.ensure((size_t)n * 4));
@@ -2693,15 +2697,29 @@ int ma_set_pair(ma_ctx* ctx, const float* gold_xyz, uint64_t m, float cell, cons
     HIPCHK(ctx->acub_tmp.ensure(tmp_bytes));
   }
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->raw.p, gold_xyz, (size_t)mg * 12, hipMemcpyDefault, ctx->stream));
+  double shift[3] = {0.0, 0.0, 0.0};
+  if (f64) {          // upload, fp64 bounds and the large-coordinate shift of the gold map, conversion to the fp32 frame
+    int rc = stage_f64(ctx, static_cast<const double*>(gold_xyz), mg, true, shift);
+    if (rc) return rc;
+    for (int a = 0; a < 3; ++a) shift_out[a] = shift[a];
+  } else {
+    HIPCHK(hipMemcpyAsync(ctx->raw.p, gold_xyz, (size_t)mg * 12, hipMemcpyDefault, ctx->stream));
+  }
   ma_ctx::PairHandoff handoff;
   ctx->pair_handoff = &handoff;
   int rc_src = MA_OK;
   std::thread helper([&]() {
     try {
       hipError_t e = hipSetDevice(ctx->device);
-      if (e == hipSuccess) e = hipMemcpyAsync(ctx->raw_src.p, src_xyz, (size_t)n * 12, hipMemcpyDefault, ctx->aux_stream);
+      void* dst = f64 ? ctx->raw64_src.p : ctx->raw_src.p;
+      if (e == hipSuccess) e = hipMemcpyAsync(dst, src_xyz, (size_t)n * in_bytes, hipMemcpyDefault, ctx->aux_stream);
       if (e != hipSuccess) { rc_src = ctx->fail(MA_ERR_HIP, std::string("upload of the source cloud: ") + hipGetErrorString(e)); return; }
+      if (f64) {      // the shift is final before the helper starts: convert behind the upload, on the aux stream
+        const uint64_t n3 = 3ull * n;
+        hipLaunchKernelGGL(k_f64_to_raw, dim3((uint32_t)((n3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->aux_stream,
+                           ctx->raw64_src.as<double>(), n3, shift[0], shift[1], shift[2], ctx->raw_src.as<float>());
+        if ((e = hipGetLastError()) != hipSuccess) { rc_src = ctx->fail(MA_ERR_HIP, std::string("k_f64_to_raw: ") + hipGetErrorString(e)); return; }
+      }
       float cell_edge = 0.f;
       {
         std::unique_lock<std::mutex> lock(handoff.m);
@@ -2738,6 +2756,21 @@ int ma_set_pair(ma_ctx* ctx, const float* gold_xyz, uint64_t m, float cell, cons
     return rc_gold ? rc_gold : rc_src;
   }
   return MA_OK;
+}
+
+int ma_set_pair(ma_ctx* ctx, const float* gold_xyz, uint64_t m, float cell, const float* src_xyz, const float* weights,
+                uint64_t n64) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  return set_pair_impl(ctx, gold_xyz, m, cell, src_xyz, weights, n64, false, nullptr);
+  });
+}
+
+int ma_set_pair_f64(ma_ctx* ctx, const double* gold_xyz, uint64_t m, float cell, double shift_out[3], const double* src_xyz,
+                    const float* weights, uint64_t n64) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  return set_pair_impl(ctx, gold_xyz, m, cell, src_xyz, weights, n64, true, shift_out);
   });
 }
 

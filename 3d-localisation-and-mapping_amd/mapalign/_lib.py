@@ -88,6 +88,7 @@ ABI = {
     "ma_grid_info_get": (C.c_int, [_ctx_p, C.POINTER(ma_grid_info)]),
     "ma_set_source": (C.c_int, [_ctx_p, _f32p, _f32p, C.c_uint64]),
     "ma_set_pair": (C.c_int, [_ctx_p, _f32p, C.c_uint64, C.c_float, _f32p, _f32p, C.c_uint64]),
+    "ma_set_pair_f64": (C.c_int, [_ctx_p, _f64p, C.c_uint64, C.c_float, _f64p, _f64p, _f32p, C.c_uint64]),
     "ma_set_gold_f64": (C.c_int, [_ctx_p, _f64p, C.c_uint64, C.c_float, _f64p]),
     "ma_set_source_f64": (C.c_int, [_ctx_p, _f64p, _f32p, C.c_uint64, _f64p]),
     "ma_set_source_from_depth": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, _f32p, _f64p,

@@ -303,15 +303,17 @@ class MapAligner:
         self.n_source = n
 
     def set_pair(self, gold_cloud, comparison_cloud, weights=None, cell=0.0):
-        """``set_gold`` + ``set_source`` of one pair.  Two float32 HOST arrays go through ``ma_set_pair``,
-        which uploads the comparison cloud while the gold map is being indexed (same state afterwards,
-        bitwise); anything else (fp64, device-resident, weights on the device) takes the two calls."""
-        def plain_f32_host(a):
+        """``set_gold`` + ``set_source`` of one pair.  Two HOST arrays of the same dtype — float32, or float64 as
+        Open3D / NumPy hand them over — go through ``ma_set_pair`` / ``ma_set_pair_f64``, which upload and sort the
+        comparison cloud while the gold map is being indexed (same state afterwards, bitwise); anything else
+        (mixed dtypes, device-resident arrays) takes the two calls."""
+        def plain_host(a, dt):
             return (_device_array(a, "cloud", self.device, None, ("<f4", "<f8")) is None
-                    and isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[1:] == (3,)
+                    and isinstance(a, np.ndarray) and a.dtype == dt and a.ndim == 2 and a.shape[1:] == (3,)
                     and a.shape[0] > 0)
         w_ok = weights is None or (isinstance(weights, np.ndarray) and weights.ndim == 1)
-        if not (plain_f32_host(gold_cloud) and plain_f32_host(comparison_cloud) and w_ok):
+        dt = next((d for d in (np.float32, np.float64) if plain_host(gold_cloud, d) and plain_host(comparison_cloud, d)), None)
+        if dt is None or not w_ok:
             grid = self.set_gold(gold_cloud, cell)
             self.set_source(comparison_cloud, weights)
             return grid
@@ -326,8 +328,14 @@ class MapAligner:
         self._shift = np.zeros(3)
         self.n_gold = self.n_source = 0
         self.gold_token = None
-        self._chk(self._lib.ma_set_pair(self._ctx, g.ctypes.data_as(fp), g.shape[0], float(cell), c.ctypes.data_as(fp), w_p,
-                                        c.shape[0]))
+        if dt is np.float32:
+            self._chk(self._lib.ma_set_pair(self._ctx, g.ctypes.data_as(fp), g.shape[0], float(cell), c.ctypes.data_as(fp), w_p,
+                                            c.shape[0]))
+        else:
+            shift = np.zeros(3)
+            self._chk(self._lib.ma_set_pair_f64(self._ctx, _f64p(g), g.shape[0], float(cell), _f64p(shift), _f64p(c), w_p,
+                                                c.shape[0]))
+            self._shift = shift
         self.n_gold, self.n_source = g.shape[0], c.shape[0]
         return self.grid_info()
 

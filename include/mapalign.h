@@ -135,6 +135,10 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
  * exception (resource exhaustion): reported as MA_ERR_INVALID like every other C++ exception at this boundary. */
 int ma_set_pair(ma_ctx* ctx, const float* gold_xyz, uint64_t m, float cell, const float* comparison_xyz,
                 const float* weights, uint64_t n);
+/* The same for two fp64 clouds (ma_set_gold_f64 + ma_set_source_f64 with the shift the gold map chose, reported in
+ * shift_out): the reference's own arrays are float64 (np.asarray(pcd.points)), so this is the drop-in path. */
+int ma_set_pair_f64(ma_ctx* ctx, const double* gold_xyz, uint64_t m, float cell, double shift_out[3],
+                    const double* comparison_xyz, const float* weights, uint64_t n);
 
 /* The same for fp64 clouds — what Open3D and NumPy hand over by default (the reference's
  * arrays are np.asarray(pcd.points), float64).  Upload, bounds and the conversion to the engine's

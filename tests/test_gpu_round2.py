@@ -796,8 +796,20 @@ def test_set_pair_equals_the_two_calls_bitwise_and_shared_context_users_do_not_m
         with pytest.raises(mapalign.MapAlignError) as e:
             b.set_pair(gold, np.full((5, 3), np.nan, np.float32))
         assert e.value.status == _lib.MA_ERR_INVALID
-        b.set_pair(gold, comp.astype(np.float64))            # anything but two float32 host arrays: the two calls, same answer
-        assert np.allclose(b.icp(12, 0.0, 0.10).T, a.icp(12, 0.0, 0.10, init=None).T, atol=1e-9) or True
+        # two float64 host arrays (what Open3D hands over) take ma_set_pair_f64: bitwise the two fp64 calls, georeferenced too
+        for off in (np.zeros(3), np.array([4.5e5, 5.2e6, 120.0])):
+            g64, c64 = gold.astype(np.float64) + off, comp.astype(np.float64) + off
+            a.set_gold(g64)
+            a.set_source(c64, w)
+            r2 = a.icp(12, 0.0, 0.10, with_trace=True)
+            b.set_pair(g64, c64, w)
+            r3 = b.icp(12, 0.0, 0.10, with_trace=True)
+            assert np.array_equal(r2.T, r3.T) and np.array_equal(r2.trace, r3.trace)
+        a.set_gold(gold)
+        a.set_source(comp)
+        plain = a.icp(12, 0.0, 0.10)
+        b.set_pair(gold, comp.astype(np.float64))            # mixed dtypes: the two calls underneath, the same cloud values
+        assert np.array_equal(b.icp(12, 0.0, 0.10).T, plain.T)
     mapalign.release_cached_engines()
     gold2, comp2, _, _ = syn.make_pair(22, 60_000, 50_000)
     scans = [comp[: 60_000 + 500 * k] for k in range(4)]
