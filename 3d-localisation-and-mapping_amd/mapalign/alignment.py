@@ -101,8 +101,11 @@ class Alignment:
     def compare(self, data_folder):
         if self.base_map_filepath is None or self.comparison_map_filepath is None:
             self.base_map_filepath, self.comparison_map_filepath = self.map_resolver(data_folder)
-        gold = ply.read_ply(self.base_map_filepath)                 # NaN / inf removed, as mapping.py:63-68
-        comp = ply.read_ply(self.comparison_map_filepath)
+        # both files at once (NumPy's file reads release the interpreter lock): NaN / inf removed, as mapping.py:63-68
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            fg, fc = pool.submit(ply.read_ply, self.base_map_filepath), pool.submit(ply.read_ply, self.comparison_map_filepath)
+            gold, comp = fg.result(), fc.result()
         self.transformations, T, info = self.align_clouds(gold, comp)
         aligned = boxes.transform_bboxes(self.comparison_bboxes, T)
         if self.pickle_path:

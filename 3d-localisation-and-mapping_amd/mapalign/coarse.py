@@ -32,21 +32,53 @@ from . import transforms
 
 
 PCA_MAX_POINTS = 1 << 18
+BLAS_THREADS = 8
+
+_blas_controller = None
+
+
+def _few_blas_threads():
+    """Context manager capping the BLAS thread pool for the two small products below.  A [1M, 3] matrix-vector
+    product needs no more than a few threads, but OpenBLAS fans it out over every hardware thread of the host
+    (256 on an MI355X box); under a CPU quota (containers, batch schedulers) that burst exhausts the quota and
+    the WHOLE process is throttled for the rest of the scheduling period — measured as a 40-80 ms stall in
+    whichever call came 20-30 ms later (`tools/coarse_times.py`).  The controller is built once (it scans the
+    loaded libraries); without threadpoolctl this is a no-op."""
+    global _blas_controller
+    import contextlib
+    if _blas_controller is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _blas_controller = ThreadpoolController()
+        except Exception:           # pragma: no cover - optional dependency
+            _blas_controller = False
+    if not _blas_controller:
+        return contextlib.nullcontext()
+    return _blas_controller.limit(limits=BLAS_THREADS, user_api="blas")
 
 
 def principal_frame(points, max_points=PCA_MAX_POINTS):
     """(centroid, axes [3,3] columns by decreasing variance, right-handed, variances).
 
-    The centroid is taken over all points; the covariance over every k-th point once the cloud
-    holds more than ``max_points`` (a fixed stride, so the result is repeatable): the axes of a
-    million-point scan do not change in the fourth digit, and the two fp64 covariance passes over
-    the full clouds were three quarters of the whole coarse stage (2 x 33 ms of 88 ms, 1M-point pair)."""
+    Centroid and covariance are taken over every k-th point once the cloud holds more than
+    ``max_points`` (a fixed stride, so the result is repeatable): the axes of a million-point scan do
+    not change in the fourth digit, and the two fp64 passes over the full clouds were three quarters of
+    the whole coarse stage (2 x 33 ms of 88 ms, 1M-point pair)."""
+    with _few_blas_threads():
+        return _principal_frame(points, max_points)
+
+
+def _principal_frame(points, max_points):
     p = np.asarray(points)
-    # (reductions along axis 0 of an [N,3] array run at a tenth of NumPy's contiguous speed)
-    c = np.ascontiguousarray(p.T).mean(axis=1, dtype=np.float64)
+    # every k-th point once the cloud holds more than max_points (a fixed stride: repeatable) — for the centroid as
+    # well (round 3): the mean of 262 144 points of a 20 m scan is within a centimetre of the mean of all of them, the
+    # stage only has to land inside the basin of the gated loop that follows, and the full-cloud mean was half of this
+    # function's 5 ms per million points (a [N,3] axis-0 reduction runs at a tenth of NumPy's contiguous speed)
     if len(p) > max_points:
         p = p[::-(-len(p) // max_points)]
-    d = np.asarray(p, dtype=np.float64) - c
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    c = (np.ones(len(p)) @ p) / max(len(p), 1)          # column sums as ONE matrix-vector product
+    d = p - c
     w, v = np.linalg.eigh(d.T @ d / max(len(d) - 1, 1))
     order = np.argsort(w)[::-1]
     axes = v[:, order]
@@ -122,27 +154,33 @@ def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0, bas
     """
     gold = np.asarray(gold_cloud)
     comp = np.asarray(comparison_cloud)
-    cg, ag, _ = principal_frame(gold)
-    cc, ac, _ = principal_frame(comp)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=2) as pool:              # the two frames side by side (NumPy releases the interpreter lock)
+        fg, fc = pool.submit(principal_frame, gold), pool.submit(principal_frame, comp)
+        (cg, ag, _), (cc, ac, _) = fg.result(), fc.result()
     rng = np.random.default_rng(seed)
     sub = comp if len(comp) <= sample else comp[rng.choice(len(comp), sample, replace=False)]
-    engine.set_source(np.ascontiguousarray(sub))       # dtype kept: fp64 georeferenced coordinates are shifted before they become fp32
     base_traj, comp_traj = trajectory_xyz(base_pose_df), trajectory_xyz(comparison_pose_df)
     use_traj = base_traj is not None and comp_traj is not None
-    scores, cloud_scores, traj_scores = [], [], []
     cands = candidate_rotations(ag, ac)
     if truncate is None:
         gi = engine.grid_info()                                  # the gold map's box, as the engine gridded it
         truncate = 0.05 * float(np.linalg.norm(np.asarray(gi["dims"], dtype=np.float64) * gi["cell"]))
     truncate = max(float(truncate), 1e-6)
-    for R in cands:
-        T = transforms.rt_to_matrix(np.eye(3), cg - cc) @ transforms.rotation_about_centre(R, cc)
-        _, d2 = engine.nn(T, max_corr_dist=truncate)            # inf where nothing lies within the bound
-        cloud = float(np.sqrt(np.mean(np.minimum(d2.astype(np.float64), truncate * truncate))))
-        traj = trajectory_residual(T, base_traj, comp_traj) if use_traj else 0.0
-        cloud_scores.append(cloud)
-        traj_scores.append(traj)
-        scores.append(float(np.hypot(cloud, traj)))
+    Ts = [transforms.rt_to_matrix(np.eye(3), cg - cc) @ transforms.rotation_about_centre(R, cc) for R in cands]
+    traj_scores = [trajectory_residual(T, base_traj, comp_traj) if use_traj else 0.0 for T in Ts]
+
+    def cloud_score(k):
+        _, d2 = engine.nn(Ts[k], max_corr_dist=truncate)        # inf where nothing lies within the bound
+        return float(np.sqrt(np.mean(np.minimum(d2.astype(np.float64), truncate * truncate))))
+
+    # (one round over the whole sample: a wrong candidate costs 3-4 ms whether 2 000 or 20 000 points are scored —
+    # its points lie decimetres to metres from the map and each walks hundreds of grid rows, a chain of dependent
+    # reads per wavefront that does not get shorter with fewer wavefronts; a cheaper first round on a tenth of the
+    # sample was measured and saved nothing, `tools/coarse_times.py`)
+    engine.set_source(np.ascontiguousarray(sub))       # dtype kept: fp64 georeferenced coordinates are shifted before they become fp32
+    cloud_scores = [cloud_score(k) for k in range(len(cands))]
+    scores = [float(np.hypot(cloud_scores[k], traj_scores[k])) for k in range(len(cands))]
     best = int(np.argmin(scores))
     R = cands[best]
     # (a stage next to a half turn becomes two of half the angle: the visualiser's logm needs the principal branch)
