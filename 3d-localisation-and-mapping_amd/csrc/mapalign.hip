@@ -2706,7 +2706,11 @@ static int set_pair_impl(ma_ctx* ctx, const void* gold_xyz, uint64_t m, float ce
     HIPCHK(hipMemcpyAsync(ctx->raw.p, gold_xyz, (size_t)mg * 12, hipMemcpyDefault, ctx->stream));
   }
   ma_ctx::PairHandoff handoff;
-  ctx->pair_handoff = &handoff;
+  struct HandoffScope {       // the context points at a stack object: detached again on EVERY way out, a throwing std::thread included
+    ma_ctx* ctx;
+    explicit HandoffScope(ma_ctx* c, ma_ctx::PairHandoff* h) : ctx(c) { ctx->pair_handoff = h; }
+    ~HandoffScope() { ctx->pair_handoff = nullptr; }
+  } handoff_scope(ctx, &handoff);
   int rc_src = MA_OK;
   std::thread helper([&]() {
     try {
@@ -2742,7 +2746,6 @@ static int set_pair_impl(ma_ctx* ctx, const void* gold_xyz, uint64_t m, float ce
     ~Joiner() {
       h.set(2, 0.f);          // (no effect once the build has said "go")
       if (t.joinable()) t.join();
-      ctx->pair_handoff = nullptr;
     }
   };
   int rc_gold;

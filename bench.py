@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--pairs-per-gpu", type=int, default=1,
                     help="alignments iterating at once on each GPU (separate contexts / streams / host threads); the headline "
                          "metric is quoted at 1 — more is the fleet-throughput figure of configs.concurrent_pairs as a whole run")
+    ap.add_argument("--sharded-timeout", type=float, default=180.0,
+                    help="N > 1: seconds the sharded-source leg (library RCCL) may take before the line is printed without it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=ITERS, help="oracle iterations for parity_vs_cpu (default: all 50)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs.c3 / c4 / c5_per_gpu objects")
@@ -422,6 +424,32 @@ def config_c5(eng, seed=0):
             "final_error_vs_truth": {"R_fro": float(np.linalg.norm(res.R - R0)), "t_m": float(np.linalg.norm(res.t - t0))}}
 
 
+def run_guarded(fn, seconds, device=None):
+    """Run ``fn`` on a helper thread and wait at most ``seconds`` for it -> (result, timed_out).
+    The N > 1 run executes library-RCCL code that no builder's one-GPU box can rehearse; if a communicator
+    bootstrap or a collective ever hangs on the real node, the headline line must still come out.  A timed-out
+    leg leaves its (daemon) thread behind, so the caller finishes with os._exit once the line is written."""
+    import threading
+
+    box = {}
+
+    def work():
+        try:
+            if device is not None:
+                import torch
+                torch.cuda.set_device(device)          # the current device is per thread
+            box["result"] = fn()
+        except BaseException as e:                    # noqa: BLE001 - reported in the line
+            box["result"] = {"error": f"{type(e).__name__}: {e}"}
+
+    th = threading.Thread(target=work, name="bench-guarded-leg", daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {"error": f"no answer within {seconds:.0f} s; the headline value above was measured before this leg and is unaffected"}, True
+    return box.get("result"), False
+
+
 def sharded_region(args, world, rank, local_rank, barrier, dist, torch):
     """ONE 1M-point pair (seed 0 on every rank) over all ranks through ma_icp_sharded, timed like
     the headline region.  Every rank returns the same dict; a failure anywhere is agreed on by all
@@ -578,39 +606,14 @@ def main():
     T = out.T
     err = np.array([float(np.linalg.norm(T[:3, :3] - R0)), float(np.linalg.norm(T[:3, 3] - t0))])
     if world > 1:
-        if not sharded:
-            # exercise the library's own RCCL path at N > 1 as well (a fleet-level
-            # stats vector through the communicator); never fatal for the benchmark itself
-            try:
-                # every rank first checks locally that the library can reach librccl, and the ranks
-                # agree through torch.distributed before any of them enters the library's communicator
-                # bootstrap (a rank that cannot would otherwise leave the others waiting in it)
-                try:
-                    eng.comm_unique_id()
-                    can = 1.0
-                except Exception:
-                    can = 0.0
-                agree = torch.tensor([can], dtype=torch.float64, device=f"cuda:{local_rank}")
-                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-                if float(agree.item()) < 1.0:
-                    raise RuntimeError("librccl is not loadable from libmapalign on every rank")
-                mdist.bootstrap_comm(eng)
-                err = eng.comm_allreduce(err, "max")
-                eng.comm_destroy()
-                lib_rccl = "fleet statistics reduced through libmapalign's RCCL communicator (ma_comm_allreduce_f64)"
-            except Exception as e:   # pragma: no cover - depends on the node
-                lib_rccl = f"library RCCL path failed ({e}); statistics reduced with torch.distributed instead"
-                fleet = torch.tensor(err, dtype=torch.float64, device=f"cuda:{local_rank}")
-                dist.all_reduce(fleet, op=dist.ReduceOp.MAX)
-                err = fleet.cpu().numpy()
+        if not sharded:       # fleet statistics: max over ranks (the library's own RCCL path is exercised by the sharded leg below)
+            fleet = torch.tensor(err, dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(fleet, op=dist.ReduceOp.MAX)
+            err = fleet.cpu().numpy()
         else:
             err = eng.comm_allreduce(err, "max")
 
     # ---- the second curve of SURVEY.md 8e in the same run: one pair sharded over all ranks ----
-    sharded_leg = None
-    if world > 1 and not sharded:
-        sharded_leg = sharded_region(args, world, rank, local_rank, barrier, dist, torch)
-
     line = None
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live (untimed extra passes) -----
@@ -694,19 +697,30 @@ def main():
         }
         if e2e:
             line["config"].update(e2e)
-        if sharded_leg is not None:
-            line["sharded"] = sharded_leg
         if cpu:
             line["speedup_vs_cpu_baseline"] = value / cpu["value"]
         if extra:
             line["configs"] = extra
-    eng.close()
-    if world > 1:
-        barrier()
-        dist.destroy_process_group()
+    # ---- the second curve of SURVEY.md 8e in the same run: one pair sharded over all ranks, LAST and under a
+    # watchdog — the headline line is complete before this leg starts and comes out whatever the leg does
+    wedged = False
+    if world > 1 and not sharded:
+        sharded_leg, wedged = run_guarded(lambda: sharded_region(args, world, rank, local_rank, barrier, dist, torch),
+                                          args.sharded_timeout, local_rank)
+        if line is not None:
+            line["sharded"] = sharded_leg
+            line["config"]["library_rccl"] = (sharded_leg or {}).get("library_rccl") or (sharded_leg or {}).get("error") \
+                or (sharded_leg or {}).get("skipped")
+    if not wedged:
+        eng.close()
+        if world > 1:
+            barrier()
+            dist.destroy_process_group()
     if line is not None:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if wedged:                 # a stuck collective cannot be cancelled: leave without the interpreter's shutdown
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -47,3 +47,17 @@ def test_plain_shell_run_with_gpus_2_goes_through_the_launcher_before_any_gpu_us
         assert "needs an MI355X" in err or "no HIP device" in err or "No HIP GPUs" in err, err[-2000:]
     else:                            # on a GPU box the same command yields the line
         assert json.loads(p.stdout.decode().strip().splitlines()[-1])["n_gpus"] == 2
+
+
+def test_guarded_leg_returns_its_result_or_gives_up_after_the_timeout():
+    """The N > 1 run's library-RCCL leg sits under a watchdog: a leg that never answers must not take the headline
+    line with it."""
+    import time as _time
+
+    res, timed_out = bench.run_guarded(lambda: {"value": 1.0}, 5.0)
+    assert res == {"value": 1.0} and not timed_out
+    res, timed_out = bench.run_guarded(lambda: (_ for _ in ()).throw(RuntimeError("rccl said no")), 5.0)
+    assert not timed_out and "rccl said no" in res["error"]
+    t0 = _time.perf_counter()
+    res, timed_out = bench.run_guarded(lambda: _time.sleep(30), 0.3)
+    assert timed_out and "no answer within" in res["error"] and _time.perf_counter() - t0 < 5.0
