@@ -83,6 +83,8 @@ def parse():
     # rehearsal on a one-GPU box only: several ranks share device 0 and rendezvous over gloo
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--force-device", type=int, default=None, help=argparse.SUPPRESS)
+    # rehearsal of the N > 1 run's second region on ONE GPU: a 1-rank RCCL process group and communicator
+    ap.add_argument("--rehearse-sharded", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -535,15 +537,16 @@ def main():
     if args.force_device is not None:
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.rehearse_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if args.backend == "nccl":      # RCCL
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
-        if world > 1:
+        if world > 1 or args.rehearse_sharded:
             if args.backend == "nccl":
                 dist.barrier(device_ids=[local_rank])
             else:
@@ -704,7 +707,7 @@ def main():
     # ---- the second curve of SURVEY.md 8e in the same run: one pair sharded over all ranks, LAST and under a
     # watchdog — the headline line is complete before this leg starts and comes out whatever the leg does
     wedged = False
-    if world > 1 and not sharded:
+    if (world > 1 or args.rehearse_sharded) and not sharded:
         sharded_leg, wedged = run_guarded(lambda: sharded_region(args, world, rank, local_rank, barrier, dist, torch),
                                           args.sharded_timeout, local_rank)
         if line is not None:
@@ -713,7 +716,7 @@ def main():
                 or (sharded_leg or {}).get("skipped")
     if not wedged:
         eng.close()
-        if world > 1:
+        if world > 1 or args.rehearse_sharded:
             barrier()
             dist.destroy_process_group()
     if line is not None:
