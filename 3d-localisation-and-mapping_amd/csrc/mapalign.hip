@@ -995,7 +995,8 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   const unsigned long long wg_start = wall_clock64();
   constexpr int kNW = kNNBlock / kWave;
   const uint32_t G = gridDim.x;
-  const uint32_t chunk = xcd_chunk(blockIdx.x, sched, sched.order != nullptr && st->iter > 0);
+  const bool warm = st->iter > 0;          // iteration 0 of a run: no schedule yet, and prev[] holds another run's matches
+  const uint32_t chunk = xcd_chunk(blockIdx.x, sched, sched.order != nullptr && warm);
   const uint32_t i = chunk * kNNBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   // per-wavefront LDS: the work queues during the search, the group sums afterwards
@@ -1021,7 +1022,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   if (has) {
     image(i);
     px = (float)Px; py = (float)Py; pz = (float)Pz;
-    if (prev) {
+    if (prev && warm) {
       // temporal coherence: last iteration's match bounds the search radius from the start
       const uint32_t pj = prev[i];
       if (pj != kNoMatch) {
@@ -1229,7 +1230,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ 
 // ~110 VGPRs and would halve the occupancy of the search.)
 __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0, DevState* __restrict__ st,
                                            double* __restrict__ trace, const int trace_cap, const double tol,
-                                           int* __restrict__ host_done) {
+                                           int* __restrict__ host_done, DevState* __restrict__ host_mirror = nullptr) {
   const int it = s0.iter;
   const double W = a[0];
   const double rmse = W > 0.0 ? sqrt(a[16] / W) : NAN;
@@ -1247,6 +1248,7 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
     s0.degenerate = 1;
     s0.done = 1;
     *st = s0;
+    if (host_mirror) *host_mirror = s0;
     if (host_done) *host_done = 1;
     return;
   }
@@ -1270,6 +1272,9 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
   }
   s0.prev_rmse = rmse;
   *st = s0;
+  // pinned host copy of the state (ma_icp): written with every solve, read by the host after its one
+  // synchronisation — no device-to-host copy at the end of the loop (posted writes: the solve does not wait for them)
+  if (host_mirror) *host_mirror = s0;
 }
 
 // The solve alone (sharded-source stepping: the 17 sums come back from the all-reduce).
@@ -1301,7 +1306,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
                                                          const int trace_cap, const double tol,
                                                          const uint32_t* __restrict__ wg_cost,
                                                          uint32_t* __restrict__ order, const uint32_t gshift,
-                                                         int* __restrict__ host_done) {
+                                                         int* __restrict__ host_done, DevState* __restrict__ host_mirror) {
   // `done` is written only by the last arriver, after every workgroup has read it.  It is
   // tested AFTER the first loads have been issued: every dependent memory round trip of
   // this small kernel is ~1 us of the iteration.
@@ -1357,7 +1362,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   asm volatile("" :: "v"(a[0]), "v"(a[18]));
   if (dbg_it < 64) g_rs[dbg_it][k][3] = wall_clock64();
 #endif
-  solve_step(a, s0, st, trace, trace_cap, tol, host_done);
+  solve_step(a, s0, st, trace, trace_cap, tol, host_done, host_mirror);
 #if MA_WGTIMES
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (dbg_it < 64) g_rs[dbg_it][k][4] = wall_clock64();
@@ -1840,7 +1845,9 @@ struct ma_ctx {
   // when it was uploaded; installing another gold map or source cloud invalidates it
   // (ma_step_accumulate / ma_step_solve then return MA_ERR_STATE until ma_state_set).
   bool state_valid = false;
-  int* host_done = nullptr;      // pinned host word the solve sets when the loop stops (tol > 0 runs)
+  int* host_done = nullptr;      // pinned host word the solve sets when the loop stops (tol > 0 runs); first word of a 1 KB pinned block:
+  DevState* host_state_in = nullptr;    //   + 256: the initial state of a run, uploaded from here (a pageable source blocks the caller while it is staged)
+  DevState* host_state_out = nullptr;   //   + 512: the state as the last solve left it (k_reduce_solve mirrors it here)
   std::vector<hipEvent_t> batch_ev;
   MemStats mem;
   int n_cus = 256;               // compute units of the device (how many workgroups are resident at once)
@@ -2095,12 +2102,13 @@ int upload_state(ma_ctx* ctx, const double* T) {
   world_to_centred(T, ctx->origin, s);
   s.prev_rmse = NAN; s.last_rmse = NAN; s.last_W = 0;
   s.iter = 0; s.done = 0; s.converged = 0; s.degenerate = 0;
-  // pageable source: hipMemcpyAsync stages it before returning, so `s` may go out of scope
-  HIPCHK(hipMemcpyAsync(ctx->state.p, &s, sizeof(s), hipMemcpyHostToDevice, ctx->stream));
-  if (ctx->have_src) {  // a new run starts without remembered matches
-    HIPCHK(ctx->prev.ensure((size_t)ctx->n * 4));
-    HIPCHK(hipMemsetAsync(ctx->prev.p, 0xFF, (size_t)ctx->n * 4, ctx->stream));
-  }
+  // from the pinned slot (every earlier use of it has completed: each entry point that runs the loop ends with a sync)
+  *ctx->host_state_in = s;
+  *ctx->host_state_out = s;
+  HIPCHK(hipMemcpyAsync(ctx->state.p, ctx->host_state_in, sizeof(s), hipMemcpyHostToDevice, ctx->stream));
+  // a new run starts without remembered matches: the search ignores prev[] while DevState::iter == 0 and has
+  // written every entry by the end of that iteration — no 4 MB fill per run
+  if (ctx->have_src) HIPCHK(ctx->prev.ensure((size_t)ctx->n * 4));
   *ctx->host_done = 0;   // every earlier launch has completed: each entry point that runs the loop ends with a sync
   ctx->state_valid = ctx->have_src;
   return MA_OK;
@@ -2144,7 +2152,8 @@ int launch_reduce_solve(ma_ctx* ctx, double tol) {
   hipLaunchKernelGGL(k_reduce_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
                      ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>(), ctx->ticket.as<uint32_t>(),
                      ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(),
-                     ctx->seg_order.as<uint32_t>(), ctx->last_gshift, tol > 0.0 ? ctx->host_done : (int*)nullptr);
+                     ctx->seg_order.as<uint32_t>(), ctx->last_gshift, tol > 0.0 ? ctx->host_done : (int*)nullptr,
+                     ctx->host_state_out);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
@@ -2378,8 +2387,11 @@ int ma_create(int device, ma_ctx** out) {
   if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_done), 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-  *ctx->host_done = 0;
+  static_assert(sizeof(DevState) <= 256, "pinned state slots are 256 bytes apart");
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_done), 1024, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+  std::memset(ctx->host_done, 0, 1024);
+  ctx->host_state_in = reinterpret_cast<DevState*>(reinterpret_cast<char*>(ctx->host_done) + 256);
+  ctx->host_state_out = reinterpret_cast<DevState*>(reinterpret_cast<char*>(ctx->host_done) + 512);
   for (DevBuf* b : ctx->all_bufs()) b->stats = &ctx->mem;
   *out = ctx;
   return MA_OK;
@@ -3214,8 +3226,8 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
     if (early_exit && (k + 1) % kBatch == 0) HIPCHK(hipEventRecord(ctx->batch_ev[k / kBatch], ctx->stream));
   }
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-  DevState s;
-  if ((rc = fetch_state(ctx, &s))) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const DevState s = *ctx->host_state_out;     // the last solve's pinned copy of the state: no device-to-host copy
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   if (timek) {
