@@ -303,40 +303,48 @@ class MapAligner:
         self.n_source = n
 
     def set_pair(self, gold_cloud, comparison_cloud, weights=None, cell=0.0):
-        """``set_gold`` + ``set_source`` of one pair.  Two HOST arrays of the same dtype — float32, or float64 as
-        Open3D / NumPy hand them over — go through ``ma_set_pair`` / ``ma_set_pair_f64``, which upload and sort the
-        comparison cloud while the gold map is being indexed (same state afterwards, bitwise); anything else
-        (mixed dtypes, device-resident arrays) takes the two calls."""
-        def plain_host(a, dt):
-            return (_device_array(a, "cloud", self.device, None, ("<f4", "<f8")) is None
-                    and isinstance(a, np.ndarray) and a.dtype == dt and a.ndim == 2 and a.shape[1:] == (3,)
-                    and a.shape[0] > 0)
+        """``set_gold`` + ``set_source`` of one pair.  Two arrays of the same dtype — float32, or float64 as Open3D /
+        NumPy hand them over — that are both host arrays or both already in this GPU's memory go through
+        ``ma_set_pair`` / ``ma_set_pair_f64``, which stage the comparison cloud (copy, bounds, sort) on a second stream
+        while the gold map is being indexed (same state afterwards, bitwise); anything else (mixed dtypes or places)
+        takes the two calls."""
+        fp = C.POINTER(C.c_float)
+
+        def view(a):
+            """(pointer, n, typestr, keepalive) of an [N,3] float32 / float64 array, host or device; None if it is neither."""
+            dev = _device_array(a, "cloud", self.device, (3,), ("<f4", "<f8"))
+            if dev is not None:
+                return dev[0], dev[1][0], dev[2], dev[3], True
+            if isinstance(a, np.ndarray) and a.dtype in (np.float32, np.float64) and a.ndim == 2 and a.shape[1:] == (3,) and a.shape[0] > 0:
+                h = np.ascontiguousarray(a)
+                return h.ctypes.data, h.shape[0], "<f4" if h.dtype == np.float32 else "<f8", h, False
+            return None
+
         w_ok = weights is None or (isinstance(weights, np.ndarray) and weights.ndim == 1)
-        dt = next((d for d in (np.float32, np.float64) if plain_host(gold_cloud, d) and plain_host(comparison_cloud, d)), None)
-        if dt is None or not w_ok:
+        vg, vc = view(gold_cloud), view(comparison_cloud)
+        if vg is None or vc is None or vg[2] != vc[2] or vg[4] != vc[4] or not w_ok:
             grid = self.set_gold(gold_cloud, cell)
             self.set_source(comparison_cloud, weights)
             return grid
-        g, c = np.ascontiguousarray(gold_cloud), np.ascontiguousarray(comparison_cloud)
-        fp = C.POINTER(C.c_float)
         w_p = None
         if weights is not None:
             w = np.ascontiguousarray(weights, dtype=np.float32)
-            if w.shape[0] != c.shape[0]:
+            if w.shape[0] != vc[1]:
                 raise ValueError("weights must have one entry per comparison point")
             w_p = w.ctypes.data_as(fp)
         self._shift = np.zeros(3)
         self.n_gold = self.n_source = 0
         self.gold_token = None
-        if dt is np.float32:
-            self._chk(self._lib.ma_set_pair(self._ctx, g.ctypes.data_as(fp), g.shape[0], float(cell), c.ctypes.data_as(fp), w_p,
-                                            c.shape[0]))
+        if vg[2] == "<f4":
+            self._chk(self._lib.ma_set_pair(self._ctx, C.cast(C.c_void_p(vg[0]), fp), vg[1], float(cell),
+                                            C.cast(C.c_void_p(vc[0]), fp), w_p, vc[1]))
         else:
+            dp = C.POINTER(C.c_double)
             shift = np.zeros(3)
-            self._chk(self._lib.ma_set_pair_f64(self._ctx, _f64p(g), g.shape[0], float(cell), _f64p(shift), _f64p(c), w_p,
-                                                c.shape[0]))
+            self._chk(self._lib.ma_set_pair_f64(self._ctx, C.cast(C.c_void_p(vg[0]), dp), vg[1], float(cell), _f64p(shift),
+                                                C.cast(C.c_void_p(vc[0]), dp), w_p, vc[1]))
             self._shift = shift
-        self.n_gold, self.n_source = g.shape[0], c.shape[0]
+        self.n_gold, self.n_source = vg[1], vc[1]
         return self.grid_info()
 
     def set_source_from_depth(self, depth, K, T_cam_to_world, depth_scale=1000.0):
