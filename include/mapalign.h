@@ -164,13 +164,16 @@ int ma_search_geometry(const ma_ctx* ctx, uint32_t* n_workgroups, uint32_t* bloc
  *   g = (T_cam_to_world @ [X,Y,Z,1])[:3]
  * K = {fx, fy, cx, cy} already rescaled to the depth resolution.  dtype: 0 = float32
  * (the reference's format, dataset.py:68-81: float32 millimetres, depth_scale = 1000),
- * 1 = uint16.  Pixels with depth <= 0 / NaN / inf are dropped; survivors keep row-major
- * pixel order.  *n_valid receives the number of points written. */
+ * 1 = uint16.  Pixels with depth <= 0 / NaN / inf are dropped: *n_valid receives the number of
+ * valid pixels, and everything that hands points or per-point results back (ma_get_source,
+ * ma_get_source_stored, ma_nn) reports exactly those, in row-major pixel order.  (Inside, every
+ * pixel keeps its slot and an invalid one is a hole the search skips; the compaction happens
+ * only where points are handed back.) */
 int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height,
                              const float K[4], const double T_cam_to_world[16],
                              float depth_scale, uint64_t* n_valid);
 /* Device time (ms, hipEvents on the ctx stream) of the last ma_set_source_from_depth /
- * ma_map_add_depth: memset of the scan status + the single-pass k_unproject. */
+ * ma_map_add_depth: the k_unproject launch (one streaming pass, pixel i -> slot i). */
 int ma_last_device_ms(const ma_ctx* ctx, double* ms);
 /* Row N4: full-frame map builder — what RTAB-Map's .ply export does for the
  * reference, on the device: every depth frame is unprojected with its pose (same pinhole
