@@ -36,6 +36,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -248,31 +250,46 @@ __global__ __launch_bounds__(kBlock) void k_cell_keys(const float* __restrict__ 
   if (counts) atomicAdd(&counts[c], 1u);
 }
 
-// Occupancy probes of the cell-edge / grid-phase search (13 per gold map): only WHETHER a cell
-// holds a point matters, so the probe marks a byte per cell with plain stores (idempotent: no
+// Occupancy probes of the cell-edge / grid-phase search (12 per gold map): only WHETHER a cell
+// holds a point matters, so a probe marks a byte per cell with plain stores (idempotent: no
 // atomics, a quarter of the table bytes of a u32 histogram) and counts the marks 16 at a time.
 // (The histogram kernels took 55 + 28 us per probe at 1M points, a third of the grid build.)
+constexpr int kMaxProbes = 16;
+constexpr uint32_t kProbeBlocks = 256;         // workgroups of k_count_marks per probe
+struct ProbeSet {
+  GridP g[kMaxProbes];
+  uint32_t n16[kMaxProbes];     // 16-byte words of each probe's table
+  uint32_t stride16;            // distance between two tables, in 16-byte words
+  int count;
+};
+
+// ALL probes of a round trip in one launch (round 3; round 2 launched one pair of kernels per probe, 12.5 us each,
+// for kernels that take 3-7 us of work): every point is read and centred once and marked in `count` tables.
 __global__ __launch_bounds__(kBlock) void k_mark_cells(const float* __restrict__ xyz, uint32_t n, double o0, double o1,
-                                                       double o2, GridP g, uint8_t* __restrict__ mark) {
+                                                       double o2, const ProbeSet P, uint8_t* __restrict__ mark) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const float x = (float)((double)xyz[3 * (size_t)i] - o0);
   const float y = (float)((double)xyz[3 * (size_t)i + 1] - o1);
   const float z = (float)((double)xyz[3 * (size_t)i + 2] - o2);
-  mark[cell_of(x, y, z, g)] = 1;
+#pragma unroll 1
+  for (int k = 0; k < P.count; ++k) mark[(size_t)k * P.stride16 * 16u + cell_of(x, y, z, P.g[k])] = 1;
 }
 
-// marks: 0 / 1 bytes, padded with zeros to a multiple of 16.  Counts them AND clears them (the next probe
-// marks the same table: no memset between probes — 5 of a probe's 25 us in round 2), with a few hundred
-// large workgroups: the count ends in one atomic add per workgroup on one address, and those queue
-// (859 workgroups: 12 us for 3.5 MB; 256: 4 us).
-__global__ __launch_bounds__(kBlock) void k_count_marks(uint4* __restrict__ mark16, uint32_t n16,
-                                                        unsigned long long* __restrict__ out) {
+// marks: 0 / 1 bytes, each table padded with zeros to a multiple of 16.  Counts them AND clears them (the tables
+// are all-zero again afterwards: no memset, neither between probes nor between calls), blockIdx.y = probe, with
+// kProbeBlocks large workgroups per probe.  Every workgroup stores its count with a plain store — straight into the
+// pinned mailbox in host memory (see Mailbox below) — and the host adds them up: no atomic (round 2: one per
+// workgroup on one address, and those queue), no cleared counter, no device-to-host copy.
+__global__ __launch_bounds__(kBlock) void k_count_marks(uint4* __restrict__ mark16, const ProbeSet P,
+                                                        unsigned long long* __restrict__ out_per_block) {
+  const uint32_t n16 = P.n16[blockIdx.y];
+  uint4* __restrict__ tab = mark16 + (size_t)blockIdx.y * P.stride16;
   uint32_t c = 0;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n16; i += gridDim.x * kBlock) {
-    const uint4 v = mark16[i];
+    const uint4 v = tab[i];
     c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-    if (v.x | v.y | v.z | v.w) mark16[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (v.x | v.y | v.z | v.w) tab[i] = make_uint4(0u, 0u, 0u, 0u);
   }
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_count_marks(uint4* __restrict__ mark
     uint32_t t = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / kWave; ++w) t += part[w];
-    if (t) atomicAdd(out, (unsigned long long)t);
+    out_per_block[(size_t)blockIdx.y * kProbeBlocks + blockIdx.x] = t;
   }
 }
 
@@ -336,6 +353,25 @@ __global__ __launch_bounds__(kBlock) void k_cell_tails(const uint32_t* __restric
 #pragma unroll
     for (int w = 0; w < kBlock / kWave; ++w) t += part[w];
     ends_per_block[blockIdx.x] = t;
+  }
+}
+
+// sum of n words -> one 64-bit word (ONE workgroup; the destination is the pinned mailbox): the run-end counts of
+// k_cell_tails = the number of occupied cells
+__global__ __launch_bounds__(kBlock) void k_sum_u32(const uint32_t* __restrict__ v, const uint32_t n,
+                                                    unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += kBlock) c += v[i];
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) c += __shfl_down(c, off, kWave);
+  __shared__ unsigned long long part[kBlock / kWave];
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) t += part[w];
+    *out = t;
   }
 }
 
@@ -395,39 +431,91 @@ __global__ __launch_bounds__(kBlock) void k_gather(const float* __restrict__ xyz
 // their axis and stop as soon as the offset reaches the best value found (near the surfaces,
 // i.e. almost everywhere it matters, after one or two taps).
 constexpr int kOccCap = 9;
+constexpr int kOccReach = kOccCap - 1;             // farthest offset looked at
+constexpr int kOccXOut = kBlock - 2 * kOccReach;   // cells a workgroup of k_occ_x writes
 
+// Pass x (round 3): occupancy comes from the cell table with ONE coalesced read per cell (round 2: up to 32 per
+// cell — most of the grid is empty and an empty cell looked at all 16 neighbours, two table words each: 37 us for
+// 3.8M cells).  Thread t of a workgroup looks at cell base - 8 + t, the wavefronts' ballots form a 256-bit
+// occupancy map in LDS, and the distance to the nearest set bit inside the cell's own row is two bit scans.
 __global__ __launch_bounds__(kBlock) void k_occ_x(const uint32_t* __restrict__ cstart, const int nx, const uint32_t ncells,
                                                   uint8_t* __restrict__ d) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= ncells) return;
-  const int x = (int)(i % (uint32_t)nx);
-  const uint32_t row = i - (uint32_t)x;
+  __shared__ unsigned long long bits[kBlock / kWave + 1];
+  const long long cell = (long long)blockIdx.x * kOccXOut - kOccReach + (long long)threadIdx.x;
+  bool occ = false;
+  if (cell >= 0 && cell < (long long)ncells) occ = cstart[cell + 1] != cstart[cell];
+  const unsigned long long m = __ballot(occ);
+  if ((threadIdx.x & (kWave - 1)) == 0) bits[threadIdx.x / kWave] = m;
+  if (threadIdx.x == 0) bits[kBlock / kWave] = 0ull;
+  __syncthreads();
+  if (threadIdx.x < kOccReach || threadIdx.x >= kBlock - kOccReach || cell >= (long long)ncells) return;
+  const int lo = (int)threadIdx.x - kOccReach, w = lo >> 6, sh = lo & 63;
+  unsigned long long win = bits[w] >> sh;
+  if (sh) win |= bits[w + 1] << (64 - sh);
+  // bit kOccReach of the window is the cell itself; keep what lies inside its row
+  const int x = (int)((uint32_t)cell % (uint32_t)nx);
+  const int left = min(x, kOccReach), right = min(nx - 1 - x, kOccReach);
+  uint32_t wb = (uint32_t)win & ((2u << (kOccReach + right)) - 1u) & ~((1u << (kOccReach - left)) - 1u);
   int best = kOccCap;
-  if (cstart[i + 1] != cstart[i]) {
-    best = 0;
-  } else {
-    for (int k = 1; k < kOccCap; ++k) {
-      const int xl = x - k, xr = x + k;
-      const bool l = xl >= 0 && cstart[row + (uint32_t)xl + 1u] != cstart[row + (uint32_t)xl];
-      const bool r = xr < nx && cstart[row + (uint32_t)xr + 1u] != cstart[row + (uint32_t)xr];
-      if (l || r) { best = k; break; }
-    }
+  if (wb) {
+    const uint32_t lower = wb & ((2u << kOccReach) - 1u), upper = wb >> kOccReach;
+    const int dl = lower ? kOccReach - (31 - __clz((int)lower)) : kOccCap;
+    const int dr = upper ? __ffs((int)upper) - 1 : kOccCap;
+    best = min(dl, dr);
   }
-  d[i] = (uint8_t)best;
+  d[cell] = (uint8_t)best;
 }
 
-// out(p) = min over offsets k along the axis (stride in cells, n cells long) of max(in(p + k), |k|)
+// out(p) = min over offsets k along the axis (stride in cells, n cells long) of max(in(p + k), |k|).
+// Round 3: FOUR cells per thread — consecutive along x inside one row, so that they share their position along the
+// axis — read with one (unaligned) 32-bit load per tap and combined as two pairs of 16-bit lanes (v_pk_max_u16 /
+// v_pk_min_u16): a quarter of the load instructions of the byte-per-thread form (40 us per pass for 3.8M cells,
+// bound by the L1's one-request-per-lane rate, not by bytes).  Tables are padded by 16 bytes: the last group of a
+// row reads (never writes) up to 3 bytes beyond it.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t ld_u32_unaligned(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
 __global__ __launch_bounds__(kBlock) void k_occ_axis(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                     const uint32_t ncells, const uint32_t stride, const int n) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= ncells) return;
-  const int pos = (int)((i / stride) % (uint32_t)n);
-  int best = in[i];
-  for (int k = 1; k < best; ++k) {       // an offset of `best` or more cannot improve on best
-    if (pos - k >= 0) best = min(best, max((int)in[i - (uint32_t)k * stride], k));
-    if (pos + k < n) best = min(best, max((int)in[i + (uint32_t)k * stride], k));
+                                                     const uint32_t nrows, const uint32_t nx, const uint32_t stride,
+                                                     const uint32_t rows_per_step, const int n) {
+  // a "row" is a run of nx cells along x; rows_per_step rows make one step along the axis (1 for y, ny for z)
+  const uint32_t per_row = (nx + 3u) / 4u;
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t row = t / per_row, x = (t - row * per_row) * 4u;
+  if (row >= nrows) return;
+  const int pos = (int)((row / rows_per_step) % (uint32_t)n);
+  const size_t i = (size_t)row * nx + x;
+  const uint32_t w = ld_u32_unaligned(in + i);
+  const uint32_t kLo = 0x00FF00FFu;
+  us2 be = __builtin_bit_cast(us2, w & kLo), bo = __builtin_bit_cast(us2, (w >> 8) & kLo);
+  auto widest = [&]() -> int {
+    const us2 m = __builtin_elementwise_max(be, bo);
+    return max((int)m.x, (int)m.y);
+  };
+  int kmax = widest();
+  for (int k = 1; k < kmax; ++k) {       // an offset of `best` or more cannot improve on best
+    const us2 ks = {(unsigned short)k, (unsigned short)k};
+    if (pos - k >= 0) {
+      const uint32_t u = ld_u32_unaligned(in + i - (size_t)k * stride);
+      be = __builtin_elementwise_min(be, __builtin_elementwise_max(__builtin_bit_cast(us2, u & kLo), ks));
+      bo = __builtin_elementwise_min(bo, __builtin_elementwise_max(__builtin_bit_cast(us2, (u >> 8) & kLo), ks));
+    }
+    if (pos + k < n) {
+      const uint32_t u = ld_u32_unaligned(in + i + (size_t)k * stride);
+      be = __builtin_elementwise_min(be, __builtin_elementwise_max(__builtin_bit_cast(us2, u & kLo), ks));
+      bo = __builtin_elementwise_min(bo, __builtin_elementwise_max(__builtin_bit_cast(us2, (u >> 8) & kLo), ks));
+    }
+    kmax = widest();
   }
-  out[i] = (uint8_t)best;
+  const uint32_t r = __builtin_bit_cast(uint32_t, be) | (__builtin_bit_cast(uint32_t, bo) << 8);
+  if (x + 4u <= nx) {
+    __builtin_memcpy(out + i, &r, 4);
+  } else {
+    for (uint32_t j = 0; x + j < nx; ++j) out[i + j] = (uint8_t)(r >> (8u * j));
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1834,6 +1922,9 @@ struct ma_ctx {
   DevBuf raw_src, raw64_src;     // ma_set_pair{,_f64}: the scan is uploaded here while the gold map is being built from `raw`
   DevBuf akeys_a, akeys_b, avals_a, avals_b, acub_tmp, amisc;     // ... and sorted with its own scratch on its own stream
   hipStream_t aux_stream = nullptr;
+  DevBuf probe_marks;            // mark tables of the occupancy probes: all-zero between calls (occupied_cells_multi)
+  size_t probe_clean = 0;        //   bytes of it known to be zero
+  char* mailbox = nullptr;       // pinned host memory, 2 x kMailBytes: the small results of the build kernels land here (Mailbox below)
 
   // batched box lifting (a10 over many frames)
   DevBuf lift_poses, lift_frames;
@@ -1883,7 +1974,7 @@ struct ma_ctx {
   };
   PairHandoff* pair_handoff = nullptr;
   std::vector<DevBuf*> all_bufs() {
-    std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b,
+    std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b, &probe_marks,
                               &src, &src_perm, &raw, &raw_src, &raw64_src, &akeys_a, &akeys_b, &avals_a, &avals_b, &acub_tmp, &amisc, &raw64, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
                               &depth_in, &lift_poses, &lift_frames, &unproj_cnt, &state, &partials, &trace, &acc19, &ticket,
                               &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
@@ -1980,12 +2071,40 @@ int need_ready(ma_ctx* ctx) {
 // A lane = one stream plus the scratch buffers the staging steps of a cloud use on it.  Everything runs on
 // the main lane (the context's stream) except the scan of ma_set_pair, which is staged on the aux lane by a
 // helper thread while the main lane builds the gold map.
+#if MA_PAIR_TIMES   // debug variant only (tools/pair_host_times.py): host-side time stamps of one ma_set_pair, both threads
+std::mutex g_pt_mu;
+std::vector<std::pair<const char*, double>> g_pt;
+void pt(const char* what) {
+  const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  std::lock_guard<std::mutex> lock(g_pt_mu);
+  g_pt.emplace_back(what, t);
+}
+void pt_dump() {
+  std::lock_guard<std::mutex> lock(g_pt_mu);
+  std::sort(g_pt.begin(), g_pt.end(), [](const auto& a, const auto& b) { return a.second < b.second; });
+  for (const auto& e : g_pt) std::fprintf(stderr, "  %9.1f us  %s\n", e.second - g_pt.front().second, e.first);
+  g_pt.clear();
+}
+#define MA_PT(x) pt(x)
+#else
+#define MA_PT(x) ((void)0)
+#endif
+//
+// Mailbox: the few numbers a staging step hands back to the host (bounds, occupancy counts, the count of bad
+// weights) are WRITTEN BY THE KERNELS INTO PINNED HOST MEMORY and read after the stream synchronisation the step
+// has anyway.  Round 2 copied them device-to-host into pageable vectors; next to the other thread's 12 MB pageable
+// upload such a copy waited for that upload to finish (rocprofv3 memory-copy trace: the gold map's 32 KB of bounds
+// arrived 230 us after the kernel that produced them, right behind the scan's upload).
+constexpr size_t kMailBytes = 128 * 1024;      // per lane: [0, 64K) bounds, [64K, 96K) probe counts, [96K, ...) single words
+constexpr size_t kMailProbe = 64 * 1024, kMailWord = 96 * 1024;
+static_assert(kMaxProbes * kProbeBlocks * 8 <= kMailWord - kMailProbe, "probe region of the mailbox");
 struct Lane {
   hipStream_t stream;
   DevBuf *keys_a, *keys_b, *vals_a, *vals_b, *cub_tmp, *misc;
+  char* mail;
 };
-Lane main_lane(ma_ctx* ctx) { return {ctx->stream, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc}; }
-Lane aux_lane(ma_ctx* ctx) { return {ctx->aux_stream, &ctx->akeys_a, &ctx->akeys_b, &ctx->avals_a, &ctx->avals_b, &ctx->acub_tmp, &ctx->amisc}; }
+Lane main_lane(ma_ctx* ctx) { return {ctx->stream, &ctx->keys_a, &ctx->keys_b, &ctx->vals_a, &ctx->vals_b, &ctx->cub_tmp, &ctx->misc, ctx->mailbox}; }
+Lane aux_lane(ma_ctx* ctx) { return {ctx->aux_stream, &ctx->akeys_a, &ctx->akeys_b, &ctx->avals_a, &ctx->avals_b, &ctx->acub_tmp, &ctx->amisc, ctx->mailbox + kMailBytes}; }
 
 // bounding box (and finiteness check) of a device-resident n x 3 cloud
 int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3], int stride = 3, bool holes_ok = false,
@@ -1993,12 +2112,10 @@ int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float
   const Lane ml = main_lane(ctx);
   const Lane& L = lane ? *lane : ml;
   const int nb = std::min<uint32_t>(div_up(n, kBlock), 1024);
-  HIPCHK(L.misc->ensure((size_t)nb * 8 * sizeof(float)));
-  if (stride == 4) hipLaunchKernelGGL(k_minmax<4>, dim3(nb), dim3(kBlock), 0, L.stream, d_xyz, n, L.misc->as<float>(), holes_ok ? 1 : 0);
-  else hipLaunchKernelGGL(k_minmax<3>, dim3(nb), dim3(kBlock), 0, L.stream, d_xyz, n, L.misc->as<float>(), 0);
+  float* h = reinterpret_cast<float*>(L.mail);          // [nb][8], written by the kernel
+  if (stride == 4) hipLaunchKernelGGL(k_minmax<4>, dim3(nb), dim3(kBlock), 0, L.stream, d_xyz, n, h, holes_ok ? 1 : 0);
+  else hipLaunchKernelGGL(k_minmax<3>, dim3(nb), dim3(kBlock), 0, L.stream, d_xyz, n, h, 0);
   HIPCHK(hipGetLastError());
-  std::vector<float> h((size_t)nb * 8);
-  HIPCHK(hipMemcpyAsync(h.data(), L.misc->p, h.size() * sizeof(float), hipMemcpyDeviceToHost, L.stream));
   HIPCHK(hipStreamSynchronize(L.stream));
   double bad = 0;
   for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
@@ -2011,6 +2128,21 @@ int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float
   }
   if (bad > 0) return ctx->fail(MA_ERR_INVALID, "cloud has non-finite coordinates (filter them first, as the reference's read_point_cloud(remove_nan_points=True, remove_infinite_points=True) does)");
   return MA_OK;
+}
+
+// Stable radix sort of (cell key, index) pairs.  hipCUB forwards to rocPRIM with its default configuration, which
+// sorts up to 2^20 items by MERGE sort (block sort + 10 merge passes: 21 launches of 6-9 us for the 1M-point
+// benchmark cloud, 150-190 us) and only larger inputs by Onesweep (one histogram + one pass per 8 key bits).  The
+// same library call with the merge-sort limit lowered to 64K items takes the Onesweep path from there on.
+#ifndef MA_MERGE_SORT_LIMIT
+#define MA_MERGE_SORT_LIMIT 65536
+#endif
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config,
+                                              (size_t)MA_MERGE_SORT_LIMIT>;
+hipError_t sort_pairs_u32(void* tmp, size_t& tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                          uint32_t* vals_out, uint32_t n, int bits, hipStream_t stream) {
+  return rocprim::radix_sort_pairs<SortConfig>(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                               (unsigned)bits, stream);
 }
 
 // keys/vals for `n` raw points + optional histogram; then a stable radix sort by cell id.
@@ -2033,42 +2165,57 @@ int sort_by_cell(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, co
   int bits = 1;
   while (bits < 32 && (1ull << bits) < ncells) ++bits;
   size_t tmp_bytes = 0;
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, L.keys_a->as<uint32_t>(),
-                                            L.keys_b->as<uint32_t>(), L.vals_a->as<uint32_t>(),
-                                            L.vals_b->as<uint32_t>(), (int)n, 0, bits, L.stream));
+  HIPCHK(sort_pairs_u32(nullptr, tmp_bytes, L.keys_a->as<uint32_t>(), L.keys_b->as<uint32_t>(), L.vals_a->as<uint32_t>(),
+                        L.vals_b->as<uint32_t>(), n, bits, L.stream));
   HIPCHK(L.cub_tmp->ensure(tmp_bytes));
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(L.cub_tmp->p, tmp_bytes, L.keys_a->as<uint32_t>(),
-                                            L.keys_b->as<uint32_t>(), L.vals_a->as<uint32_t>(),
-                                            L.vals_b->as<uint32_t>(), (int)n, 0, bits, L.stream));
+  HIPCHK(sort_pairs_u32(L.cub_tmp->p, tmp_bytes, L.keys_a->as<uint32_t>(), L.keys_b->as<uint32_t>(), L.vals_a->as<uint32_t>(),
+                        L.vals_b->as<uint32_t>(), n, bits, L.stream));
   return MA_OK;
 }
 
-// byte marks of the raw gold points in each of `count` (<= 16) candidate grids -> numbers of
-// occupied cells.  The probes are enqueued back to back (same mark buffer, cleared in stream
-// order) and read back with ONE synchronisation.
+// byte marks of the raw gold points in each of `count` (<= 16) candidate grids -> numbers of occupied cells.
+// One marking launch and one counting launch for all probes whose tables fit kProbeBudget together (all of them,
+// unless the grids are huge), ONE synchronisation.  The mark tables live in their own buffer, which is all-zero
+// whenever this function is not running (the counting kernel clears what it counts): it is cleared once after
+// every (re)allocation and after a failed call, never per call.
+constexpr size_t kProbeBudget = 256u << 20;
 int occupied_cells_multi(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP* grids, int count, const double o[3],
                          uint64_t* out) {
+  if (count > kMaxProbes) return ctx->fail(MA_ERR_INVALID, "too many occupancy probes");
   uint64_t n16_max = 0;
   for (int k = 0; k < count; ++k) n16_max = std::max<uint64_t>(n16_max, ((uint64_t)grids[k].nx * grids[k].ny * grids[k].nz + 15) / 16);
-  HIPCHK(ctx->occ_b.ensure(n16_max * 16));
-  if (count > 16) return ctx->fail(MA_ERR_INVALID, "too many occupancy probes");
-  HIPCHK(ctx->misc.ensure(128));
-  HIPCHK(hipMemsetAsync(ctx->misc.p, 0, 8 * (size_t)count, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->occ_b.p, 0, n16_max * 16, ctx->stream));     // once: every count clears what its probe marked
-  for (int k = 0; k < count; ++k) {
-    const GridP& g = grids[k];
-    const uint64_t n16 = ((uint64_t)g.nx * g.ny * g.nz + 15) / 16;
-    hipLaunchKernelGGL(k_mark_cells, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0], o[1], o[2], g,
-                       ctx->occ_b.as<uint8_t>());
+  const size_t table = n16_max * 16;
+  const int per_launch = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, kProbeBudget / std::max<size_t>(table, 1)));
+  const size_t bytes = table * (size_t)per_launch;
+  if (ctx->probe_marks.cap < bytes) ctx->probe_clean = 0;
+  HIPCHK(ctx->probe_marks.ensure(bytes));
+  if (ctx->probe_clean < bytes) {
+    HIPCHK(hipMemsetAsync(ctx->probe_marks.p, 0, ctx->probe_marks.cap, ctx->stream));
+  }
+  ctx->probe_clean = 0;                    // until this call has come to its end
+  unsigned long long* mail = reinterpret_cast<unsigned long long*>(ctx->mailbox + kMailProbe);   // [count][kProbeBlocks]
+  for (int k0 = 0; k0 < count; k0 += per_launch) {
+    ProbeSet P{};
+    P.count = std::min(per_launch, count - k0);
+    P.stride16 = (uint32_t)n16_max;
+    for (int k = 0; k < P.count; ++k) {
+      P.g[k] = grids[k0 + k];
+      P.n16[k] = (uint32_t)(((uint64_t)P.g[k].nx * P.g[k].ny * P.g[k].nz + 15) / 16);
+    }
+    hipLaunchKernelGGL(k_mark_cells, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, d_xyz, n, o[0], o[1], o[2], P,
+                       ctx->probe_marks.as<uint8_t>());
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_count_marks, dim3(std::min<uint32_t>(div_up(n16, kBlock), 256)), dim3(kBlock), 0, ctx->stream,
-                       ctx->occ_b.as<uint4>(), (uint32_t)n16, ctx->misc.as<unsigned long long>() + k);
+    hipLaunchKernelGGL(k_count_marks, dim3(kProbeBlocks, P.count), dim3(kBlock), 0, ctx->stream,
+                       ctx->probe_marks.as<uint4>(), P, mail + (size_t)k0 * kProbeBlocks);
     HIPCHK(hipGetLastError());
   }
-  unsigned long long h[16] = {0};
-  HIPCHK(hipMemcpyAsync(h, ctx->misc.p, 8 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  for (int k = 0; k < count; ++k) out[k] = h[k];
+  ctx->probe_clean = ctx->probe_marks.cap;
+  for (int k = 0; k < count; ++k) {
+    uint64_t t = 0;
+    for (uint32_t b = 0; b < kProbeBlocks; ++b) t += mail[(size_t)k * kProbeBlocks + b];
+    out[k] = t;
+  }
   return MA_OK;
 }
 int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, const double o[3], uint64_t* out) {
@@ -2271,11 +2418,11 @@ int build_coarse_levels(ma_ctx* ctx) {
     int bits = 1;
     while (bits < 32 && (1ull << bits) < ncells) ++bits;
     size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
-                                              ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), (int)n, 0, bits, ctx->stream));
+    HIPCHK(sort_pairs_u32(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                          ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream));
     HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(),
-                                              ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), (int)n, 0, bits, ctx->stream));
+    HIPCHK(sort_pairs_u32(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
+                          ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream));
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), (int)(ncells + 8), ctx->stream));
     HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), (int)(ncells + 8), ctx->stream));
@@ -2378,6 +2525,8 @@ int ma_create(int device, ma_ctx** out) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->host_done) (void)hipHostFree(ctx->host_done);
+    if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     delete ctx;
     return MA_ERR_HIP;
   };
@@ -2392,6 +2541,8 @@ int ma_create(int device, ma_ctx** out) {
   std::memset(ctx->host_done, 0, 1024);
   ctx->host_state_in = reinterpret_cast<DevState*>(reinterpret_cast<char*>(ctx->host_done) + 256);
   ctx->host_state_out = reinterpret_cast<DevState*>(reinterpret_cast<char*>(ctx->host_done) + 512);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), 2 * kMailBytes, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+  std::memset(ctx->mailbox, 0, 2 * kMailBytes);
   for (DevBuf* b : ctx->all_bufs()) b->stats = &ctx->mem;
   *out = ctx;
   return MA_OK;
@@ -2408,6 +2559,7 @@ int ma_destroy(ma_ctx* ctx) {
   } catch (...) {   // (the buffer list is a std::vector: never let its allocation failure cross the ABI)
   }
   if (ctx->host_done) (void)hipHostFree(ctx->host_done);
+  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   for (hipEvent_t e : ctx->batch_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -2460,6 +2612,7 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   float lo[3], hi[3];
   int rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, lo, hi);
   if (rc) return rc;
+  MA_PT("gold: bounds read");
   // centring origin: bounding-box centre, rounded to fp32 so that (x - o) is exact-ish
   for (int a = 0; a < 3; ++a) ctx->origin[a] = (double)(float)(0.5 * ((double)lo[a] + (double)hi[a]));
 
@@ -2500,6 +2653,7 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   }
   c = clamp_cell_to_budget(lo, hi, c, kMaxCells);
   if (!(c > 0.f) || !std::isfinite(c)) return ctx->fail(MA_ERR_INVALID, "could not choose a cell edge");
+  MA_PT("gold: cell edge chosen");
   if (ctx->pair_handoff) ctx->pair_handoff->set(1, c);     // ma_set_pair: the scan's sort may start (origin and cell edge are final)
 
   // Grid phase: a surface that runs along a cell boundary (walls and floors of man-made
@@ -2537,6 +2691,7 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
       if (occ[k] < best_axis_occ[a]) { best_axis_occ[a] = occ[k]; best_lo[a] = trial_lo[k]; }
     }
     for (int a = 0; a < 3; ++a) lo[a] = best_lo[a];
+    MA_PT("gold: phase probes read");
   }
 
   // one grid per level: cell edges c, 2c, 4c, 8c over the same box
@@ -2555,11 +2710,16 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     HIPCHK(hipMemsetAsync(hist.p, 0, (ncells + 8) * 4 + 64, ctx->stream));
     // stable radix sort by cell id -> keys_b sorted, vals_b = permutation (sorted pos -> original index);
     // run ends of the sorted keys -> cell table (k_cell_tails + exclusive max-scan)
-    if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, nullptr))) return rc;
+    Lane gl = main_lane(ctx);
+    gl.vals_b = &ctx->perm0;                            // the permutation is sorted straight into its final place
+    if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, nullptr, 0, &gl))) return rc;
     const uint32_t nblk = div_up(n, kBlock);
     HIPCHK(ctx->occ_b.ensure((size_t)nblk * 4));
     hipLaunchKernelGGL(k_cell_tails, dim3(nblk), dim3(kBlock), 0, ctx->stream, ctx->keys_b.as<uint32_t>(), n, d_hist,
                        ctx->occ_b.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->occ_b.as<uint32_t>(), nblk,
+                       reinterpret_cast<unsigned long long*>(ctx->mailbox + kMailWord));
     HIPCHK(hipGetLastError());
     size_t tmp_bytes = 0;
     HIPCHK(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), hipcub::Max(), 0u,
@@ -2568,14 +2728,8 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     HIPCHK(hipcub::DeviceScan::ExclusiveScan(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), hipcub::Max(), 0u,
                                              (int)(ncells + 8), ctx->stream));
     HIPCHK(ctx->gold[l].ensure(((size_t)n + 8) * sizeof(float4)));   // + 8 pad entries (level 0)
-    std::vector<uint32_t> ends(nblk);
-    if (l == 0) {
-      HIPCHK(hipMemcpyAsync(ends.data(), ctx->occ_b.p, (size_t)nblk * 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx->perm0.ensure((size_t)n * 4));
-      HIPCHK(hipMemcpyAsync(ctx->perm0.p, ctx->vals_b.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    }
     hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->raw.as<float>(),
-                       (const float*)nullptr, ctx->vals_b.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1],
+                       (const float*)nullptr, ctx->perm0.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1],
                        ctx->origin[2], 1, (const uint32_t*)nullptr, ctx->gold[l].as<float4>());
     HIPCHK(hipGetLastError());
     if (l == 0) {
@@ -2586,12 +2740,7 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
                                      {3e18f, 3e18f, 3e18f, 0.f}, {3e18f, 3e18f, 3e18f, 0.f}};
       HIPCHK(hipMemcpyAsync(ctx->gold[0].as<float4>() + n, kFar, sizeof(kFar), hipMemcpyHostToDevice, ctx->stream));
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));   // hist / sort scratch is reused by the next level
-    if (l == 0) {
-      uint64_t occ_cells = 0;
-      for (uint32_t e : ends) occ_cells += e;
-      ctx->noccupied = occ_cells;
-    }
+    // (no synchronisation here: the number of occupied cells is read from the mailbox after the build's last one)
     L.gold[l] = ctx->gold[l].as<float4>();
     L.cs[l] = ctx->cstart[l].as<uint32_t>();
     L.c[l] = g.c; L.inv_c[l] = g.inv_c;
@@ -2611,21 +2760,24 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   // distance-to-occupied table of level 0: three separable passes, x (from the cell table), y, z
   {
     const uint32_t nc = (uint32_t)ncells0;
-    HIPCHK(ctx->occ_a.ensure(nc));
-    HIPCHK(ctx->occ_b.ensure(nc));
-    hipLaunchKernelGGL(k_occ_x, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->cstart[0].as<uint32_t>(),
+    HIPCHK(ctx->occ_a.ensure((size_t)nc + 16));     // (+ padding: k_occ_axis reads whole 32-bit words)
+    HIPCHK(ctx->occ_b.ensure((size_t)nc + 16));
+    hipLaunchKernelGGL(k_occ_x, dim3(div_up(nc, (uint32_t)kOccXOut)), dim3(kBlock), 0, ctx->stream, ctx->cstart[0].as<uint32_t>(),
                        g0.nx, nc, ctx->occ_a.as<uint8_t>());
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_occ_axis, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->occ_a.as<uint8_t>(),
-                       ctx->occ_b.as<uint8_t>(), nc, (uint32_t)g0.nx, g0.ny);
+    const uint32_t nrows = (uint32_t)g0.ny * (uint32_t)g0.nz, nthreads = nrows * (((uint32_t)g0.nx + 3u) / 4u);
+    hipLaunchKernelGGL(k_occ_axis, dim3(div_up(nthreads, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->occ_a.as<uint8_t>(),
+                       ctx->occ_b.as<uint8_t>(), nrows, (uint32_t)g0.nx, (uint32_t)g0.nx, 1u, g0.ny);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_occ_axis, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->occ_b.as<uint8_t>(),
-                       ctx->occ_a.as<uint8_t>(), nc, (uint32_t)g0.nx * (uint32_t)g0.ny, g0.nz);
+    hipLaunchKernelGGL(k_occ_axis, dim3(div_up(nthreads, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->occ_b.as<uint8_t>(),
+                       ctx->occ_a.as<uint8_t>(), nrows, (uint32_t)g0.nx, (uint32_t)g0.nx * (uint32_t)g0.ny, (uint32_t)g0.ny, g0.nz);
     HIPCHK(hipGetLastError());
     L.occ_dist = ctx->occ_a.as<uint8_t>();
   }
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  MA_PT("gold: build synchronised");
+  ctx->noccupied = *reinterpret_cast<const unsigned long long*>(ctx->mailbox + kMailWord);
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->build_ms = ms;
@@ -2697,40 +2849,43 @@ static int set_pair_impl(ma_ctx* ctx, const void* gold_xyz, uint64_t m, float ce
   HIPCHK(ctx->akeys_a.ensure((size_t)n * 4));
   HIPCHK(ctx->akeys_b.ensure((size_t)n * 4));
   HIPCHK(ctx->avals_a.ensure((size_t)n * 4));
-  HIPCHK(ctx->avals_b.ensure((size_t)n * 4));
   HIPCHK(ctx->amisc.ensure(1024 * 8 * sizeof(float)));
   HIPCHK(ctx->src.ensure((size_t)n * sizeof(float4)));
   HIPCHK(ctx->src_perm.ensure((size_t)n * 4));
   if (weights) HIPCHK(ctx->wts.ensure((size_t)n * 4));
   {
     size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->akeys_a.as<uint32_t>(), ctx->akeys_b.as<uint32_t>(),
-                                              ctx->avals_a.as<uint32_t>(), ctx->avals_b.as<uint32_t>(), (int)n, 0, 32, ctx->aux_stream));
+    HIPCHK(sort_pairs_u32(nullptr, tmp_bytes, ctx->akeys_a.as<uint32_t>(), ctx->akeys_b.as<uint32_t>(), ctx->avals_a.as<uint32_t>(),
+                          ctx->src_perm.as<uint32_t>(), n, 32, ctx->aux_stream));
     HIPCHK(ctx->acub_tmp.ensure(tmp_bytes));
   }
+  MA_PT("set_pair: buffers sized");
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   double shift[3] = {0.0, 0.0, 0.0};
-  if (f64) {          // upload, fp64 bounds and the large-coordinate shift of the gold map, conversion to the fp32 frame
-    int rc = stage_f64(ctx, static_cast<const double*>(gold_xyz), mg, true, shift);
-    if (rc) return rc;
-    for (int a = 0; a < 3; ++a) shift_out[a] = shift[a];
-  } else {
-    HIPCHK(hipMemcpyAsync(ctx->raw.p, gold_xyz, (size_t)mg * 12, hipMemcpyDefault, ctx->stream));
-  }
   ma_ctx::PairHandoff handoff;
   struct HandoffScope {       // the context points at a stack object: detached again on EVERY way out, a throwing std::thread included
     ma_ctx* ctx;
     explicit HandoffScope(ma_ctx* c, ma_ctx::PairHandoff* h) : ctx(c) { ctx->pair_handoff = h; }
     ~HandoffScope() { ctx->pair_handoff = nullptr; }
   } handoff_scope(ctx, &handoff);
+  // The helper is started FIRST (creating a thread and its first HIP call take 60-100 us) and then waits for the
+  // gold map's upload call to return before it issues its own: the two uploads share one PCIe link, and the gold
+  // map's build is the longer chain, so its 12 MB go first and undisturbed.
+  std::atomic<int> gold_uploaded{0};      // 0: wait, 1: go (shift[] is final), 2: give up
   int rc_src = MA_OK;
   std::thread helper([&]() {
     try {
+      MA_PT("scan: helper thread runs");
       hipError_t e = hipSetDevice(ctx->device);
+      MA_PT("scan: hipSetDevice returned");
+      int go;
+      while ((go = gold_uploaded.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+      if (go != 1) return;
       void* dst = f64 ? ctx->raw64_src.p : ctx->raw_src.p;
       if (e == hipSuccess) e = hipMemcpyAsync(dst, src_xyz, (size_t)n * in_bytes, hipMemcpyDefault, ctx->aux_stream);
+      MA_PT("scan: upload call returned");
       if (e != hipSuccess) { rc_src = ctx->fail(MA_ERR_HIP, std::string("upload of the source cloud: ") + hipGetErrorString(e)); return; }
-      if (f64) {      // the shift is final before the helper starts: convert behind the upload, on the aux stream
+      if (f64) {      // convert behind the upload, on the aux stream, with the gold map's shift
         const uint64_t n3 = 3ull * n;
         hipLaunchKernelGGL(k_f64_to_raw, dim3((uint32_t)((n3 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->aux_stream,
                            ctx->raw64_src.as<double>(), n3, shift[0], shift[1], shift[2], ctx->raw_src.as<float>());
@@ -2743,6 +2898,7 @@ static int set_pair_impl(ma_ctx* ctx, const void* gold_xyz, uint64_t m, float ce
         if (handoff.state != 1) return;            // the gold build failed before it chose a cell edge
         cell_edge = handoff.cell;
       }
+      MA_PT("scan: cell edge received");
       const Lane aux = aux_lane(ctx);
       rc_src = build_source_from_raw(ctx, n, weights, ctx->raw_src.as<float>(), cell_edge, &aux);
     } catch (const std::bad_alloc&) {
@@ -2753,18 +2909,35 @@ static int set_pair_impl(ma_ctx* ctx, const void* gold_xyz, uint64_t m, float ce
   });
   struct Joiner {             // whatever ends the build below — a status or an exception — the helper is released and joined
     std::thread& t;
-    ma_ctx* ctx;
+    std::atomic<int>& uploaded;
     ma_ctx::PairHandoff& h;
     ~Joiner() {
+      int expected = 0;
+      uploaded.compare_exchange_strong(expected, 2);     // (no effect once the upload has said "go")
       h.set(2, 0.f);          // (no effect once the build has said "go")
       if (t.joinable()) t.join();
     }
   };
   int rc_gold;
   {
-    Joiner joiner{helper, ctx, handoff};
-    rc_gold = build_gold_from_raw(ctx, mg, cell);
+    Joiner joiner{helper, gold_uploaded, handoff};
+    rc_gold = [&]() -> int {
+      if (f64) {          // upload, fp64 bounds and the large-coordinate shift of the gold map, conversion to the fp32 frame
+        int rc = stage_f64(ctx, static_cast<const double*>(gold_xyz), mg, true, shift);
+        if (rc) return rc;
+        for (int a = 0; a < 3; ++a) shift_out[a] = shift[a];
+      } else {
+        HIPCHK(hipMemcpyAsync(ctx->raw.p, gold_xyz, (size_t)mg * 12, hipMemcpyDefault, ctx->stream));
+      }
+      MA_PT("gold: upload call returned");
+      gold_uploaded.store(1, std::memory_order_release);
+      return build_gold_from_raw(ctx, mg, cell);
+    }();
   }
+  MA_PT("set_pair: helper joined");
+#if MA_PAIR_TIMES
+  pt_dump();
+#endif
   if (rc_gold || rc_src) {
     ctx->have_src = false;
     if (rc_gold) ctx->have_gold = false;
@@ -2806,28 +2979,31 @@ static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, 
     hipLaunchKernelGGL(k_count_bad_weights, dim3(std::min<uint32_t>(div_up(n, kBlock), 1024)), dim3(kBlock), 0,
                        L.stream, d_w, n, L.misc->as<unsigned long long>());
     HIPCHK(hipGetLastError());
-    unsigned long long bad = 0;
-    HIPCHK(hipMemcpyAsync(&bad, L.misc->p, 8, hipMemcpyDeviceToHost, L.stream));
+    unsigned long long* bad = reinterpret_cast<unsigned long long*>(L.mail + kMailWord + 64);
+    HIPCHK(hipMemcpyAsync(bad, L.misc->p, 8, hipMemcpyDeviceToHost, L.stream));     // into pinned memory
     HIPCHK(hipStreamSynchronize(L.stream));
-    if (bad) return ctx->fail(MA_ERR_INVALID, "weights must be finite and >= 0");
+    if (*bad) return ctx->fail(MA_ERR_INVALID, "weights must be finite and >= 0");
   }
   float lo[3], hi[3];
   int rc = cloud_bounds(ctx, d_raw, n, lo, hi, 3, false, &L);
   if (rc) return rc;
+  MA_PT("scan: bounds read");
   // sort in the cloud's own frame with the gold map's cell edge (coarsened to fit 2^27
   // cells), brick-major: 256 consecutive points then form a compact patch, so that a
   // workgroup's queries share one small block of the gold grid under any rigid motion.
   const float c = clamp_cell_to_budget(lo, hi, gold_cell, kMaxCells);
   const GridP g = make_grid(lo, hi, ctx->origin, c);
-  if ((rc = sort_by_cell(ctx, d_raw, n, g, ctx->origin, nullptr, /*brick=*/1, &L))) return rc;
   HIPCHK(ctx->src.ensure((size_t)n * sizeof(float4)));
   HIPCHK(ctx->src_perm.ensure((size_t)n * 4));
-  HIPCHK(hipMemcpyAsync(ctx->src_perm.p, L.vals_b->p, (size_t)n * 4, hipMemcpyDeviceToDevice, L.stream));
+  Lane sl = L;
+  sl.vals_b = &ctx->src_perm;                           // the permutation is sorted straight into its final place
+  if ((rc = sort_by_cell(ctx, d_raw, n, g, ctx->origin, nullptr, /*brick=*/1, &sl))) return rc;
   hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, L.stream, d_raw, d_w,
                      ctx->src_perm.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1], ctx->origin[2], 0,
                      (const uint32_t*)nullptr, ctx->src.as<float4>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(L.stream));
+  MA_PT("scan: build synchronised");
   ctx->n = n;
   ctx->n_pts = n;
   ctx->src_sorted = true;
@@ -2845,11 +3021,10 @@ static int stage_f64(ma_ctx* ctx, const double* xyz, uint32_t n, bool choose_shi
   HIPCHK(hipMemcpyAsync(ctx->raw64.p, xyz, (size_t)n * 24, hipMemcpyDefault, ctx->stream));
   if (choose_shift) {
     const int nb = std::min<uint32_t>(div_up(n, kBlock), 1024);
-    HIPCHK(ctx->misc.ensure((size_t)nb * 8 * sizeof(double)));
-    hipLaunchKernelGGL(k_minmax_f64, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->raw64.as<double>(), n, ctx->misc.as<double>());
+    static_assert(1024 * 8 * sizeof(double) <= kMailProbe, "bounds region of the mailbox");
+    double* h = reinterpret_cast<double*>(ctx->mailbox);      // [nb][8], written by the kernel
+    hipLaunchKernelGGL(k_minmax_f64, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->raw64.as<double>(), n, h);
     HIPCHK(hipGetLastError());
-    std::vector<double> h((size_t)nb * 8);
-    HIPCHK(hipMemcpyAsync(h.data(), ctx->misc.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, bad = 0;
     for (int b = 0; b < nb; ++b) {

@@ -191,6 +191,30 @@ def test_nn_fuzz_shapes_sizes_gates_cells(engine):
         assert_nn_exact_on_stored(engine, T, gate, idx, d2)        # exact on the stored coordinates, every case
 
 
+def test_nn_gated_queries_in_a_sparse_grid(engine):
+    """The distance-to-occupied table (one byte per cell, three separable passes) dismisses gated queries that have
+    nothing within reach: a few small clusters in a big, mostly empty box (grids with nx not a multiple of 4, one
+    flat axis, one cell thick), queries all over the box, gates from 1.5 to 9 cells.  A table entry that is too
+    large would dismiss a query that has a neighbour inside the gate: every result is checked against brute force."""
+    rng = np.random.default_rng(2024)
+    for case, (ext, cell) in enumerate([((4.0, 3.1, 2.3), 0.1), ((5.0, 0.05, 3.0), 0.07), ((1.3, 2.9, 0.02), 0.05),
+                                        ((6.0, 6.0, 6.0), 0.25), ((0.9, 0.9, 0.9), 0.3)]):
+        ext = np.asarray(ext)
+        centres = rng.uniform(-0.5, 0.5, size=(12, 3)) * ext
+        gold = (centres[rng.integers(0, 12, size=600)] + rng.normal(0, 0.3 * cell, size=(600, 3))).astype(np.float32)
+        gold = np.clip(gold, -0.5 * ext, 0.5 * ext).astype(np.float32)
+        gold[:8] = (np.array([[sx, sy, sz] for sx in (-.5, .5) for sy in (-.5, .5) for sz in (-.5, .5)]) * ext).astype(np.float32)  # corners span the box
+        comp = (rng.uniform(-0.5, 0.5, size=(5000, 3)) * ext).astype(np.float32)
+        engine.set_gold(gold, cell)
+        engine.set_source(comp)
+        oidx, od2 = orc.nn_bruteforce(gold, comp.astype(np.float64))
+        for cells_wide in (1.5, 2.5, 4.0, 6.5, 9.0):
+            gate = cells_wide * cell
+            idx, d2 = engine.nn(None, gate)
+            assert_nn_matches(idx, d2, oidx, od2, gate=gate)
+            assert_nn_exact_on_stored(engine, np.eye(4), gate, idx, d2)
+
+
 # ----------------------------------------------------------------------------- rows a4-a6
 @pytest.mark.parametrize("gate", [0.10, 0.35, np.inf])
 def test_one_iteration_accumulators_and_solve(engine, gate):
