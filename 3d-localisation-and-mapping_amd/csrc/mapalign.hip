@@ -304,6 +304,129 @@ __global__ __launch_bounds__(kBlock) void k_count_marks(uint4* __restrict__ mark
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Stable LSD radix sort of (cell key, index) pairs for clouds of up to a few million points
+// ---------------------------------------------------------------------------------------
+// The library sorts (rocPRIM behind hipCUB) are built for large inputs: below 2^20 items a merge sort of 21 launches
+// (150-190 us for the 1M-point benchmark cloud), above it Onesweep, whose passes are chained workgroup to workgroup by
+// decoupled look-back — 26-29 us per pass at 1M points, where the chain's latency, not bandwidth, sets the time
+// (`profiles/r03_variants_ab.txt`, staging).  With a few hundred workgroups the classic three-kernel pass is faster:
+//   k_sort_hist     every workgroup counts the digits of its tile (2048 keys) -> hist[digit][workgroup]
+//   k_sort_rows     one WAVEFRONT per digit: exclusive prefix along its row of workgroups, and the digit's total
+//   k_sort_scatter  every workgroup: digit starts from the 256 totals (LDS scan), stable rank of every key inside the
+//                   tile (match-by-ballot per wavefront, wavefront bases from LDS), and the scatter
+// 8-bit digits, ceil(bits / 8) passes, no atomics on global memory, no spinning.  Stable: the order inside a tile is
+// wavefront-major, then item, then lane — which is also its order in memory.
+constexpr int kSortItems = 8;                         // keys per thread
+constexpr int kSortTile = kBlock * kSortItems;        // keys per workgroup
+constexpr int kSortBins = 256;
+static_assert(kSortBins == kBlock, "one thread per digit in the base computation");
+
+__global__ __launch_bounds__(kBlock) void k_sort_hist(const uint32_t* __restrict__ keys, const uint32_t n, const int shift,
+                                                      const uint32_t nblocks, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[kSortBins];
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * (uint32_t)kSortTile;
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const uint32_t i = base + (uint32_t)j * kBlock + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (kSortBins - 1)], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void k_sort_rows(uint32_t* __restrict__ hist, const uint32_t nblocks,
+                                                      uint32_t* __restrict__ totals) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t bin = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  uint32_t* __restrict__ row = hist + (size_t)bin * nblocks;
+  uint32_t run = 0u;
+  for (uint32_t c0 = 0; c0 < nblocks; c0 += kWave) {
+    const uint32_t i = c0 + (uint32_t)lane;
+    const uint32_t v = i < nblocks ? row[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const uint32_t u = __shfl_up(incl, off, kWave);
+      if (lane >= off) incl += u;
+    }
+    if (i < nblocks) row[i] = run + incl - v;
+    run += __shfl(incl, kWave - 1, kWave);
+  }
+  if (lane == 0) totals[bin] = run;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                         const uint32_t n, const int shift, const uint32_t nblocks,
+                                                         const uint32_t* __restrict__ row_prefix, const uint32_t* __restrict__ totals,
+                                                         uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+  constexpr int kNW = kBlock / kWave;
+  __shared__ uint32_t cnt[kNW][kSortBins];      // per-wavefront digit counts, then per-wavefront output bases
+  __shared__ uint32_t wave_tot[kNW];
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+#pragma unroll
+  for (int k = 0; k < kNW; ++k) cnt[k][threadIdx.x] = 0u;
+  // digit starts: exclusive scan of the 256 totals (thread = digit)
+  const uint32_t tot = totals[threadIdx.x];
+  uint32_t incl = tot;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const uint32_t u = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += u;
+  }
+  if (lane == kWave - 1) wave_tot[w] = incl;
+  __syncthreads();
+  uint32_t digit_start = incl - tot;
+  for (int k = 0; k < w; ++k) digit_start += wave_tot[k];
+
+  // stable ranks inside the wavefront's segment of the tile
+  const uint32_t seg = blockIdx.x * (uint32_t)kSortTile + (uint32_t)w * (uint32_t)(kWave * kSortItems);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t key[kSortItems], rank[kSortItems];
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const uint32_t i = seg + (uint32_t)j * kWave + (uint32_t)lane;
+    const bool valid = i < n;
+    key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
+    const uint32_t d = (key[j] >> shift) & (kSortBins - 1);
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    uint32_t prior = 0u;
+    if (valid) prior = cnt[w][d];
+    __builtin_amdgcn_wave_barrier();            // every lane has read the count before the group's last lane replaces it
+    rank[j] = prior + (uint32_t)__popcll(peers & lt);
+    if (valid && (peers >> lane) == 1ull) cnt[w][d] = prior + (uint32_t)__popcll(peers);    // highest lane of the group
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {   // thread = digit: where each wavefront's keys of this digit go
+    uint32_t run = digit_start + row_prefix[(size_t)threadIdx.x * nblocks + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kNW; ++k) {
+      const uint32_t c = cnt[k][threadIdx.x];
+      cnt[k][threadIdx.x] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    const uint32_t i = seg + (uint32_t)j * kWave + (uint32_t)lane;
+    if (i < n) {
+      const uint32_t pos = cnt[w][(key[j] >> shift) & (kSortBins - 1)] + rank[j];
+      keys_out[pos] = key[j];
+      vals_out[pos] = vals_in[i];
+    }
+  }
+}
+
 // Coarser levels are built on demand from the level-0 copy (already centred, float4):
 // cell ids of level l (+ histogram), and the gather that keeps .w = position in level 0.
 __global__ __launch_bounds__(kBlock) void k_cell_keys4(const float4* __restrict__ pts, uint32_t n, GridP g,
@@ -2130,19 +2253,43 @@ int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float
   return MA_OK;
 }
 
-// Stable radix sort of (cell key, index) pairs.  hipCUB forwards to rocPRIM with its default configuration, which
-// sorts up to 2^20 items by MERGE sort (block sort + 10 merge passes: 21 launches of 6-9 us for the 1M-point
-// benchmark cloud, 150-190 us) and only larger inputs by Onesweep (one histogram + one pass per 8 key bits).  The
-// same library call with the merge-sort limit lowered to 64K items takes the Onesweep path from there on.
-#ifndef MA_MERGE_SORT_LIMIT
-#define MA_MERGE_SORT_LIMIT 65536
-#endif
+// Stable radix sort of (cell key, index) pairs: the three-kernel passes above for clouds of up to kSortMaxN points,
+// rocPRIM's Onesweep (one look-back-chained launch per 8 key bits; the library's choice above 2^20 items anyway)
+// beyond.  Two-call pattern of the library: tmp == nullptr asks for the temporary bytes.  The inputs are left intact.
+constexpr uint32_t kSortMaxN = 4u << 20;
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config,
-                                              (size_t)MA_MERGE_SORT_LIMIT>;
+                                              (size_t)65536>;
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 hipError_t sort_pairs_u32(void* tmp, size_t& tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
                           uint32_t* vals_out, uint32_t n, int bits, hipStream_t stream) {
-  return rocprim::radix_sort_pairs<SortConfig>(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                               (unsigned)bits, stream);
+  if (n > kSortMaxN)
+    return rocprim::radix_sort_pairs<SortConfig>(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                                 (unsigned)bits, stream);
+  const uint32_t nblocks = div_up(n, (uint32_t)kSortTile);
+  const size_t pair_bytes = align256((size_t)n * 4), hist_bytes = align256((size_t)kSortBins * nblocks * 4);
+  const size_t need = 2 * pair_bytes + hist_bytes + align256(kSortBins * 4);
+  if (!tmp) { tmp_bytes = need; return hipSuccess; }
+  if (tmp_bytes < need) return hipErrorInvalidValue;
+  char* base = static_cast<char*>(tmp);
+  uint32_t* t_keys = reinterpret_cast<uint32_t*>(base);
+  uint32_t* t_vals = reinterpret_cast<uint32_t*>(base + pair_bytes);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(base + 2 * pair_bytes);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(base + 2 * pair_bytes + hist_bytes);
+  const int passes = std::max(1, (bits + 7) / 8);
+  const uint32_t* src_k = keys_in;
+  const uint32_t* src_v = vals_in;
+  for (int p = 0; p < passes; ++p) {
+    const bool to_out = ((passes - 1 - p) & 1) == 0;       // the last pass writes the caller's output; alternate backwards from there
+    uint32_t* dst_k = to_out ? keys_out : t_keys;
+    uint32_t* dst_v = to_out ? vals_out : t_vals;
+    hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(kBlock), 0, stream, src_k, n, 8 * p, nblocks, hist);
+    hipLaunchKernelGGL(k_sort_rows, dim3(kSortBins / (kBlock / kWave)), dim3(kBlock), 0, stream, hist, nblocks, totals);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(kBlock), 0, stream, src_k, src_v, n, 8 * p, nblocks,
+                       (const uint32_t*)hist, (const uint32_t*)totals, dst_k, dst_v);
+    src_k = dst_k;
+    src_v = dst_v;
+  }
+  return hipGetLastError();
 }
 
 // keys/vals for `n` raw points + optional histogram; then a stable radix sort by cell id.
