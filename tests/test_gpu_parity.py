@@ -191,6 +191,26 @@ def test_nn_fuzz_shapes_sizes_gates_cells(engine):
         assert_nn_exact_on_stored(engine, T, gate, idx, d2)        # exact on the stored coordinates, every case
 
 
+@pytest.mark.parametrize("cell", [50.0, 0.3, 0.02])
+def test_exact_duplicates_resolve_to_the_smallest_index_at_every_size(engine, cell):
+    """Equal distances resolve to the smaller position of the cell-sorted gold array, and the cell sort is STABLE, so
+    among exact duplicates the caller's smallest index wins — as in the oracle's first-minimum rule.  Sizes around
+    the tile of the radix sort (2048 keys per workgroup), one cell for everything (every key equal: the sort must be
+    the identity), a few cells, many cells."""
+    rng = np.random.default_rng(5)
+    for n_unique in (1, 683, 1365, 1366, 2048, 23456):
+        base = rng.uniform(-1, 1, size=(n_unique, 3)).astype(np.float32)
+        order = np.concatenate([rng.permutation(n_unique) for _ in range(3)])     # every point three times
+        gold = base[order]
+        first = np.full(n_unique, len(gold), dtype=np.int64)
+        np.minimum.at(first, order, np.arange(len(gold)))
+        engine.set_gold(gold, cell)
+        engine.set_source(base)
+        idx, d2 = engine.nn(None, np.inf)
+        assert (d2 == 0).all()
+        assert (idx.astype(np.int64) == first).all()
+
+
 def test_nn_gated_queries_in_a_sparse_grid(engine):
     """The distance-to-occupied table (one byte per cell, three separable passes) dismisses gated queries that have
     nothing within reach: a few small clusters in a big, mostly empty box (grids with nx not a multiple of 4, one
