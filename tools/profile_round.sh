@@ -8,10 +8,12 @@
 #   pmc_traffic.json                   HBM-side bytes of k_nn_accum per launch (separate --pmc passes), stamped
 #                                      with the kernel-source hash bench.py checks
 #   <tag>_pmc_k_nn_accum.txt           SQ / TA / TCP / TCC counters per launch (separate --pmc passes)
+#   <tag>_set_pair_timeline_now.txt    kernels and copies of one warm ma_set_pair in time order (+ host time stamps of both
+#                                      threads if lib/libmapalign_pt.so, the -DMA_PAIR_TIMES=1 build, is there)
 # PMC passes are never combined with trace options; every rocprofv3 runs `python3 <script>` directly.
 set -u
 TAG=${1:-r02}
-STEPS=${2:-12345}      # which of the five steps to run, e.g. 123 or 45
+STEPS=${2:-123456}     # which of the six steps to run, e.g. 123 or 45
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -53,6 +55,19 @@ if [[ $STEPS == *5* ]]; then
 echo "[5/5] SQ / TA / TCP / TCC counters"
 bash $R/tools/pmc_collect.sh pmc_$TAG 0.0 > $R/gpurun_out/pmc_collect.log 2>&1
 python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_$TAG $OUT/${TAG}_pmc_k_nn_accum.txt > /dev/null 2>&1 || echo "pmc summary failed"
+fi
+
+if [[ $STEPS == *6* ]]; then
+echo "[6] one warm ma_set_pair in time order"
+rm -rf $R/gpurun_out/prof_pair
+timeout -k 10 200 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/prof_pair -- python3 $R/tools/pair_prof.py > $R/gpurun_out/prof_pair.log 2>&1 \
+  || echo "pair_prof under rocprof failed"
+python3 $R/tools/pair_timeline.py $R/gpurun_out/prof_pair > $OUT/${TAG}_set_pair_timeline_now.txt
+PT=$R/3d-localisation-and-mapping_amd/lib/libmapalign_pt.so
+if [ -f $PT ]; then
+  MAPALIGN_LIB=$PT timeout -k 10 120 python3 $R/tools/pair_host_times.py 2> $R/gpurun_out/pair_host_times.txt
+  { echo; echo "## host time stamps of both threads, no profiler (tools/pair_host_times.py, -DMA_PAIR_TIMES=1 build)"; tail -14 $R/gpurun_out/pair_host_times.txt; } >> $OUT/${TAG}_set_pair_timeline_now.txt
+fi
 fi
 
 ls -la $OUT
