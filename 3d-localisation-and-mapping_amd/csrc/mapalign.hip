@@ -498,6 +498,37 @@ __global__ __launch_bounds__(kBlock) void k_sum_u32(const uint32_t* __restrict__
   }
 }
 
+// First and second moments of a stored cloud (centred float4; holes skipped): per workgroup {count, x, y, z, xx, xy,
+// xz, yy, yz, zz} in fp64, written to the pinned mailbox; the host adds the rows.  What the coarse stage's principal
+// axes need (N1) — 30 us on the device against 5-6 ms per million points for the same sums in NumPy.
+constexpr int kMomLen = 10;
+constexpr uint32_t kMomBlocks = 256;
+__global__ __launch_bounds__(kBlock) void k_moments(const float4* __restrict__ pts, const uint32_t n, double* __restrict__ out) {
+  double a[kMomLen];
+#pragma unroll
+  for (int k = 0; k < kMomLen; ++k) a[k] = 0.0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 p = pts[i];
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) continue;
+    const double x = p.x, y = p.y, z = p.z;
+    a[0] += 1.0; a[1] += x; a[2] += y; a[3] += z;
+    a[4] += x * x; a[5] += x * y; a[6] += x * z; a[7] += y * y; a[8] += y * z; a[9] += z * z;
+  }
+  __shared__ double part[kBlock / kWave][kMomLen];
+#pragma unroll
+  for (int k = 0; k < kMomLen; ++k) {
+    const double v = wave_sum(a[k]);
+    if ((threadIdx.x & (kWave - 1)) == kWave - 1) part[threadIdx.x / kWave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kMomLen) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) v += part[w][threadIdx.x];
+    out[(size_t)blockIdx.x * kMomLen + threadIdx.x] = v;
+  }
+}
+
 // number of weights that are not finite and >= 0 (one integer atomic per workgroup)
 __global__ __launch_bounds__(kBlock) void k_count_bad_weights(const float* __restrict__ w, uint32_t n,
                                                               unsigned long long* __restrict__ out) {
@@ -3643,6 +3674,34 @@ int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16], dou
   if (acc_out) acc_to_world(a, ctx->origin, acc_out);
   if (T_out) centred_to_world(s, ctx->origin, T_out);
   if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "no correspondence inside max_corr_dist, or rank-deficient covariance (fewer than 3 non-collinear pairs)");
+  return MA_OK;
+  });
+}
+
+int ma_cloud_moments(ma_ctx* ctx, int which, double out[13]) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx || !out) return MA_ERR_INVALID;
+  if (which != 0 && which != 1) return ctx->fail(MA_ERR_INVALID, "which: 0 = gold map, 1 = source cloud");
+  if (which == 0 ? !ctx->have_gold : !ctx->have_src) return ctx->fail(MA_ERR_STATE, which == 0 ? "gold map not set" : "source cloud not set");
+  HIPCHK(hipSetDevice(ctx->device));
+  const float4* pts = which == 0 ? ctx->gold[0].as<float4>() : ctx->src.as<float4>();
+  const uint32_t n = which == 0 ? ctx->m : ctx->n;
+  const uint32_t nb = std::min<uint32_t>(div_up(n, kBlock), kMomBlocks);
+  static_assert(kMomBlocks * kMomLen * sizeof(double) <= kMailProbe, "bounds region of the mailbox");
+  double* rows = reinterpret_cast<double*>(ctx->mailbox);
+  hipLaunchKernelGGL(k_moments, dim3(nb), dim3(kBlock), 0, ctx->stream, pts, n, rows);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double a[kMomLen] = {0};
+  for (uint32_t b = 0; b < nb; ++b)
+    for (int k = 0; k < kMomLen; ++k) a[k] += rows[(size_t)b * kMomLen + k];
+  if (!(a[0] >= 1.0)) return ctx->fail(MA_ERR_EMPTY, "the cloud holds no valid point");
+  const double cnt = a[0], mx = a[1] / cnt, my = a[2] / cnt, mz = a[3] / cnt, den = cnt > 1.0 ? cnt - 1.0 : 1.0;
+  out[0] = cnt;
+  out[1] = ctx->origin[0] + mx; out[2] = ctx->origin[1] + my; out[3] = ctx->origin[2] + mz;
+  const double cxx = (a[4] - cnt * mx * mx) / den, cxy = (a[5] - cnt * mx * my) / den, cxz = (a[6] - cnt * mx * mz) / den;
+  const double cyy = (a[7] - cnt * my * my) / den, cyz = (a[8] - cnt * my * mz) / den, czz = (a[9] - cnt * mz * mz) / den;
+  out[4] = cxx; out[5] = cxy; out[6] = cxz; out[7] = cxy; out[8] = cyy; out[9] = cyz; out[10] = cxz; out[11] = cyz; out[12] = czz;
   return MA_OK;
   });
 }

@@ -74,13 +74,12 @@ class Alignment:
         """Staged alignment of two point arrays -> (transformations list, composed 4x4, info)."""
         eng, lock = cached_engine(self.device)     # one context per device for the process: warm buffers
         with lock:
-            eng.set_gold(gold_cloud)
+            eng.set_pair(gold_cloud, comparison_cloud)     # both clouds staged at once (the scan beside the gold build)
             stages, T0, info = [], np.eye(4), {}
-            if self.coarse_stage:
+            if self.coarse_stage:                          # frames and scores from the device-resident clouds
                 stages, T0, info = coarse.coarse_align(eng, gold_cloud, comparison_cloud,
                                                        base_pose_df=self.base_pose_df,
-                                                       comparison_pose_df=self.comparison_pose_df)
-            eng.set_source(comparison_cloud)
+                                                       comparison_pose_df=self.comparison_pose_df, resident=True)
             T, gpu_ms, widened = T0, 0.0, []
             for gate, iters in self.gate_schedule:          # wide gates first: pulls a rough start into the final gate's basin
                 try:
@@ -101,10 +100,12 @@ class Alignment:
     def compare(self, data_folder):
         if self.base_map_filepath is None or self.comparison_map_filepath is None:
             self.base_map_filepath, self.comparison_map_filepath = self.map_resolver(data_folder)
-        # both files at once (NumPy's file reads release the interpreter lock): NaN / inf removed, as mapping.py:63-68
+        # both files at once (NumPy's file reads release the interpreter lock): NaN / inf removed, as mapping.py:63-68;
+        # coordinates in the files' own type (float32 from RTAB-Map: a view of the bytes read, no conversion pass)
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=2) as pool:
-            fg, fc = pool.submit(ply.read_ply, self.base_map_filepath), pool.submit(ply.read_ply, self.comparison_map_filepath)
+            fg = pool.submit(ply.read_ply, self.base_map_filepath, dtype=None)
+            fc = pool.submit(ply.read_ply, self.comparison_map_filepath, dtype=None)
             gold, comp = fg.result(), fc.result()
         self.transformations, T, info = self.align_clouds(gold, comp)
         aligned = boxes.transform_bboxes(self.comparison_bboxes, T)

@@ -33,6 +33,8 @@ from . import transforms
 
 PCA_MAX_POINTS = 1 << 18
 BLAS_THREADS = 8
+NARROW_CELLS = 5.5      # first scoring bound, in cells of the gold grid (inside the engine's ring walk and distance table)
+DECISIVE = 0.6          # the narrow scores decide if the best is below this fraction of the runner-up
 
 _blas_controller = None
 
@@ -87,6 +89,17 @@ def _principal_frame(points, max_points):
     return c, axes, w[order]
 
 
+def frame_from_moments(centroid, cov):
+    """(centroid, axes, variances) as ``principal_frame`` from a centroid and a 3x3 covariance
+    (``MapAligner.cloud_moments``: the sums taken on the device over the whole stored cloud)."""
+    w, v = np.linalg.eigh(np.asarray(cov, dtype=np.float64))
+    order = np.argsort(w)[::-1]
+    axes = v[:, order]
+    if np.linalg.det(axes) < 0:
+        axes[:, 2] = -axes[:, 2]
+    return np.asarray(centroid, dtype=np.float64), axes, w[order]
+
+
 def candidate_rotations(axes_gold, axes_comp):
     """The four proper rotations taking the comparison principal frame onto the gold one."""
     out = []
@@ -138,8 +151,15 @@ def trajectory_residual(T, base_traj, comp_traj, n=64):
 
 
 def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0, base_pose_df=None,
-                 comparison_pose_df=None, truncate=None):
+                 comparison_pose_df=None, truncate=None, resident=False):
     """Returns (stages, T_coarse, info); ``engine`` is a MapAligner with the gold map set.
+
+    ``resident=True``: the engine already holds BOTH clouds (``set_pair``), and it still does when this returns.
+    Then nothing of the stage walks the clouds on the host: the principal frames come from the device's moment
+    sums over the whole stored clouds (``cloud_moments``; 30 us each against 5-6 ms per million points in NumPy),
+    and the narrow-bound score of a candidate is one search + accumulate launch over the whole comparison cloud
+    (``truncated_rms``: the sums come back, not a distance per point).  Only an undecided narrow round falls back
+    to the sub-sample and the wide bound, and puts the full comparison cloud back afterwards.
 
     ``stages`` = [(R, centre), T_translate] in the reference's mixed format.  With both
     trajectories given, each candidate's score is ``sqrt(cloud_rms^2 + trajectory_rms^2)``.
@@ -154,37 +174,64 @@ def coarse_align(engine, gold_cloud, comparison_cloud, sample=20000, seed=0, bas
     """
     gold = np.asarray(gold_cloud)
     comp = np.asarray(comparison_cloud)
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=2) as pool:              # the two frames side by side (NumPy releases the interpreter lock)
-        fg, fc = pool.submit(principal_frame, gold), pool.submit(principal_frame, comp)
-        (cg, ag, _), (cc, ac, _) = fg.result(), fc.result()
-    rng = np.random.default_rng(seed)
-    sub = comp if len(comp) <= sample else comp[rng.choice(len(comp), sample, replace=False)]
+    if resident:
+        (_, cg, Cg), (_, cc, Cc) = engine.cloud_moments(0), engine.cloud_moments(1)
+        (cg, ag, _), (cc, ac, _) = frame_from_moments(cg, Cg), frame_from_moments(cc, Cc)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=2) as pool:          # the two frames side by side (NumPy releases the interpreter lock)
+            fg, fc = pool.submit(principal_frame, gold), pool.submit(principal_frame, comp)
+            (cg, ag, _), (cc, ac, _) = fg.result(), fc.result()
+
+    def subsample():
+        rng = np.random.default_rng(seed)
+        return comp if len(comp) <= sample else comp[rng.choice(len(comp), sample, replace=False)]
     base_traj, comp_traj = trajectory_xyz(base_pose_df), trajectory_xyz(comparison_pose_df)
     use_traj = base_traj is not None and comp_traj is not None
     cands = candidate_rotations(ag, ac)
+    gi = engine.grid_info()                                      # the gold map's box, as the engine gridded it
     if truncate is None:
-        gi = engine.grid_info()                                  # the gold map's box, as the engine gridded it
         truncate = 0.05 * float(np.linalg.norm(np.asarray(gi["dims"], dtype=np.float64) * gi["cell"]))
     truncate = max(float(truncate), 1e-6)
     Ts = [transforms.rt_to_matrix(np.eye(3), cg - cc) @ transforms.rotation_about_centre(R, cc) for R in cands]
     traj_scores = [trajectory_residual(T, base_traj, comp_traj) if use_traj else 0.0 for T in Ts]
 
-    def cloud_score(k):
-        _, d2 = engine.nn(Ts[k], max_corr_dist=truncate)        # inf where nothing lies within the bound
-        return float(np.sqrt(np.mean(np.minimum(d2.astype(np.float64), truncate * truncate))))
+    def cloud_score(k, bound, sums_only):
+        if sums_only:
+            return engine.truncated_rms(Ts[k], bound)
+        _, d2 = engine.nn(Ts[k], max_corr_dist=bound)           # inf where nothing lies within the bound
+        return float(np.sqrt(np.mean(np.minimum(d2.astype(np.float64), bound * bound))))
 
-    # (one round over the whole sample: a wrong candidate costs 3-4 ms whether 2 000 or 20 000 points are scored —
-    # its points lie decimetres to metres from the map and each walks hundreds of grid rows, a chain of dependent
-    # reads per wavefront that does not get shorter with fewer wavefronts; a cheaper first round on a tenth of the
-    # sample was measured and saved nothing, `tools/coarse_times.py`)
-    engine.set_source(np.ascontiguousarray(sub))       # dtype kept: fp64 georeferenced coordinates are shifted before they become fp32
-    cloud_scores = [cloud_score(k) for k in range(len(cands))]
-    scores = [float(np.hypot(cloud_scores[k], traj_scores[k])) for k in range(len(cands))]
+    def all_scores(bound, sums_only=False):
+        cs = [cloud_score(k, bound, sums_only) for k in range(len(cands))]
+        return cs, [float(np.hypot(cs[k], traj_scores[k])) for k in range(len(cands))]
+
+    # A wrong candidate is what costs: its points lie decimetres to metres from the map, and an exact search
+    # bounded at `truncate` (1 m for a 20 m carriage) walks hundreds of grid rows per point — 3-4 ms per wrong
+    # candidate, whether 2 000 or 20 000 points are scored (a chain of dependent reads per wavefront), plus the
+    # coarser grid levels such a wide search makes the engine build.  Round 3: score first with the bound at
+    # NARROW_CELLS cells of the gold grid.  There the engine's distance-to-occupied table settles "nothing within
+    # the bound" with one byte per point, nothing wider than its ring walk is needed, and a candidate costs ~0.1 ms.
+    # The narrow scores decide when they are decisive — the best below DECISIVE x the runner-up; otherwise (a sloppy
+    # coarse pose leaves the right candidate decimetres off, and every score saturates at the bound) the wide
+    # bound is used as before.
+    narrow = min(truncate, NARROW_CELLS * float(gi["cell"]))
+    if not resident:
+        engine.set_source(np.ascontiguousarray(subsample()))    # dtype kept: fp64 georeferenced coordinates are shifted before they become fp32
+    cloud_scores, scores = all_scores(narrow, sums_only=resident)
+    ranked = sorted(scores)
+    used = narrow
+    if narrow < truncate and not (ranked[0] < DECISIVE * ranked[1]):
+        if resident:
+            engine.set_source(np.ascontiguousarray(subsample()))
+        cloud_scores, scores = all_scores(truncate)
+        used = truncate
+        if resident:
+            engine.set_source(comp)                             # as the caller left it
     best = int(np.argmin(scores))
     R = cands[best]
     # (a stage next to a half turn becomes two of half the angle: the visualiser's logm needs the principal branch)
     stages = transforms.split_half_turns([(R, cc)]) + [transforms.rt_to_matrix(np.eye(3), cg - cc)]
     return stages, transforms.compose(stages), {"scores": scores, "cloud_scores": cloud_scores,
                                                 "trajectory_scores": traj_scores if use_traj else None,
-                                                "chosen": best, "truncate_m": truncate}
+                                                "chosen": best, "truncate_m": truncate, "score_bound_m": used}

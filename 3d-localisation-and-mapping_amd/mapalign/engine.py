@@ -11,8 +11,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
-from ._lib import (MA_ACC_LEN, MA_COMM_ID_BYTES, MA_TRACE_STRIDE, MapAlignError, ma_grid_info, ma_mem_info,
-                   ma_params, ma_stats)
+from ._lib import (MA_ACC_LEN, MA_COMM_ID_BYTES, MA_ERR_DEGENERATE, MA_TRACE_STRIDE, MapAlignError, ma_grid_info,
+                   ma_mem_info, ma_params, ma_stats)
 
 
 def _as_T(init):
@@ -473,6 +473,27 @@ class MapAligner:
         g, b = C.c_uint32(0), C.c_uint32(0)
         self._chk(self._lib.ma_search_geometry(self._ctx, C.byref(g), C.byref(b)))
         return int(g.value), int(b.value)
+
+    def cloud_moments(self, which):
+        """(number of valid points, centroid [3], covariance [3,3]) of the gold map (``which=0``) or the source cloud
+        (``which=1``) as stored on the device — one reduction over data that is in HBM anyway (coarse stage, N1)."""
+        out = np.empty(13, dtype=np.float64)
+        self._chk(self._lib.ma_cloud_moments(self._ctx, int(which), _f64p(out)))
+        return int(out[0]), out[1:4] + self._shift, out[4:13].reshape(3, 3).copy()
+
+    def truncated_rms(self, T, bound):
+        """sqrt(mean(min(d, bound)^2)) over the source cloud's nearest-neighbour distances d under ``T`` — from the
+        17 sums of ONE search + accumulate launch gated at ``bound`` (E = sum of matched d^2, W = matches), nothing
+        per point comes back to the host.  Unweighted clouds only (the weights would enter E and W)."""
+        p = self._params(1, 0.0, float(bound), False)
+        Tin = _conj_shift(_as_T(T), self._shift, inverse=True)
+        acc = np.empty(MA_ACC_LEN, dtype=np.float64)
+        Tout = np.empty((4, 4), dtype=np.float64)
+        rc = self._lib.ma_icp_step(self._ctx, C.byref(p), _f64p(Tin), _f64p(acc), _f64p(Tout))
+        if rc != MA_ERR_DEGENERATE:        # "nothing (or too little) inside the bound" still fills the sums
+            self._chk(rc)
+        n = float(self.n_source)
+        return float(np.sqrt(max(acc[16] + (n - acc[0]) * float(bound) ** 2, 0.0) / n))
 
     def get_source(self):
         n = C.c_uint64(0)

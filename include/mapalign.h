@@ -157,6 +157,12 @@ int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out);
  * (padded to whole XCD segments and scheduling groups) and threads (= points) per workgroup.  What a roofline
  * computation needs for the per-workgroup terms (19 fp64 partials each). */
 int ma_search_geometry(const ma_ctx* ctx, uint32_t* n_workgroups, uint32_t* block_threads);
+/* Row N1 (coarse pre-alignment): number of valid points, centroid (frame of the coordinates handed in, minus the
+ * large-coordinate shift if one is in force) and 3x3 sample covariance (row-major) of a cloud AS STORED on the
+ * device: which = 0 the gold map, 1 the source cloud (holes of a depth frame are skipped).  out = {n, c[3], C[9]}.
+ * The principal axes of both clouds give the (R, centre) candidates of the first stage of the transformations
+ * list (src/map_alignment/visualise.py:82-92); the sums are one pass over data that is in HBM anyway. */
+int ma_cloud_moments(ma_ctx* ctx, int which, double out[13]);
 
 /* Row a8: fused depth -> 3-D unprojection written straight into the source-cloud device
  * buffer.  Pinhole model of pose_processor.py:133-137,184-196,242-260:

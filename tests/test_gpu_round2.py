@@ -878,3 +878,44 @@ def test_device_solve_vs_numpy_svd_through_step_solve(lib_built):
             eng.step_solve(acc_dev.data_ptr())
             T, info = eng.state_get()
             assert info["degenerate"] and np.array_equal(T, np.eye(4))
+
+
+def test_cloud_moments_and_truncated_rms_against_numpy(engine):
+    """N1 on the device: ma_cloud_moments (count, centroid, covariance of a cloud as stored) against NumPy on the same
+    points — float32 clouds, a georeferenced float64 pair (large-coordinate shift in force), a depth frame with holes —
+    and MapAligner.truncated_rms (from the 17 sums of one gated launch) against the per-point distances of ma_nn."""
+    gold, comp, _, _ = syn.make_pair(4, 60_000, 50_000)
+    engine.set_pair(gold, comp)
+    for which, cloud in ((0, gold), (1, comp)):
+        n, c, C = engine.cloud_moments(which)
+        p = cloud.astype(np.float64)
+        assert n == len(p)
+        assert np.abs(c - p.mean(0)).max() < 1e-6
+        assert np.abs(C - np.cov(p.T)).max() < 1e-6 * np.abs(np.cov(p.T)).max() + 1e-9
+    T = transforms.rt_to_matrix(syn.rotation_about_axis([0.2, 1.0, 0.1], 0.4), [0.5, -0.2, 0.1])
+    for bound in (0.05, 0.19, 0.6):
+        for M in (np.eye(4), T):
+            _, d2 = engine.nn(M, bound)
+            want = float(np.sqrt(np.mean(np.minimum(d2.astype(np.float64), bound * bound))))
+            got = engine.truncated_rms(M, bound)
+            assert abs(got - want) < 1e-6 * max(want, 1e-3), (bound, got, want)
+    # nothing inside the bound at all: the score is the bound, not an error
+    far = transforms.rt_to_matrix(np.eye(3), [500.0, 0.0, 0.0])
+    assert abs(engine.truncated_rms(far, 0.1) - 0.1) < 1e-12
+    # georeferenced float64 clouds: the centroid comes back in the caller's frame
+    off = np.array([4.5e5, 5.2e6, 120.0])
+    g64, c64 = gold.astype(np.float64) + off, comp.astype(np.float64) + off
+    engine.set_pair(g64, c64)
+    n, c, C = engine.cloud_moments(1)
+    assert n == len(c64) and np.abs(c - c64.mean(0)).max() < 1e-4 and np.abs(C - np.cov(c64.T)).max() < 1e-4
+    # a depth frame with holes as the source cloud: holes do not count
+    depth, K, Tcw = syn.make_depth_frame(0, width=128, height=96, fx=100.0, fy=100.0, cx=63.5, cy=47.5)
+    rng = np.random.default_rng(0)
+    depth = depth.copy()
+    depth[rng.random(depth.shape) < 0.3] = 0.0
+    engine.set_gold(gold)
+    engine.set_source_from_depth(depth, K, Tcw, 1000.0)
+    pts = engine.get_source().astype(np.float64)
+    n, c, C = engine.cloud_moments(1)
+    assert n == len(pts) == int((depth > 0).sum())
+    assert np.abs(c - pts.mean(0)).max() < 1e-5 and np.abs(C - np.cov(pts.T)).max() < 1e-5

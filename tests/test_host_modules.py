@@ -57,6 +57,45 @@ def test_ply_big_endian_double_and_extra_properties(tmp_path):
     assert np.array_equal(ply.read_ply(path), pts)
 
 
+def test_ply_coordinates_in_the_files_own_type(tmp_path):
+    """dtype=None (what Alignment.compare uses): float32 files come back as float32 — a view of the bytes read for an
+    x-y-z-only record, a strided view with colours in the record — with the same values and the same filters; a
+    big-endian double file as native float64; scattered or mixed-type coordinates still work."""
+    rng = np.random.default_rng(9)
+    pts = rng.normal(size=(300, 3)).astype(np.float32)
+    plain, coloured = tmp_path / "plain.ply", tmp_path / "coloured.ply"
+    ply.write_ply(plain, pts)
+    ply.write_ply(coloured, pts, rng.integers(0, 255, size=(300, 3), dtype=np.uint8))
+    for path in (plain, coloured):
+        out = ply.read_ply(path, dtype=None)
+        assert out.dtype == np.float32 and np.array_equal(out, pts)
+        assert np.array_equal(ply.read_ply(path), pts.astype(np.float64))       # default: float64, as before
+        assert np.array_equal(ply.read_ply(path, dtype=np.float32), pts)
+    assert not ply.read_ply(plain, dtype=None).flags.owndata                   # no copy was made
+    holes = pts.copy()
+    holes[5, 2] = np.nan
+    holes[9, 0] = -np.inf
+    ply.write_ply(plain, holes)
+    out = ply.read_ply(plain, dtype=None)
+    assert out.dtype == np.float32 and np.array_equal(out, holes[np.isfinite(holes).all(axis=1)])
+    assert len(ply.read_ply(plain, dtype=None, remove_nan_points=False)) == 299
+    # big-endian doubles -> native float64; x, y, z not adjacent in the record -> gathered column by column
+    p64 = np.arange(30, dtype=np.float64).reshape(10, 3) / 7.0
+    rec = np.zeros(10, dtype=np.dtype([("x", ">f8"), ("nx", ">f4"), ("y", ">f8"), ("z", ">f8")]))
+    rec["x"], rec["y"], rec["z"] = p64.T
+    be = tmp_path / "be.ply"
+    be.write_bytes(("ply\nformat binary_big_endian 1.0\nelement vertex 10\nproperty double x\nproperty float nx\n"
+                    "property double y\nproperty double z\nend_header\n").encode() + rec.tobytes())
+    out = ply.read_ply(be, dtype=None)
+    assert out.dtype == np.float64 and out.dtype.isnative and np.array_equal(out, p64)
+    rec2 = np.zeros(10, dtype=np.dtype([("x", ">f8"), ("y", ">f8"), ("z", ">f8")]))
+    rec2["x"], rec2["y"], rec2["z"] = p64.T
+    be.write_bytes(("ply\nformat binary_big_endian 1.0\nelement vertex 10\nproperty double x\n"
+                    "property double y\nproperty double z\nend_header\n").encode() + rec2.tobytes())
+    out = ply.read_ply(be, dtype=None)
+    assert out.dtype == np.float64 and out.dtype.isnative and np.array_equal(out, p64)
+
+
 def test_ply_errors(tmp_path):
     bad = tmp_path / "bad.ply"
     bad.write_bytes(b"plx\n")

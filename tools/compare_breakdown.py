@@ -20,6 +20,8 @@ gp, sp = os.path.join(d, "gold.ply"), os.path.join(d, "scan.ply")
 ply.write_ply(gp, gold); ply.write_ply(sp, far)
 t_read, g = T(ply.read_ply, gp)
 print(f"read_ply (one file, {g.dtype}): {t_read:.1f} ms")
+t_read, g32 = T(lambda: ply.read_ply(gp, dtype=None))
+print(f"read_ply (one file, dtype=None -> {g32.dtype}, a view: {not g32.flags.owndata}): {t_read:.1f} ms")
 eng, lock = mapalign.api.cached_engine(0)
 t, _ = T(eng.set_gold, g); print(f"set_gold: {t:.2f} ms")
 c = ply.read_ply(sp)
@@ -27,7 +29,20 @@ t, (cg, ag, _) = T(coarse.principal_frame, g); print(f"principal_frame(gold): {t
 t, (cc, ac, _) = T(coarse.principal_frame, c); print(f"principal_frame(scan): {t:.1f} ms")
 t, (stages, T0, info) = T(coarse.coarse_align, eng, g, c, reps=3); print(f"coarse_align total: {t:.1f} ms")
 t, _ = T(eng.set_source, c); print(f"set_source: {t:.2f} ms")
+t, _ = T(eng.set_pair, g, c); print(f"set_pair: {t:.2f} ms")
+t, _ = T(lambda: coarse.coarse_align(eng, g, c, resident=True), reps=3); print(f"coarse_align on the resident pair (device moments, sums-only scores): {t:.2f} ms")
 t, r = T(lambda: eng.icp(50, 0.0, 0.10, init=T0)); print(f"icp 50 from the coarse start: {t:.2f} ms")
 al = mapalign.Alignment(base_map_filepath=gp, comparison_map_filepath=sp)
 t, _ = T(al.align_clouds, g, c, reps=3); print(f"align_clouds (coarse + gate schedule + final): {t:.1f} ms")
 t, _ = T(lambda: mapalign.Alignment(base_map_filepath=gp, comparison_map_filepath=sp).compare(d), reps=3); print(f"compare(): {t:.1f} ms")
+from concurrent.futures import ThreadPoolExecutor
+def both():
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        a, b = pool.submit(ply.read_ply, gp, dtype=None), pool.submit(ply.read_ply, sp, dtype=None)
+        return a.result(), b.result()
+t, _ = T(both); print(f"both .ply files in two threads: {t:.1f} ms")
+import cProfile, pstats
+al = mapalign.Alignment(base_map_filepath=gp, comparison_map_filepath=sp)
+al.compare(d)
+pr = cProfile.Profile(); pr.enable(); al.compare(d); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
