@@ -71,7 +71,8 @@ def test_ply_coordinates_in_the_files_own_type(tmp_path):
         assert out.dtype == np.float32 and np.array_equal(out, pts)
         assert np.array_equal(ply.read_ply(path), pts.astype(np.float64))       # default: float64, as before
         assert np.array_equal(ply.read_ply(path, dtype=np.float32), pts)
-    assert not ply.read_ply(plain, dtype=None).flags.owndata                   # no copy was made
+    view = ply.read_ply(plain, dtype=None)
+    assert not view.flags.owndata and view.flags.writeable                     # no copy was made, and the caller may edit it
     holes = pts.copy()
     holes[5, 2] = np.nan
     holes[9, 0] = -np.inf
