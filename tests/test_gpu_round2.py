@@ -919,3 +919,26 @@ def test_cloud_moments_and_truncated_rms_against_numpy(engine):
     n, c, C = engine.cloud_moments(1)
     assert n == len(pts) == int((depth > 0).sum())
     assert np.abs(c - pts.mean(0)).max() < 1e-5 and np.abs(C - np.cov(pts.T)).max() < 1e-5
+
+
+def test_coarse_stage_on_the_resident_pair_equals_the_host_side_stage(engine, monkeypatch):
+    """coarse_align(resident=True) — principal frames from the device's moment sums, candidates scored from the sums of
+    one narrow-gated launch each over the whole comparison cloud — picks the same candidate as the host-side stage
+    (sub-sample, per-point distances) and lands within a few millimetres / 0.1 degree of it; when the narrow round is
+    undecided (forced here) it falls back to the wide bound and leaves the full comparison cloud in the engine."""
+    gold, _, _, _ = syn.make_pair(0, 200_000)
+    far = syn.make_pair(0, 200_000, angle_deg=150.0, t0=(7.0, -1.0, 0.5))[1]
+    engine.set_gold(gold)
+    stages_h, T_h, info_h = coarse.coarse_align(engine, gold, far)
+    engine.set_pair(gold, far)
+    stages_r, T_r, info_r = coarse.coarse_align(engine, gold, far, resident=True)
+    assert info_r["chosen"] == info_h["chosen"] and info_r["score_bound_m"] < info_r["truncate_m"]
+    assert engine.n_source == len(far)
+    dR = T_r[:3, :3] @ T_h[:3, :3].T
+    assert np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))) < 0.1 and np.linalg.norm(T_r[:3, 3] - T_h[:3, 3]) < 0.02
+    r = engine.icp(30, 0.0, 0.1, init=T_r)              # the full cloud is what iterates
+    assert r.inliers > 0.5 * len(far)
+    monkeypatch.setattr(coarse, "DECISIVE", 0.0)         # never decisive: the wide round must run and tidy up after itself
+    stages_w, T_w, info_w = coarse.coarse_align(engine, gold, far, resident=True)
+    assert info_w["score_bound_m"] == info_w["truncate_m"] and info_w["chosen"] == info_h["chosen"]
+    assert engine.n_source == len(far) and np.allclose(T_w, T_r)
