@@ -451,38 +451,85 @@ __global__ __launch_bounds__(kBlock) void k_gather4(const float4* __restrict__ g
   out[pos] = v;
 }
 
-// Cell table without a histogram (round 3).  Round 2 counted the points of every cell with one integer atomic
-// per point beside the key computation (k_cell_keys: 54 us with, 8 us without, for 1M points) and turned the
-// counts into starts with an exclusive sum.  The sorted keys already hold the same information: a run of equal
-// keys ENDS at position i iff keys[i + 1] differs, and cstart[c] = number of points with key < c = the largest
-// run end among the cells in front of c.  So: tails[key] = i + 1 at every run end (a scatter of one word per
-// OCCUPIED cell into a zeroed table), then an exclusive MAX-scan over the cells.  The number of occupied cells
-// (ma_grid_info: informational) is the number of run ends: one count per workgroup, summed on the host.
-__global__ __launch_bounds__(kBlock) void k_cell_tails(const uint32_t* __restrict__ sorted_keys, const uint32_t n,
-                                                       uint32_t* __restrict__ tails, uint32_t* __restrict__ ends_per_block) {
+// Cell table straight from the sorted keys (round 3).  Round 2 counted the points of every cell with one integer
+// atomic per point beside the key computation (k_cell_keys: 54 us with, 8 us without, for 1M points) and summed the
+// counts over all cells (hipCUB, 28 us for 3.8M cells); the first form of this round scattered the run ends into a
+// zeroed table and max-scanned it (memset 6 + 5 + 28 us).  Neither pass over the cells is needed: cstart[c] = number
+// of points with key < c, so the run that STARTS at sorted position i (keys[i] != keys[i - 1]) settles every cell in
+// (keys[i - 1], keys[i]] — its own cell and the empty ones in front of it — to the value i; item n (one past the
+// last point) settles the cells behind the last occupied one, padding included, to n.  A gap of a few cells is
+// written by its own thread; a longer one (row ends, empty slabs: thousands of cells) by the whole wavefront, 64
+// cells per store; a HUGE one (empty layers of the box: 10^5 cells and more — one wavefront filling it alone took
+// 26 of this kernel's 28 us) is put on a short list and filled by a whole grid (k_fill_gaps).  Reads 4 MB of keys,
+// writes the table once.  The number of occupied cells (ma_grid_info: informational) is the number of run starts:
+// one count per workgroup.
+constexpr uint32_t kGapShort = 4, kGapHuge = 2048, kGapListCap = 4096;
+struct GapList {
+  uint32_t count;                 // zero between builds (k_fill_gaps' successor, k_sum_u32, clears it)
+  uint32_t pad[3];
+  uint32_t first[kGapListCap], len[kGapListCap], value[kGapListCap];
+};
+__global__ __launch_bounds__(kBlock) void k_cell_starts(const uint32_t* __restrict__ sorted_keys, const uint32_t n,
+                                                        const uint32_t table_len, uint32_t* __restrict__ cstart,
+                                                        uint32_t* __restrict__ starts_per_block, GapList* __restrict__ gaps) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  bool end = false;
+  const int lane = threadIdx.x & (kWave - 1);
+  bool start = false;
+  uint32_t first = 0, len = 0;
   if (i < n) {
     const uint32_t k = sorted_keys[i];
-    end = i + 1 == n || sorted_keys[i + 1] != k;
-    if (end) tails[k] = i + 1u;
+    if (i == 0) { start = true; first = 0; len = k + 1u; }
+    else {
+      const uint32_t p = sorted_keys[i - 1];
+      if (p != k) { start = true; first = p + 1u; len = k - p; }
+    }
+  } else if (i == n) {            // behind the last occupied cell
+    first = sorted_keys[n - 1] + 1u;
+    len = table_len - first;
   }
-  const uint32_t c = (uint32_t)__popcll(__ballot(end));
+  if (len != 0u && len <= kGapShort) {
+    for (uint32_t j = 0; j < len; ++j) cstart[first + j] = i;
+  }
+  if (len > kGapHuge) {           // rare (a few per grid): one atomic each is no queue
+    const uint32_t slot = atomicAdd(&gaps->count, 1u);
+    if (slot < kGapListCap) {
+      gaps->first[slot] = first; gaps->len[slot] = len; gaps->value[slot] = i;
+      len = 0u;                   // handed over
+    }                             // (list full: filled here after all, as a wide gap)
+  }
+  unsigned long long wide = __ballot(len > kGapShort);
+  while (wide) {
+    const int src = __ffsll((long long)wide) - 1;
+    wide &= wide - 1ull;
+    const uint32_t f = __shfl(first, src, kWave), l = __shfl(len, src, kWave), v = __shfl(i, src, kWave);
+    for (uint32_t j = (uint32_t)lane; j < l; j += kWave) cstart[f + j] = v;
+  }
+  const uint32_t c = (uint32_t)__popcll(__ballot(start));
   __shared__ uint32_t part[kBlock / kWave];
-  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = c;
+  if (lane == 0) part[threadIdx.x / kWave] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t t = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / kWave; ++w) t += part[w];
-    ends_per_block[blockIdx.x] = t;
+    starts_per_block[blockIdx.x] = t;
   }
 }
 
-// sum of n words -> one 64-bit word (ONE workgroup; the destination is the pinned mailbox): the run-end counts of
-// k_cell_tails = the number of occupied cells
+// the listed gaps, every one by the whole grid
+__global__ __launch_bounds__(kBlock) void k_fill_gaps(const GapList* __restrict__ gaps, uint32_t* __restrict__ cstart) {
+  const uint32_t count = min(gaps->count, kGapListCap);
+  for (uint32_t g = 0; g < count; ++g) {
+    const uint32_t f = gaps->first[g], l = gaps->len[g], v = gaps->value[g];
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < l; j += gridDim.x * kBlock) cstart[f + j] = v;
+  }
+}
+
+// sum of n words -> one 64-bit word (ONE workgroup; the destination is the pinned mailbox): the run-start counts of
+// k_cell_starts = the number of occupied cells.  Also leaves the gap list empty for the next build.
 __global__ __launch_bounds__(kBlock) void k_sum_u32(const uint32_t* __restrict__ v, const uint32_t n,
-                                                    unsigned long long* __restrict__ out) {
+                                                    unsigned long long* __restrict__ out, uint32_t* __restrict__ clear) {
+  if (threadIdx.x == 0 && clear) *clear = 0u;
   unsigned long long c = 0;
   for (uint32_t i = threadIdx.x; i < n; i += kBlock) c += v[i];
 #pragma unroll
@@ -2076,6 +2123,8 @@ struct ma_ctx {
   DevBuf raw_src, raw64_src;     // ma_set_pair{,_f64}: the scan is uploaded here while the gold map is being built from `raw`
   DevBuf akeys_a, akeys_b, avals_a, avals_b, acub_tmp, amisc;     // ... and sorted with its own scratch on its own stream
   hipStream_t aux_stream = nullptr;
+  DevBuf gap_list;               // k_cell_starts' list of huge runs of empty cells (GapList)
+  bool gap_list_dirty = false;
   DevBuf probe_marks;            // mark tables of the occupancy probes: all-zero between calls (occupied_cells_multi)
   size_t probe_clean = 0;        //   bytes of it known to be zero
   char* mailbox = nullptr;       // pinned host memory, 2 x kMailBytes: the small results of the build kernels land here (Mailbox below)
@@ -2128,7 +2177,7 @@ struct ma_ctx {
   };
   PairHandoff* pair_handoff = nullptr;
   std::vector<DevBuf*> all_bufs() {
-    std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b, &probe_marks,
+    std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b, &probe_marks, &gap_list,
                               &src, &src_perm, &raw, &raw_src, &raw64_src, &akeys_a, &akeys_b, &avals_a, &avals_b, &acub_tmp, &amisc, &raw64, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
                               &depth_in, &lift_poses, &lift_frames, &unproj_cnt, &state, &partials, &trace, &acc19, &ticket,
                               &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
@@ -2873,7 +2922,6 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   }
 
   // one grid per level: cell edges c, 2c, 4c, 8c over the same box
-  DevBuf& hist = ctx->misc;
   LevelSet L{};
   GridP g0{};
   uint64_t ncells0 = 0;
@@ -2883,28 +2931,29 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
     if (l == 0) { g0 = g; ncells0 = ncells; }
     HIPCHK(ctx->cstart[l].ensure((ncells + 8) * 4));   // + padding for the 16-byte table reads
-    HIPCHK(hist.ensure((ncells + 8) * 4 + 64));
-    uint32_t* d_hist = reinterpret_cast<uint32_t*>(static_cast<char*>(hist.p) + 64);
-    HIPCHK(hipMemsetAsync(hist.p, 0, (ncells + 8) * 4 + 64, ctx->stream));
-    // stable radix sort by cell id -> keys_b sorted, vals_b = permutation (sorted pos -> original index);
-    // run ends of the sorted keys -> cell table (k_cell_tails + exclusive max-scan)
+    // stable radix sort by cell id -> keys_b sorted, perm0 = permutation (sorted pos -> original index);
+    // run starts of the sorted keys -> cell table (k_cell_starts)
     Lane gl = main_lane(ctx);
     gl.vals_b = &ctx->perm0;                            // the permutation is sorted straight into its final place
     if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, nullptr, 0, &gl))) return rc;
-    const uint32_t nblk = div_up(n, kBlock);
+    const uint32_t nblk = div_up(n + 1u, kBlock);       // item n settles the cells behind the last occupied one
     HIPCHK(ctx->occ_b.ensure((size_t)nblk * 4));
-    hipLaunchKernelGGL(k_cell_tails, dim3(nblk), dim3(kBlock), 0, ctx->stream, ctx->keys_b.as<uint32_t>(), n, d_hist,
-                       ctx->occ_b.as<uint32_t>());
+    if (!ctx->gap_list.p || ctx->gap_list_dirty) {      // the list's counter is zero whenever no build runs (a build that
+      HIPCHK(ctx->gap_list.ensure(sizeof(GapList)));    // failed half-way is the exception: cleared here)
+      HIPCHK(hipMemsetAsync(ctx->gap_list.p, 0, sizeof(GapList), ctx->stream));
+    }
+    ctx->gap_list_dirty = true;
+    hipLaunchKernelGGL(k_cell_starts, dim3(nblk), dim3(kBlock), 0, ctx->stream, ctx->keys_b.as<uint32_t>(), n,
+                       (uint32_t)(ncells + 8), ctx->cstart[l].as<uint32_t>(), ctx->occ_b.as<uint32_t>(),
+                       ctx->gap_list.as<GapList>());
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_fill_gaps, dim3(256), dim3(kBlock), 0, ctx->stream, ctx->gap_list.as<GapList>(),
+                       ctx->cstart[l].as<uint32_t>());
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->occ_b.as<uint32_t>(), nblk,
-                       reinterpret_cast<unsigned long long*>(ctx->mailbox + kMailWord));
+                       reinterpret_cast<unsigned long long*>(ctx->mailbox + kMailWord), &ctx->gap_list.as<GapList>()->count);
     HIPCHK(hipGetLastError());
-    size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveScan(nullptr, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), hipcub::Max(), 0u,
-                                             (int)(ncells + 8), ctx->stream));
-    HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-    HIPCHK(hipcub::DeviceScan::ExclusiveScan(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), hipcub::Max(), 0u,
-                                             (int)(ncells + 8), ctx->stream));
+    ctx->gap_list_dirty = false;                        // the clearing launch is in the stream
     HIPCHK(ctx->gold[l].ensure(((size_t)n + 8) * sizeof(float4)));   // + 8 pad entries (level 0)
     hipLaunchKernelGGL(k_gather, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->raw.as<float>(),
                        (const float*)nullptr, ctx->perm0.as<uint32_t>(), n, ctx->origin[0], ctx->origin[1],
