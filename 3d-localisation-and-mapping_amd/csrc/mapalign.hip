@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void k_gather4(const float4* __restrict__ g
 // 26 of this kernel's 28 us) is put on a short list and filled by a whole grid (k_fill_gaps).  Reads 4 MB of keys,
 // writes the table once.  The number of occupied cells (ma_grid_info: informational) is the number of run starts:
 // one count per workgroup.
-constexpr uint32_t kGapShort = 4, kGapHuge = 2048, kGapListCap = 4096;
+constexpr uint32_t kGapShort = 4, kGapHuge = 1024, kGapListCap = 4096;
 struct GapList {
   uint32_t count;                 // zero between builds (k_fill_gaps' successor, k_sum_u32, clears it)
   uint32_t pad[3];
@@ -472,7 +472,11 @@ struct GapList {
 __global__ __launch_bounds__(kBlock) void k_cell_starts(const uint32_t* __restrict__ sorted_keys, const uint32_t n,
                                                         const uint32_t table_len, uint32_t* __restrict__ cstart,
                                                         uint32_t* __restrict__ starts_per_block, GapList* __restrict__ gaps) {
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  // workgroups are dealt round-robin over the 8 XCDs: give every XCD ONE contiguous eighth of the sorted array, so that
+  // the cache lines of the table (neighbouring runs write neighbouring cells) are completed inside one L2 instead of
+  // being written back in pieces by several (gridDim.x is a multiple of 8)
+  const uint32_t blk = (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u;
+  const uint32_t i = blk * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   bool start = false;
   uint32_t first = 0, len = 0;
@@ -502,7 +506,14 @@ __global__ __launch_bounds__(kBlock) void k_cell_starts(const uint32_t* __restri
     const int src = __ffsll((long long)wide) - 1;
     wide &= wide - 1ull;
     const uint32_t f = __shfl(first, src, kWave), l = __shfl(len, src, kWave), v = __shfl(i, src, kWave);
-    for (uint32_t j = (uint32_t)lane; j < l; j += kWave) cstart[f + j] = v;
+    // four stores per trip: a lone wavefront pays ~25 ns per trip of this loop, and the longest chains of gaps set
+    // the kernel's time
+    for (uint32_t j = (uint32_t)lane; j < l; j += 4u * kWave) {
+      cstart[f + j] = v;
+      if (j + kWave < l) cstart[f + j + kWave] = v;
+      if (j + 2u * kWave < l) cstart[f + j + 2u * kWave] = v;
+      if (j + 3u * kWave < l) cstart[f + j + 3u * kWave] = v;
+    }
   }
   const uint32_t c = (uint32_t)__popcll(__ballot(start));
   __shared__ uint32_t part[kBlock / kWave];
@@ -512,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_starts(const uint32_t* __restri
     uint32_t t = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / kWave; ++w) t += part[w];
-    starts_per_block[blockIdx.x] = t;
+    starts_per_block[blk] = t;
   }
 }
 
@@ -2936,7 +2947,7 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     Lane gl = main_lane(ctx);
     gl.vals_b = &ctx->perm0;                            // the permutation is sorted straight into its final place
     if ((rc = sort_by_cell(ctx, ctx->raw.as<float>(), n, g, ctx->origin, nullptr, 0, &gl))) return rc;
-    const uint32_t nblk = div_up(n + 1u, kBlock);       // item n settles the cells behind the last occupied one
+    const uint32_t nblk = (div_up(n + 1u, kBlock) + 7u) & ~7u;   // item n settles the cells behind the last occupied one; 8 | grid
     HIPCHK(ctx->occ_b.ensure((size_t)nblk * 4));
     if (!ctx->gap_list.p || ctx->gap_list_dirty) {      // the list's counter is zero whenever no build runs (a build that
       HIPCHK(ctx->gap_list.ensure(sizeof(GapList)));    // failed half-way is the exception: cleared here)
