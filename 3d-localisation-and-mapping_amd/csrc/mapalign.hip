@@ -2861,9 +2861,29 @@ static int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     // so occupancy grows ~ c^2; two histogram probes estimate the exponent.
     const double target = 4.5;
     // table budget of the density-driven choice: at most 32 cells (128 B of table) per point,
-    // and at most 2^24 cells (a 64 MB level-0 table stays in the Infinity Cache; 8M points:
-    // 1.27 cm / 74M cells 25.1 ms per alignment, 2.0 cm / 19M cells 21.4 ms)
-    const uint64_t auto_cells = std::min<uint64_t>(1ull << 24, std::max<uint64_t>(1ull << 20, 32ull * n));
+    // and at most 2^24 cells up to 4M points, 4 cells per point beyond, 2^25 from 8M points on
+    // (the level-0 table has to stay in the Infinity Cache, but a cloud that dense pays for coarse
+    // cells with candidates: 8M / 16M / 32M points, 50 iterations: 2.1 cm (2^24 cells) 20.9 / 59.4 /
+    // 188.5 ms, 1.7 cm (31M cells) 19.9 / 51.8 / 153.0, 1.4 cm (55M cells) 24.6 / 61.4 / 177.6,
+    // 1.1 cm (114M cells) - / 62.3 / 171.6 - tools/big_cell_sweep.py)
+    // The relaxed cap stops at 1.7 cm where it would cross it: a search sphere wider than 6 cells leaves the
+    // wavefront-cooperative search (wave_search: kWalk), and with the default 0.10 m gate that is every unmatched
+    // query once c < 1.67 cm (16M points: 1.75 / 1.70 / 1.66 / 1.60 cm -> 51.8 / 52.0 / 61.6 / 60.2 ms).
+    const uint64_t cap_hi = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 24, 4ull * n));
+    uint64_t cell_cap = 1ull << 24;
+    if (cap_hi > cell_cap) {
+      const double ext0 = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-6});
+      const float seed = (float)(ext0 / 4096.0);
+      const float c_lo = clamp_cell_to_budget(lo, hi, seed, cap_hi), c_hi = clamp_cell_to_budget(lo, hi, seed, cell_cap);
+      constexpr float kGateFloor = 0.017f;
+      if (c_lo >= kGateFloor || c_hi <= kGateFloor) {
+        cell_cap = cap_hi;                       // the whole relaxed range lies on one side of the floor
+      } else {                                   // the range brackets it: the cell count of a 1.7 cm grid
+        const GridP gf = make_grid(lo, hi, ctx->origin, kGateFloor);
+        cell_cap = std::min<uint64_t>(cap_hi, std::max<uint64_t>(cell_cap, (uint64_t)gf.nx * gf.ny * gf.nz));
+      }
+    }
+    const uint64_t auto_cells = std::min<uint64_t>(cell_cap, std::max<uint64_t>(1ull << 20, 32ull * n));
     const double ext = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-6});
     float c0 = clamp_cell_to_budget(lo, hi, (float)(ext / 256.0), auto_cells);
     uint64_t occ = 0;
