@@ -37,10 +37,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <limits>
@@ -48,6 +50,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "host_math.h"
@@ -62,6 +65,30 @@ constexpr int kWave = 64;
 constexpr int kNAcc = 19;             // 17 accumulators + rows visited + candidates
 constexpr uint32_t kNoMatch = 0xFFFFFFFFu;
 constexpr uint32_t kHoleBitsEarly = 0x7FC00000u;   // = kHoleBits (k_unproject): x of a hole, a quiet NaN
+
+// Candidate lists (k_nn_accum, "list launches"): once the transform moves the cloud by less than a fraction of
+// a cell per iteration, a search launch also WRITES, per query, every gold point within (match distance + skin) of
+// the query's position; while a query has moved less than skin / 2 since then, its nearest neighbour is provably
+// in that list (triangle inequality, checked per query), and the launch reads 8 indices instead of searching.
+constexpr int kListLen = 8;
+constexpr int kPlan = 4;             // iterations per planning batch of ma_icp
+constexpr int kMaxReports = 1024;    // planning batches a run can report (longer runs search after that)
+struct ListCtl {
+  int have;          // lists exist (written by the launch that ran with the transform Rb, tb)
+  float skin;        // metres
+  float rs;          // largest distance of a corner of the source cloud's box from the centring origin; <= 0: no lists for this cloud
+  float blo[3], bhi[3];   // that box (source coordinates, centred frame)
+  float slack;       // rounding allowance of the per-query displacement, metres
+  double Rb[9], tb[3];
+};
+// What the last solve of a planning batch leaves in pinned host memory for the host's planner (one slot per batch, so
+// that the host reads the values of one fixed iteration whatever the device has done since): bounds on how far that
+// solve moved any point of the source cloud, and on how far the cloud has moved since the lists were written.
+struct ListReport {
+  double step, since;
+  int have;
+  volatile int iter;    // written last: iterations solved; the host spins on it
+};
 
 // plain structs and host arithmetic shared with the CPU-side sanitizer test (host_math.h)
 using ma::DevState;
@@ -1004,6 +1031,7 @@ struct WaveLds {
   uint8_t row_lane[kRowCap];
   uint8_t chunk_lane[kChunkCap];
   uint8_t chunk_cnt[kChunkCap];
+  uint32_t minx[kWave];      // list-writing launches: smallest squared distance (bits) among the candidates a full list turned away
 #if MA_WGTIMES
   unsigned long long dbg_round0;
 #endif
@@ -1016,9 +1044,10 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-template <bool COUNT>
+template <bool COUNT, bool BUILD>
 __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, const float4* __restrict__ gold0,
-                                                uint32_t& nchunk, uint32_t& ncand) {
+                                                uint32_t& nchunk, uint32_t& ncand, const float skin,
+                                                uint32_t* __restrict__ lists_wave) {
   for (uint32_t j0 = 0; j0 < nchunk; j0 += kWave) {
     const uint32_t j = j0 + lane;
     if (j < nchunk) {
@@ -1026,6 +1055,8 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
       const float4 p = W.pos[lq];
       float b2 = __uint_as_float((uint32_t)(W.best[lq] >> 32));
       const float b2_in = b2;
+      float reach2 = 0.f;      // list-writing launch: everything within (current best distance + skin) goes on the query's list
+      if (BUILD) { const float r = fast_sqrt(b2_in) + skin; reach2 = r * r; }
       uint32_t bj = kNoMatch;
       // Four candidates per trip at consecutive positions a+t .. a+t+3, WITHOUT clamping to the
       // chunk: the positions past its end hold other gold points (the next cells of the sorted
@@ -1045,6 +1076,13 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
           const float dx = p.x - q[u].x, dy = p.y - q[u].y, dz = p.z - q[u].z;
           const float d = dx * dx + dy * dy + dz * dz;
           if (d < b2) { b2 = d; bo = t + (uint32_t)u; }
+          if (BUILD) {
+            if (d <= reach2 && t + (uint32_t)u < cnt) {      // real members of the chunk only
+              const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(&W.pos[lq]) + 3, 1u);
+              if (slot < (uint32_t)kListLen) lists_wave[lq * kListLen + slot] = a + t + (uint32_t)u;
+              else atomicMin(&W.minx[lq], __float_as_uint(d));
+            }
+          }
         }
       }
       bj = a + bo;
@@ -1056,9 +1094,10 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
 }
 
 
-template <bool COUNT>
+template <bool COUNT, bool BUILD>
 __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const LevelSet& S, uint32_t& nrow,
-                                              uint32_t& nchunk, uint32_t& nrows_cnt, uint32_t& ncand) {
+                                              uint32_t& nchunk, uint32_t& nrows_cnt, uint32_t& ncand, const float skin,
+                                              uint32_t* __restrict__ lists_wave) {
   const float4* __restrict__ gold0 = S.gold[0];
   const uint32_t* __restrict__ cs0 = S.cs[0];
   const float inv_c = S.inv_c[0];
@@ -1077,7 +1116,8 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
         lq[u] = W.row_lane[i];
         const float d2yz = W.row_d2yz[i];
         const float4 p = W.pos[lq[u]];
-        const float b2 = __uint_as_float((uint32_t)(W.best[lq[u]] >> 32));
+        float b2 = __uint_as_float((uint32_t)(W.best[lq[u]] >> 32));
+        if (BUILD) { const float r = fast_sqrt(b2) + skin; b2 = r * r; }
         if (d2yz < b2) {
           const float rx = fast_sqrt(b2 - d2yz) + S.delta;
           const int x0 = (int)fmaxf(floorf((p.x - rx - S.ox) * inv_c), 0.f);
@@ -1106,7 +1146,7 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
         const unsigned long long mask = __ballot(has);
         if (mask == 0ull) break;
         const uint32_t cnt = (uint32_t)__popcll(mask);
-        if (nchunk + cnt > (uint32_t)kChunkCap) wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
+        if (nchunk + cnt > (uint32_t)kChunkCap) wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave);
         if (has) {
           const uint32_t pos = nchunk + lane_prefix(mask), ca = a[u] + k * kChunkLen;
           W.chunk_a[pos] = ca;
@@ -1121,17 +1161,27 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
 }
 
 // All 64 lanes of the wavefront must call this together.
-template <bool COUNT>
+template <bool COUNT, bool BUILD>
 __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bool has_query, const float px,
                                             const float py, const float pz, const LevelSet& S, float& best2,
                                             uint32_t& bestj, uint32_t& nrows_cnt, uint32_t& ncand,
-                                            uint32_t& ndismissed) {
+                                            uint32_t& ndismissed, const float skin = 0.f,
+                                            uint32_t* __restrict__ lists_wave = nullptr, float* list_radius = nullptr) {
   const float c = S.c[0], inv_c = S.inv_c[0];
   const int nx = S.nx[0], ny = S.ny[0], nz = S.nz[0];
   const float4* __restrict__ gold0 = S.gold[0];
   const bool finite = has_query && isfinite(px) && isfinite(py) && isfinite(pz);
   W.pos[lane] = make_float4(px, py, pz, 0.f);
   W.best[lane] = pack_best(best2, bestj);
+  if (BUILD) W.minx[lane] = 0x7F800000u;
+  // list-writing launch: every pruning decision uses the sphere widened by the skin, so that everything within
+  // (final match distance + skin) is examined — and put on the list by wq_flush_chunks
+  auto reach = [&](const float b2) -> float {
+    if (!BUILD) return b2;
+    const float r = fast_sqrt(b2) + skin;
+    return r * r;
+  };
+  float bi = reach(best2);
   const float uy = fminf(fmaxf((py - S.oy) * inv_c, -1.f), (float)ny);
   const float uz = fminf(fmaxf((pz - S.oz) * inv_c, -1.f), (float)nz);
   const int cy = (int)floorf(uy), cz = (int)floorf(uz);
@@ -1142,7 +1192,7 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     const unsigned long long mask = __ballot(pred);
     const uint32_t cnt = (uint32_t)__popcll(mask);
     if (cnt == 0u) return;
-    if (nrow + cnt > (uint32_t)kRowCap) wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
+    if (nrow + cnt > (uint32_t)kRowCap) wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave);
     if (pred) {
       const uint32_t pos = nrow + lane_prefix(mask);
       W.row_cell[pos] = (uint32_t)((z * ny + y) * nx);
@@ -1169,11 +1219,11 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     for (int k = 0; k < 9; ++k) {
       const int dy = (k % 3 == 0) ? 0 : (k % 3 == 1 ? -1 : 1), dz = (k / 3 == 0) ? 0 : (k / 3 == 1 ? -1 : 1);
       const float d2yz = gy[k % 3] + gz[k / 3];
-      push_row(finite && d2yz < best2, cy + dy, cz + dz, d2yz);
+      push_row(finite && d2yz < bi, cy + dy, cz + dz, d2yz);
     }
   }
-  wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
-  wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
+  wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave);
+  wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave);
 #if MA_WGTIMES
   if (lane == 0) W.dbg_round0 = wall_clock64();
 #endif
@@ -1181,12 +1231,13 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     const unsigned long long key = W.best[lane];
     best2 = __uint_as_float((uint32_t)(key >> 32));
     bestj = (uint32_t)key;
+    bi = reach(best2);
   }
   // ---- further rounds: ring r while some query's sphere reaches it (same level; a sphere
   // wider than kWalk cells is left to the per-lane multi-level search)
   constexpr float kWalk = 6.f;
   const float lim = c - S.delta, wide = kWalk * c;
-  bool more = finite && best2 > lim * lim && best2 <= wide * wide;
+  bool more = finite && bi > lim * lim && best2 <= wide * wide;
   const bool fallback = finite && best2 > wide * wide;
   // A sphere that is still wide after the 3 x 3 block (an early iteration: nothing, or only
   // something far, has been found) asks the distance-to-occupied table before walking rings:
@@ -1199,14 +1250,14 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     if (more && ux >= 0.f && ux < (float)nx && (unsigned)cy < (unsigned)ny && (unsigned)cz < (unsigned)nz) {
       const int k = S.occ_dist[(uint32_t)((cz * ny + cy) * nx) + (uint32_t)ux];
       const float lbk = (float)max(k - 1, 0) * c - S.delta;
-      dismissed = lbk > 0.f && lbk * lbk > best2;   // (strictly: an equal distance may still win on position)
+      dismissed = lbk > 0.f && lbk * lbk > bi;   // (strictly: an equal distance may still win on position)
     }
     more = more && !dismissed;
     ndismissed = (uint32_t)__popcll(__ballot(dismissed));
   }
   for (int r = 2; __any(more); ++r) {
     const float lb = (float)(r - 1) * c - S.delta;
-    more = more && r <= rmax && lb * lb < best2;
+    more = more && r <= rmax && lb * lb < bi;
     if (!__any(more)) break;
     // the four sides of the ring; along a side one offset is fixed, so a row costs one gap
     // evaluation, one add and one compare
@@ -1220,16 +1271,35 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
         const int dvar = side < 2 ? o - r : r - o;
         const float d2yz = gfix + gap2(dvar, fvar, cvar, nvar);
         const int dy = zfixed ? dvar : dfix, dz = zfixed ? dfix : dvar;
-        push_row(more && d2yz < best2, cy + dy, cz + dz, d2yz);
+        push_row(more && d2yz < bi, cy + dy, cz + dz, d2yz);
       }
     }
-    wq_flush_rows<COUNT>(W, lane, S, nrow, nchunk, nrows_cnt, ncand);
-    wq_flush_chunks<COUNT>(W, lane, gold0, nchunk, ncand);
+    wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave);
+    wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave);
     const unsigned long long key = W.best[lane];
     best2 = __uint_as_float((uint32_t)(key >> 32));
     bestj = (uint32_t)key;
+    bi = reach(best2);
   }
   if (fallback) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows_cnt, ncand);
+  if (BUILD) {
+    // The list is complete inside the radius L: everything within (match distance + skin) was examined — the
+    // block and the rings cover the widened sphere, a dismissed query has nothing that near at all — and put on
+    // the list unless the list was full; then L stops at the nearest candidate that was turned away.  A query
+    // that left for the multi-level search has no list (L = 0: it searches again in every list launch); a hole
+    // never matches (L = inf, nothing to check).  The low 4 bits of L carry the number of entries (work counters).
+    const uint32_t cnt = reinterpret_cast<const uint32_t*>(&W.pos[lane])[3];
+    float L = fallback ? 0.f : fast_sqrt(best2) + skin;
+    if (cnt > (uint32_t)kListLen) L = fminf(L, fast_sqrt(__uint_as_float(W.minx[lane])));
+    L *= 1.f - 4e-6f;
+    if (!finite) L = INFINITY;
+    const uint32_t kept = min(cnt, (uint32_t)kListLen);
+    if (has_query) {
+      const uint32_t fill = bestj != kNoMatch ? bestj : 0u;     // any gold point may sit on a list: a superset stays exact
+      for (uint32_t sl = kept; sl < (uint32_t)kListLen; ++sl) lists_wave[lane * kListLen + sl] = fill;
+    }
+    *list_radius = isfinite(L) ? __uint_as_float((__float_as_uint(L) & ~0xFu) | kept) : L;
+  }
 }
 
 // XCD-aware chunk order: workgroups are dealt round-robin over the 8 XCDs, so workgroups b
@@ -1285,13 +1355,18 @@ __device__ unsigned long long g_rs[64][20][5];   // k_reduce_solve, per iteratio
 #else
 #define MA_NN_ATTR
 #endif
-template <bool COUNT, int MODE>
+// LISTS (compile time, so that the plain search launch keeps its 63 VGPRs — a run-time switch between the three bodies
+// cost 6 VGPRs, a wavefront per SIMD and 10 % of every search launch): 0 search; 1 search and write the candidate lists;
+// 2 read the lists.  The host picks the kernel per iteration from the step sizes the solve reports (ma_icp).
+template <bool COUNT, int MODE, int LISTS>
 __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     const float4* __restrict__ src, const uint32_t n, const LevelSet S,
     const uint32_t* __restrict__ perm0, const DevState* __restrict__ st, const float best2_init,
     double* __restrict__ partials, uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, const Sched sched) {
+    float* __restrict__ nn_d2, const Sched sched, const ListCtl* __restrict__ lc, uint32_t* __restrict__ lists,
+    float* __restrict__ lrad) {
   if (MODE == 0 && st->done) return;
+  constexpr int lmode = MODE == 0 ? LISTS : 0;
   const unsigned long long wg_start = wall_clock64();
   constexpr int kNW = kNNBlock / kWave;
   const uint32_t G = gridDim.x;
@@ -1300,10 +1375,14 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   const uint32_t i = chunk * kNNBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   // per-wavefront LDS: the work queues during the search, the group sums afterwards
-  union WaveShared {
+  union WaveSearch {
     WaveLds q;
     double v[kNAcc][16];
   };
+  struct WaveSums {            // a list launch has no work queues
+    double v[kNAcc][16];
+  };
+  using WaveShared = typename std::conditional<lmode == 2, WaveSums, WaveSearch>::type;
   __shared__ WaveShared sh_w[kNW];
 
   const bool has = i < n;
@@ -1322,7 +1401,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   if (has) {
     image(i);
     px = (float)Px; py = (float)Py; pz = (float)Pz;
-    if (prev && warm) {
+    if (prev && warm && lmode != 2) {
       // temporal coherence: last iteration's match bounds the search radius from the start
       const uint32_t pj = prev[i];
       if (pj != kNoMatch) {
@@ -1338,9 +1417,75 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
 #if MA_WGTIMES
   const unsigned long long dbg_t1 = wall_clock64();
 #endif
-  wave_search<COUNT>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand, ndismissed);
+  if constexpr (lmode == 2) {
+    // ---- list launch: the nearest of the (at most 8) gold points on the query's list IS the nearest neighbour
+    // while (its distance, capped at the gate) + (how far the query has moved since the list was written) stays
+    // inside the radius the list is complete for; a query that fails the check searches (per-lane, exact).
+    if (has) {
+      const bool finite = isfinite(px) && isfinite(py) && isfinite(pz);
+      const uint4* __restrict__ lp = reinterpret_cast<const uint4*>(lists) + 2 * (size_t)i;
+      const uint4 l0 = lp[0], l1 = lp[1];
+      const float Lq = lrad[i];
+      // how far this query has moved since its list was written: (R - Rb) s + (t - tb), wave-uniform differences
+      float dRf[9], dtf[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dRf[k] = (float)(st->R[k] - lc->Rb[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dtf[k] = (float)(st->t[k] - lc->tb[k]);
+      const float mx = dRf[0] * s.x + dRf[1] * s.y + dRf[2] * s.z + dtf[0];
+      const float my = dRf[3] * s.x + dRf[4] * s.y + dRf[5] * s.z + dtf[1];
+      const float mz = dRf[6] * s.x + dRf[7] * s.y + dRf[8] * s.z + dtf[2];
+      const float moved = fast_sqrt(mx * mx + my * my + mz * mz) + lc->slack;
+      unsigned long long key = pack_best(best2, kNoMatch);
+      // the search starts from last iteration's match and only a strictly nearer point replaces it: same rule here
+      const uint32_t pj = (prev && warm) ? prev[i] : kNoMatch;
+      float d_pj = INFINITY;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {          // four gathers in flight at a time (eight cost 12 more registers)
+        const uint4 lh = h == 0 ? l0 : l1;
+        const uint32_t idx[4] = {lh.x, lh.y, lh.z, lh.w};
+        float3 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = ld_xyz(S.gold[0], idx[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float dx = px - q[u].x, dy = py - q[u].y, dz = pz - q[u].z;
+          const float d = dx * dx + dy * dy + dz * dz;
+          const unsigned long long ku = pack_best(d, idx[u]);
+          if (d < best2_init && ku < key) key = ku;      // equal distances: the smaller position, as in the search
+          if (idx[u] == pj) d_pj = d;
+        }
+      }
+      if (d_pj < best2_init && __float_as_uint(d_pj) == (uint32_t)(key >> 32)) key = pack_best(d_pj, pj);
+      best2 = __uint_as_float((uint32_t)(key >> 32));
+      bestj = (uint32_t)key;
+      if (COUNT) ncand += __float_as_uint(Lq) & 0xFu;
+      if (!finite) {
+        bestj = kNoMatch;
+      } else if (!(fast_sqrt(best2) + moved < Lq)) {
+        nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
+      }
+    }
+  } else if constexpr (lmode == 1) {
+    float Lr = 0.f;
+    wave_search<COUNT, true>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand, ndismissed, lc->skin,
+                             lists + (size_t)(i - (uint32_t)lane) * kListLen, &Lr);
+    if (has) lrad[i] = Lr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // the transform these lists belong to
+      ListCtl* __restrict__ w = const_cast<ListCtl*>(lc);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) w->Rb[k] = st->R[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w->tb[k] = st->t[k];
+      w->have = 1;
+    }
+  } else {
+    wave_search<COUNT, false>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand, ndismissed);
+  }
 #if MA_WGTIMES
-  const unsigned long long dbg_t3 = wall_clock64(), dbg_t2 = sh_w[wv].q.dbg_round0;
+  unsigned long long dbg_t2 = 0;
+  if constexpr (lmode != 2) dbg_t2 = sh_w[wv].q.dbg_round0;
+  const unsigned long long dbg_t3 = wall_clock64();
   unsigned long long dbg_t4 = 0;
 #endif
 
@@ -1530,7 +1675,12 @@ __global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ 
 // ~110 VGPRs and would halve the occupancy of the search.)
 __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0, DevState* __restrict__ st,
                                            double* __restrict__ trace, const int trace_cap, const double tol,
-                                           int* __restrict__ host_done, DevState* __restrict__ host_mirror = nullptr) {
+                                           int* __restrict__ host_done, DevState* __restrict__ host_mirror = nullptr,
+                                           const ListCtl* __restrict__ lc = nullptr,
+                                           ListReport* __restrict__ report = nullptr) {
+  ListCtl lc0;
+  if (report) lc0 = *lc;      // read beside everything else, needed at the very end
+  const DevState s_in = s0;   // the transform this iteration's search launch ran with
   const int it = s0.iter;
   const double W = a[0];
   const double rmse = W > 0.0 ? sqrt(a[16] / W) : NAN;
@@ -1572,6 +1722,33 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
   }
   s0.prev_rmse = rmse;
   *st = s0;
+  if (report) {
+    // Last solve of a planning batch: tell the host how far this solve moved the cloud and how far it has moved
+    // since the candidate lists were written.  |(Ra - Rb) s + (ta - tb)| is convex in s, so over the source cloud's
+    // bounding box it is largest at one of the eight corners: an exact bound for the box, evaluated there.
+    auto moved = [&](const double* Ra, const double* ta, const double* Rb, const double* tb) -> double {
+      double d[9], v[3], m2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) d[i] = Ra[i] - Rb[i];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) v[r] = ta[r] - tb[r];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const double x = (c & 1) ? (double)lc0.bhi[0] : (double)lc0.blo[0];
+        const double y = (c & 2) ? (double)lc0.bhi[1] : (double)lc0.blo[1];
+        const double z = (c & 4) ? (double)lc0.bhi[2] : (double)lc0.blo[2];
+        const double a = d[0] * x + d[1] * y + d[2] * z + v[0], b = d[3] * x + d[4] * y + d[5] * z + v[1],
+                     e = d[6] * x + d[7] * y + d[8] * z + v[2];
+        m2 = fmax(m2, a * a + b * b + e * e);
+      }
+      return sqrt(m2);
+    };
+    report->step = moved(s0.R, s0.t, s_in.R, s_in.t);
+    report->since = lc0.have ? moved(s0.R, s0.t, lc0.Rb, lc0.tb) : INFINITY;
+    report->have = lc0.have;
+    __threadfence_system();
+    report->iter = s0.iter;
+  }
   // pinned host copy of the state (ma_icp): written with every solve, read by the host after its one
   // synchronisation — no device-to-host copy at the end of the loop (posted writes: the solve does not wait for them)
   if (host_mirror) *host_mirror = s0;
@@ -1606,7 +1783,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
                                                          const int trace_cap, const double tol,
                                                          const uint32_t* __restrict__ wg_cost,
                                                          uint32_t* __restrict__ order, const uint32_t gshift,
-                                                         int* __restrict__ host_done, DevState* __restrict__ host_mirror) {
+                                                         int* __restrict__ host_done, DevState* __restrict__ host_mirror,
+                                                         const ListCtl* __restrict__ lc, ListReport* __restrict__ report) {
   // `done` is written only by the last arriver, after every workgroup has read it.  It is
   // tested AFTER the first loads have been issued: every dependent memory round trip of
   // this small kernel is ~1 us of the iteration.
@@ -1662,7 +1840,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   asm volatile("" :: "v"(a[0]), "v"(a[18]));
   if (dbg_it < 64) g_rs[dbg_it][k][3] = wall_clock64();
 #endif
-  solve_step(a, s0, st, trace, trace_cap, tol, host_done, host_mirror);
+  solve_step(a, s0, st, trace, trace_cap, tol, host_done, host_mirror, lc, report);
 #if MA_WGTIMES
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (dbg_it < 64) g_rs[dbg_it][k][4] = wall_clock64();
@@ -2146,6 +2324,14 @@ struct ma_ctx {
 
   // loop state
   DevBuf state, partials, trace, acc19, ticket, wg_cost, seg_order, nn_idx, nn_d2, nn_tmp, prev;
+  // candidate lists of the loop (k_nn_accum): 8 gold positions + one radius per source slot, and the control block
+  DevBuf lists, lrad, listctl;
+  float src_rs = 0.f;                          // largest distance of a corner of the source cloud's box from the centring origin; 0: unknown, no lists
+  float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // that box (centred frame)
+  bool lists_on = false;                       // set by ma_icp around its loop
+  ListCtl* host_lc = nullptr;                  // pinned: the control block a run starts from
+  ListReport* host_reports = nullptr;          // pinned, kMaxReports slots: what the last solve of each planning batch reports
+  int list_builds = 0, list_uses = 0;          // launches of the last ma_icp that wrote / read the lists
   // The stepping state (DevState, prev[], partials, ...) is sized for the clouds that were set
   // when it was uploaded; installing another gold map or source cloud invalidates it
   // (ma_step_accumulate / ma_step_solve then return MA_ERR_STATE until ma_state_set).
@@ -2191,7 +2377,7 @@ struct ma_ctx {
     std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b, &probe_marks, &gap_list,
                               &src, &src_perm, &raw, &raw_src, &raw64_src, &akeys_a, &akeys_b, &avals_a, &avals_b, &acub_tmp, &amisc, &raw64, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
                               &depth_in, &lift_poses, &lift_frames, &unproj_cnt, &state, &partials, &trace, &acc19, &ticket,
-                              &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev};
+                              &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev, &lists, &lrad, &listctl};
     for (int l = 0; l < kLevels; ++l) { v.push_back(&gold[l]); v.push_back(&cstart[l]); }
     return v;
   }
@@ -2460,11 +2646,24 @@ int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, 
   return occupied_cells_multi(ctx, d_xyz, n, &g, 1, o, out);
 }
 
+// MAPALIGN_LISTS=0 in the environment: every launch of the loop searches (A/B runs, and the tests that compare both)
+bool lists_enabled() {
+  const char* e = std::getenv("MAPALIGN_LISTS");
+  return !(e && e[0] == '0');
+}
+// skin of the candidate lists = cell edge / this (MAPALIGN_SKIN_DIV overrides it for sweeps)
+float list_skin_div() {
+  const char* e = std::getenv("MAPALIGN_SKIN_DIV");
+  const float v = e ? (float)std::atof(e) : 0.f;
+  return v >= 2.f && v <= 64.f ? v : 7.f;
+}
+
 int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
   HIPCHK(ctx->state.ensure(sizeof(DevState)));
   HIPCHK(ctx->partials.ensure((size_t)kNAcc * grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(double)));
   HIPCHK(ctx->acc19.ensure(kNAcc * sizeof(double)));
   HIPCHK(ctx->wg_cost.ensure((size_t)grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(uint32_t)));
+  HIPCHK(ctx->listctl.ensure(sizeof(ListCtl)));
   if (!ctx->seg_order.p) {  // never read before the first ranking wrote it (order is used from iteration 1 on); zeroed anyway
     HIPCHK(ctx->seg_order.ensure((size_t)kMaxGroups * sizeof(uint32_t)));
     HIPCHK(hipMemsetAsync(ctx->seg_order.p, 0, (size_t)kMaxGroups * sizeof(uint32_t), ctx->stream));
@@ -2494,6 +2693,17 @@ int upload_state(ma_ctx* ctx, const double* T) {
   // a new run starts without remembered matches: the search ignores prev[] while DevState::iter == 0 and has
   // written every entry by the end of that iteration — no 4 MB fill per run
   if (ctx->have_src) HIPCHK(ctx->prev.ensure((size_t)ctx->n * 4));
+  {
+    // candidate lists: none yet; the skin is a seventh of the cell edge (the density rule puts ~4.5 points into an
+    // occupied cell, so a list then holds 2-3 points on average and overflows 8 for < 0.2 % of the queries)
+    ListCtl c{};
+    c.skin = ctx->grid.c / list_skin_div();
+    c.rs = (ctx->have_src && lists_enabled()) ? ctx->src_rs : 0.f;
+    for (int a = 0; a < 3; ++a) { c.blo[a] = ctx->src_lo[a]; c.bhi[a] = ctx->src_hi[a]; }
+    c.slack = 1e-5f + 4e-7f * ctx->src_rs;
+    *ctx->host_lc = c;
+    HIPCHK(hipMemcpyAsync(ctx->listctl.p, ctx->host_lc, sizeof(c), hipMemcpyHostToDevice, ctx->stream));
+  }
   *ctx->host_done = 0;   // every earlier launch has completed: each entry point that runs the loop ends with a sync
   ctx->state_valid = ctx->have_src;
   return MA_OK;
@@ -2503,21 +2713,37 @@ int upload_state(ma_ctx* ctx, const double* T) {
 
 // `scheduled`: inside the ma_icp loop (costs recorded, longest-first order from iteration 1 on)
 template <int MODE>
-int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2, bool scheduled = false) {
+int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2, bool scheduled = false,
+              int list_kind = 0) {
   uint32_t gshift = 0;
   const uint32_t G = grid_for(ctx->n, &gshift);
   ctx->last_G = (int)G;
   ctx->last_gshift = gshift;
   Sched sched{nullptr, nullptr, gshift};
   if (scheduled) { sched.wg_cost = ctx->wg_cost.as<uint32_t>(); sched.order = ctx->seg_order.as<uint32_t>(); }
+  const bool with_lists = MODE == 0 && ctx->lists_on && list_kind != 0;
+  if (with_lists) {      // one list and one radius per slot of the launched grid
+    HIPCHK(ctx->lists.ensure((size_t)G * kNNBlock * kListLen * sizeof(uint32_t)));
+    HIPCHK(ctx->lrad.ensure((size_t)G * kNNBlock * sizeof(float)));
+  }
   auto args = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(G), dim3(kNNBlock), 0, ctx->stream, ctx->src.as<float4>(), ctx->n,
                        ctx->levels, ctx->perm0.as<uint32_t>(), ctx->state.as<DevState>(), best2_init,
                        ctx->partials.as<double>(),
-                       MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, nn_idx, nn_d2, sched);
+                       MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, nn_idx, nn_d2, sched,
+                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, ctx->lists.as<uint32_t>(),
+                       ctx->lrad.as<float>());
   };
-  if (count) args(k_nn_accum<true, MODE>);
-  else args(k_nn_accum<false, MODE>);
+  if (MODE == 0 && with_lists && list_kind == 1) {
+    if (count) args(k_nn_accum<true, MODE == 0 ? 0 : 1, MODE == 0 ? 1 : 0>);
+    else args(k_nn_accum<false, MODE == 0 ? 0 : 1, MODE == 0 ? 1 : 0>);
+  } else if (MODE == 0 && with_lists && list_kind == 2) {
+    if (count) args(k_nn_accum<true, MODE == 0 ? 0 : 1, MODE == 0 ? 2 : 0>);
+    else args(k_nn_accum<false, MODE == 0 ? 0 : 1, MODE == 0 ? 2 : 0>);
+  } else {
+    if (count) args(k_nn_accum<true, MODE, 0>);
+    else args(k_nn_accum<false, MODE, 0>);
+  }
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
@@ -2533,12 +2759,12 @@ int launch_reduce(ma_ctx* ctx, bool with_rank = false) {
 }
 
 // the same sum plus the solve by the last-arriving workgroup, one launch
-int launch_reduce_solve(ma_ctx* ctx, double tol) {
+int launch_reduce_solve(ma_ctx* ctx, double tol, ListReport* report = nullptr) {
   hipLaunchKernelGGL(k_reduce_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
                      ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>(), ctx->ticket.as<uint32_t>(),
                      ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(),
-                     ctx->seg_order.as<uint32_t>(), ctx->last_gshift, tol > 0.0 ? ctx->host_done : (int*)nullptr,
-                     ctx->host_state_out);
+                     ctx->seg_order.as<uint32_t>(), ctx->last_gshift, (tol > 0.0 || ctx->lists_on) ? ctx->host_done : (int*)nullptr,
+                     ctx->host_state_out, ctx->listctl.as<ListCtl>(), report);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
@@ -2775,10 +3001,13 @@ int ma_create(int device, ma_ctx** out) {
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
   static_assert(sizeof(DevState) <= 256, "pinned state slots are 256 bytes apart");
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_done), 1024, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_done), 1280 + kMaxReports * sizeof(ListReport), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
   std::memset(ctx->host_done, 0, 1024);
   ctx->host_state_in = reinterpret_cast<DevState*>(reinterpret_cast<char*>(ctx->host_done) + 256);
   ctx->host_state_out = reinterpret_cast<DevState*>(reinterpret_cast<char*>(ctx->host_done) + 512);
+  static_assert(sizeof(ListCtl) <= 256 && sizeof(DevState) <= 256, "pinned block slots");
+  ctx->host_lc = reinterpret_cast<ListCtl*>(reinterpret_cast<char*>(ctx->host_done) + 1024);
+  ctx->host_reports = reinterpret_cast<ListReport*>(reinterpret_cast<char*>(ctx->host_done) + 1280);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), 2 * kMailBytes, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
   std::memset(ctx->mailbox, 0, 2 * kMailBytes);
   for (DevBuf* b : ctx->all_bufs()) b->stats = &ctx->mem;
@@ -3251,6 +3480,16 @@ static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, 
   // workgroup's queries share one small block of the gold grid under any rigid motion.
   const float c = clamp_cell_to_budget(lo, hi, gold_cell, kMaxCells);
   const GridP g = make_grid(lo, hi, ctx->origin, c);
+  {
+    double r2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      const double l = (double)lo[a] - ctx->origin[a], h = (double)hi[a] - ctx->origin[a], pad = 1e-4 + 1e-6 * (std::fabs(l) + std::fabs(h));
+      ctx->src_lo[a] = (float)(l - pad);
+      ctx->src_hi[a] = (float)(h + pad);
+      r2 += std::max(l * l, h * h);
+    }
+    ctx->src_rs = (float)(std::sqrt(r2) * 1.001 + 1e-4);
+  }
   HIPCHK(ctx->src.ensure((size_t)n * sizeof(float4)));
   HIPCHK(ctx->src_perm.ensure((size_t)n * 4));
   Lane sl = L;
@@ -3365,6 +3604,7 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   ctx->src_sorted = false;
   ctx->src_holes = total != npx;
   ctx->src_map_ready = false;
+  ctx->src_rs = 0.f;                  // no bounds of this cloud are known: its loop keeps searching (no candidate lists)
   ctx->have_src = true;
   return MA_OK;
   });
@@ -3647,14 +3887,92 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   }
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   if (timek) HIPCHK(hipEventRecord(ctx->kev[0], ctx->stream));
+  struct ListsScope { ma_ctx* c; ~ListsScope() { c->lists_on = false; } } lists_scope{ctx};
+  // Candidate lists (k_nn_accum<.,.,1|2>).  WHICH kernel an iteration launches is decided here, on the host, in
+  // batches of kPlan iterations: before batch b is enqueued the host waits until the last solve of batch b-2 has
+  // reported (batch b-1 stays queued behind it, so the device never idles) — how far that solve moved the cloud and
+  // how far the cloud has moved since the lists were written.  Every batch reports into its own pinned slot, so the
+  // values read are those of one fixed iteration whatever the device has done since: the plan is the same in every
+  // run.  It only has to be good, not right: a list launch proves every correspondence it takes from a list and
+  // searches for the others, and lists on / off give the same transform bit for bit (tools/lists_check.py).
+  const int n_batches = (params->max_iter + kPlan - 1) / kPlan;
+  ctx->lists_on = ctx->src_rs > 0.f && lists_enabled() && !early_exit && params->max_iter > 3 * kPlan && n_batches <= kMaxReports;
+  ctx->list_builds = ctx->list_uses = 0;
+  if (ctx->lists_on) for (int b = 0; b < n_batches; ++b) ctx->host_reports[b].iter = -1;
+  const double skin = (double)ctx->grid.c / (double)list_skin_div();
+  const double use_max = 0.49 * skin;      // a query passes its check while it has moved less than skin / 2
+  const double build_max = 0.25 * skin;    // a cloud still moving faster than this per iteration is not worth a list
+  constexpr int kMinUses = 5;              // a list launch saves ~9 us, writing the lists costs ~26: build for >= 5 uses
+  int plan[kPlan] = {0, 0, 0, 0};
+  bool lists_live = false;       // lists exist or are planned ...
+  int built_at = -1;             // ... written by the launch of this iteration
+  double step_before = -1.0;     // step reported by the batch before the one just read (for the decay rate)
   for (int k = 0; k < params->max_iter; ++k) {
     if (early_exit && k % kBatch == 0 && k >= 2 * kBatch) {
       HIPCHK(hipEventSynchronize(ctx->batch_ev[k / kBatch - 2]));
       if (*static_cast<volatile int*>(ctx->host_done)) break;
     }
-    if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr, MA_SCHED != 0))) return rc;
+    if (ctx->lists_on && k % kPlan == 0) {
+      for (int i = 0; i < kPlan; ++i) plan[i] = 0;
+      if (k >= 2 * kPlan) {
+        const ListReport& rep = ctx->host_reports[k / kPlan - 2];
+        const int expect = k - kPlan;              // iterations solved at the end of batch b-2
+        const auto t_wait = std::chrono::steady_clock::now();
+        bool ok = true;
+        while (rep.iter != expect) {               // spin: an event wait wakes up later than the queued batch lasts
+          if (*static_cast<volatile int*>(ctx->host_done)) { ok = false; break; }   // the loop stopped (degenerate)
+          if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(20)) { ok = false; break; }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const int j = expect - 1;                  // the iteration whose solve reported
+        const double step = rep.step, since_j = rep.since;
+        // decay of the step from batch to batch, per iteration; never assumed faster than 0.85 (it slows down as the
+        // clouds settle), never growing
+        double rho = 1.0;
+        if (step_before > 0.0 && step >= 0.0) rho = std::min(1.0, std::max(0.85, std::pow(step / step_before, 1.0 / kPlan)));
+        step_before = step;
+        auto step_at = [&](int n) { return step * std::pow(rho, n); };                               // bound on the step of iteration j + n
+        auto cum = [&](int n) { double a = 0; for (int i = 1; i <= n; ++i) a += step_at(i); return a; };   // motion over iterations j+1 .. j+n
+        if (!ok || !(step >= 0.0) || !std::isfinite(step)) {
+          lists_live = false;
+          ctx->lists_on = ok;                      // a stopped or silent loop: no more planning
+        } else if (step_at(k - j) > build_max) {
+          lists_live = false;                      // still moving too fast: search
+        } else {
+          if (lists_live && built_at <= j && !rep.have) lists_live = false;
+          for (int i = 0; i < kPlan && k + i < params->max_iter; ++i) {
+            const int kk = k + i;
+            // motion between the transform the lists were (or will be) written with and the one launch kk runs with
+            double since = INFINITY;
+            if (lists_live) since = built_at <= j ? since_j + cum(kk - j - 1) : cum(kk - j - 1) - cum(built_at - j - 1);
+            if (lists_live && since <= use_max) {
+              plan[i] = 2;
+              continue;
+            }
+            // write new lists here?  only if they will serve long enough
+            int uses = 0;
+            for (int n = 1; kk + n < params->max_iter && uses < kMinUses; ++n) {
+              if (cum(kk + n - j - 1) - cum(kk - j - 1) > use_max) break;
+              ++uses;
+            }
+            if (uses >= kMinUses) {
+              plan[i] = 1;
+              lists_live = true;
+              built_at = kk;
+            } else {
+              lists_live = false;
+            }
+          }
+        }
+      }
+    }
+    const int kind = ctx->lists_on ? plan[k % kPlan] : 0;
+    ctx->list_builds += kind == 1;
+    ctx->list_uses += kind == 2;
+    if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr, MA_SCHED != 0, kind))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
-    if ((rc = launch_reduce_solve(ctx, params->tol))) return rc;
+    ListReport* report = (ctx->lists_on && (k + 1) % kPlan == 0) ? &ctx->host_reports[k / kPlan] : nullptr;
+    if ((rc = launch_reduce_solve(ctx, params->tol, report))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 2], ctx->stream));
     if (early_exit && (k + 1) % kBatch == 0) HIPCHK(hipEventRecord(ctx->batch_ev[k / kBatch], ctx->stream));
   }
@@ -3681,6 +3999,13 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "no correspondence inside max_corr_dist, or rank-deficient covariance (fewer than 3 non-collinear pairs)");
   return MA_OK;
   });
+}
+
+int ma_get_list_stats(ma_ctx* ctx, int32_t out[2]) {
+  if (!ctx || !out) return MA_ERR_INVALID;
+  out[0] = ctx->list_builds;
+  out[1] = ctx->list_uses;
+  return MA_OK;
 }
 
 int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {

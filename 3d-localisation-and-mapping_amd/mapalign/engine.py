@@ -531,6 +531,12 @@ class MapAligner:
         return AlignResult(Tout, int(st.iterations), float(st.rmse), float(st.inliers), bool(st.converged),
                            float(st.gpu_ms), tr)
 
+    def list_stats(self):
+        """{builds, uses}: launches of the last icp() that wrote / read the per-query candidate lists."""
+        out = (C.c_int32 * 2)()
+        self._chk(self._lib.ma_get_list_stats(self._ctx, out))
+        return {"builds": int(out[0]), "uses": int(out[1])}
+
     def kernel_times(self):
         """{nn_ms, nn_launches, solve_ms, solve_launches} of the last icp(time_kernels=True)."""
         out = np.zeros(4, dtype=np.float64)

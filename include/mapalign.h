@@ -157,6 +157,12 @@ int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out);
  * (padded to whole XCD segments and scheduling groups) and threads (= points) per workgroup.  What a roofline
  * computation needs for the per-workgroup terms (19 fp64 partials each). */
 int ma_search_geometry(const ma_ctx* ctx, uint32_t* n_workgroups, uint32_t* block_threads);
+/* Candidate lists of the last ma_icp run (rows a4-a7): out = {launches that searched and wrote the
+ * per-query candidate lists, launches that read them instead of searching}.  Both 0 when the loop never came to rest
+ * enough for lists to pay, for a source cloud from a depth frame, or with MAPALIGN_LISTS=0 in the environment.
+ * Results do not depend on them: a list launch proves per query that the nearest neighbour is on its list
+ * (triangle inequality over the motion since the list was written) and searches where it cannot. */
+int ma_get_list_stats(ma_ctx* ctx, int32_t out[2]);
 /* Row N1 (coarse pre-alignment): number of valid points, centroid (frame of the coordinates handed in, minus the
  * large-coordinate shift if one is in force) and 3x3 sample covariance (row-major) of a cloud AS STORED on the
  * device: which = 0 the gold map, 1 the source cloud (holes of a depth frame are skipped).  out = {n, c[3], C[9]}.
