@@ -1047,7 +1047,7 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
 template <bool COUNT, bool BUILD>
 __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, const float4* __restrict__ gold0,
                                                 uint32_t& nchunk, uint32_t& ncand, const float skin,
-                                                uint32_t* __restrict__ lists_wave) {
+                                                uint32_t* __restrict__ lists_wave, const uint32_t list_plane) {
   for (uint32_t j0 = 0; j0 < nchunk; j0 += kWave) {
     const uint32_t j = j0 + lane;
     if (j < nchunk) {
@@ -1079,7 +1079,8 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
           if (BUILD) {
             if (d <= reach2 && t + (uint32_t)u < cnt) {      // real members of the chunk only
               const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(&W.pos[lq]) + 3, 1u);
-              if (slot < (uint32_t)kListLen) lists_wave[lq * kListLen + slot] = a + t + (uint32_t)u;
+              // entries 0-3 in the first plane (every list launch reads it), 4-7 in the second (read by the few queries with > 4)
+              if (slot < (uint32_t)kListLen) lists_wave[(slot < 4u ? 0u : list_plane - 4u) + lq * 4u + slot] = a + t + (uint32_t)u;
               else atomicMin(&W.minx[lq], __float_as_uint(d));
             }
           }
@@ -1097,7 +1098,7 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
 template <bool COUNT, bool BUILD>
 __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const LevelSet& S, uint32_t& nrow,
                                               uint32_t& nchunk, uint32_t& nrows_cnt, uint32_t& ncand, const float skin,
-                                              uint32_t* __restrict__ lists_wave) {
+                                              uint32_t* __restrict__ lists_wave, const uint32_t list_plane) {
   const float4* __restrict__ gold0 = S.gold[0];
   const uint32_t* __restrict__ cs0 = S.cs[0];
   const float inv_c = S.inv_c[0];
@@ -1146,7 +1147,7 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
         const unsigned long long mask = __ballot(has);
         if (mask == 0ull) break;
         const uint32_t cnt = (uint32_t)__popcll(mask);
-        if (nchunk + cnt > (uint32_t)kChunkCap) wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave);
+        if (nchunk + cnt > (uint32_t)kChunkCap) wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave, list_plane);
         if (has) {
           const uint32_t pos = nchunk + lane_prefix(mask), ca = a[u] + k * kChunkLen;
           W.chunk_a[pos] = ca;
@@ -1166,7 +1167,8 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
                                             const float py, const float pz, const LevelSet& S, float& best2,
                                             uint32_t& bestj, uint32_t& nrows_cnt, uint32_t& ncand,
                                             uint32_t& ndismissed, const float skin = 0.f,
-                                            uint32_t* __restrict__ lists_wave = nullptr, float* list_radius = nullptr) {
+                                            uint32_t* __restrict__ lists_wave = nullptr, float* list_radius = nullptr,
+                                            const uint32_t list_plane = 0) {
   const float c = S.c[0], inv_c = S.inv_c[0];
   const int nx = S.nx[0], ny = S.ny[0], nz = S.nz[0];
   const float4* __restrict__ gold0 = S.gold[0];
@@ -1192,7 +1194,7 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     const unsigned long long mask = __ballot(pred);
     const uint32_t cnt = (uint32_t)__popcll(mask);
     if (cnt == 0u) return;
-    if (nrow + cnt > (uint32_t)kRowCap) wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave);
+    if (nrow + cnt > (uint32_t)kRowCap) wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave, list_plane);
     if (pred) {
       const uint32_t pos = nrow + lane_prefix(mask);
       W.row_cell[pos] = (uint32_t)((z * ny + y) * nx);
@@ -1222,8 +1224,8 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
       push_row(finite && d2yz < bi, cy + dy, cz + dz, d2yz);
     }
   }
-  wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave);
-  wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave);
+  wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave, list_plane);
+  wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave, list_plane);
 #if MA_WGTIMES
   if (lane == 0) W.dbg_round0 = wall_clock64();
 #endif
@@ -1274,8 +1276,8 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
         push_row(more && d2yz < bi, cy + dy, cz + dz, d2yz);
       }
     }
-    wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave);
-    wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave);
+    wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave, list_plane);
+    wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave, list_plane);
     const unsigned long long key = W.best[lane];
     best2 = __uint_as_float((uint32_t)(key >> 32));
     bestj = (uint32_t)key;
@@ -1296,7 +1298,8 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     const uint32_t kept = min(cnt, (uint32_t)kListLen);
     if (has_query) {
       const uint32_t fill = bestj != kNoMatch ? bestj : 0u;     // any gold point may sit on a list: a superset stays exact
-      for (uint32_t sl = kept; sl < (uint32_t)kListLen; ++sl) lists_wave[lane * kListLen + sl] = fill;
+      for (uint32_t sl = kept; sl < 4u; ++sl) lists_wave[lane * 4u + sl] = fill;
+      if (kept > 4u) for (uint32_t sl = kept; sl < (uint32_t)kListLen; ++sl) lists_wave[list_plane - 4u + lane * 4u + sl] = fill;
     }
     *list_radius = isfinite(L) ? __uint_as_float((__float_as_uint(L) & ~0xFu) | kept) : L;
   }
@@ -1423,9 +1426,10 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     // inside the radius the list is complete for; a query that fails the check searches (per-lane, exact).
     if (has) {
       const bool finite = isfinite(px) && isfinite(py) && isfinite(pz);
-      const uint4* __restrict__ lp = reinterpret_cast<const uint4*>(lists) + 2 * (size_t)i;
-      const uint4 l0 = lp[0], l1 = lp[1];
+      const uint4 l0 = reinterpret_cast<const uint4*>(lists)[i];
       const float Lq = lrad[i];
+      const uint32_t nlist = __float_as_uint(Lq) & 0xFu;     // entries on the list; 5-8 live in the second plane
+      const uint32_t* __restrict__ lists_hi = lists + (size_t)gridDim.x * kNNBlock * 4u;
       // how far this query has moved since its list was written: (R - Rb) s + (t - tb), wave-uniform differences
       float dRf[9], dtf[3];
 #pragma unroll
@@ -1442,7 +1446,8 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       float d_pj = INFINITY;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {          // four gathers in flight at a time (eight cost 12 more registers)
-        const uint4 lh = h == 0 ? l0 : l1;
+        if (h == 1 && nlist <= 4u) break;
+        const uint4 lh = h == 0 ? l0 : reinterpret_cast<const uint4*>(lists_hi)[i];
         const uint32_t idx[4] = {lh.x, lh.y, lh.z, lh.w};
         float3 q[4];
 #pragma unroll
@@ -1459,7 +1464,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       if (d_pj < best2_init && __float_as_uint(d_pj) == (uint32_t)(key >> 32)) key = pack_best(d_pj, pj);
       best2 = __uint_as_float((uint32_t)(key >> 32));
       bestj = (uint32_t)key;
-      if (COUNT) ncand += __float_as_uint(Lq) & 0xFu;
+      if (COUNT) ncand += nlist;
       if (!finite) {
         bestj = kNoMatch;
       } else if (!(fast_sqrt(best2) + moved < Lq)) {
@@ -1469,7 +1474,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   } else if constexpr (lmode == 1) {
     float Lr = 0.f;
     wave_search<COUNT, true>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand, ndismissed, lc->skin,
-                             lists + (size_t)(i - (uint32_t)lane) * kListLen, &Lr);
+                             lists + (size_t)(i - (uint32_t)lane) * 4u, &Lr, gridDim.x * (uint32_t)kNNBlock * 4u);
     if (has) lrad[i] = Lr;
     if (blockIdx.x == 0 && threadIdx.x == 0) {      // the transform these lists belong to
       ListCtl* __restrict__ w = const_cast<ListCtl*>(lc);

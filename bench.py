@@ -144,6 +144,9 @@ def algorithmic_bytes(trace, n_src, n_blocks):
     the launches of one step."""
     words, cands, matched = trace[:, 18], trace[:, 19], trace[:, 0]
     per_launch = 24.0 * n_src + 4.0 * words + 12.0 * cands + 12.0 * matched + 19 * 8.0 * n_blocks
+    # a list launch (no table word read: DESIGN.md 5) reads 16 B of list + 4 B of radius per point instead; the second
+    # plane of the lists (queries with 5-8 entries) and what a list-writing launch stores are left out (understates)
+    per_launch = per_launch + np.where(words == 0, 20.0 * n_src, 0.0)
     # SURVEY.md 8d's literal formula — 12 N (source xyz) + 4 per table word + 12 C — without the storage actually
     # used (float4 source points), the remembered-match words and the winner re-read: the strictest reading
     strict = 12.0 * n_src + 4.0 * words + 12.0 * cands
@@ -687,6 +690,8 @@ def main():
                     "compulsory_bytes_per_launch": 24.0 * len(comp) + 16.0 * len(gold),
                     "compulsory_frac": (24.0 * len(comp) + 16.0 * len(gold)) / t_launch_s / 1e9 / HBM_PEAK_GBPS,
                     "solve_kernel_us": kt["solve_ms"] / max(kt["solve_launches"], 1) * 1e3,
+                    # launches of the 50 that wrote / read the per-query candidate lists instead of only searching
+                    "list_launches": eng.list_stats(),
                     "timed_loop_it_per_s": ITERS / (res_t.gpu_ms * 1e-3)}
         cpu = parity = e2e = None
         extra = {}

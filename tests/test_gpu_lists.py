@@ -1,0 +1,106 @@
+"""Candidate lists of the loop (rows a4-a7; DESIGN.md 5 "list launches"): once the transform moves the cloud by less than a
+fraction of a cell per iteration, a search launch also writes, per query, every gold point within (match distance + skin),
+and the following launches read those lists instead of searching.  Every correspondence taken from a list is proved by the
+triangle inequality, so the results must be those of the searching loop BIT FOR BIT — that is what is tested here, with
+``MAPALIGN_LISTS=0`` (every launch searches) as the other arm — and against the CPU oracle."""
+import numpy as np
+import pytest
+
+import mapalign
+from mapalign import synthetic as syn
+from oracle import icp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(engine, monkeypatch, iters, gate=0.10, **kw):
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MAPALIGN_LISTS", mode)
+        res = engine.icp(iters, 0.0, gate, with_trace=True, **kw)
+        out[mode] = (res, engine.list_stats())
+    return out["1"], out["0"]
+
+
+def test_list_launches_equal_the_searching_loop_bitwise_and_the_oracle(engine, monkeypatch):
+    # a start close enough for the loop to come to rest well inside the 60 iterations
+    gold, comp, R0, t0 = syn.make_pair(11, 120_000, 100_000, angle_deg=0.4, t0=(0.02, -0.015, 0.01))
+    engine.set_pair(gold, comp)
+    (on, s_on), (off, s_off) = _both(engine, monkeypatch, 60)
+    assert s_off == {"builds": 0, "uses": 0}
+    assert s_on["builds"] >= 1 and s_on["uses"] >= 10, s_on
+    assert np.array_equal(on.T, off.T)
+    assert np.array_equal(on.trace[:, :18], off.trace[:, :18])          # all 17 sums and the rmse of every iteration
+    assert on.inliers == off.inliers and on.iterations == off.iterations == 60
+    # the same run twice, and in a fresh context: same plan, same bits
+    monkeypatch.setenv("MAPALIGN_LISTS", "1")
+    again = engine.icp(60, 0.0, 0.10, with_trace=True)
+    assert np.array_equal(again.T, on.T) and np.array_equal(again.trace, on.trace) and engine.list_stats() == s_on
+    with mapalign.MapAligner(0) as other:
+        other.set_pair(gold, comp)
+        c = other.icp(60, 0.0, 0.10, with_trace=True)
+        assert np.array_equal(c.T, on.T) and other.list_stats() == s_on
+    ref = orc.icp_oracle(gold, comp, max_iter=60, max_corr_dist=0.10, n_jobs=8)
+    eR, et = orc.rt_error(on.R, on.t, ref["R"], ref["t"])
+    assert eR <= 1e-5 and et <= 1e-5, (eR, et)        # fp32-stored coordinates against the fp64 oracle, as for the searching loop
+    assert abs(on.inliers - ref["inliers"]) <= 1
+
+
+def test_list_launches_with_weights_unmatched_points_and_a_narrow_gate(engine, monkeypatch):
+    """Queries without a gold point inside the gate keep proving that (their list is complete out to gate + skin), weights
+    ride along, and points that sit at the edge of the gate may enter or leave it while the lists are in use."""
+    rng = np.random.default_rng(5)
+    gold, comp, _, _ = syn.make_pair(12, 90_000, 80_000, angle_deg=0.3, t0=(0.015, 0.01, -0.01))
+    stray = comp[rng.choice(len(comp), 6000, replace=False)] + rng.normal(0.0, 0.06, (6000, 3)).astype(np.float32)
+    far = comp[rng.choice(len(comp), 3000, replace=False)] + np.float32(0.5)
+    comp2 = np.concatenate([comp, stray, far]).astype(np.float32)
+    w = rng.uniform(0.2, 2.0, len(comp2)).astype(np.float32)
+    w[rng.choice(len(w), 500, replace=False)] = 0.0
+    engine.set_gold(gold)
+    engine.set_source(comp2, weights=w)
+    for gate in (0.10, 0.04):
+        (on, s_on), (off, _) = _both(engine, monkeypatch, 48, gate=gate)
+        assert s_on["uses"] >= 8, (gate, s_on)
+        assert np.array_equal(on.T, off.T) and np.array_equal(on.trace[:, :18], off.trace[:, :18]), gate
+        assert 0 < on.inliers < float(w.sum())
+
+
+def test_list_launches_count_their_work_and_keep_results(engine, monkeypatch):
+    gold, comp, _, _ = syn.make_pair(13, 60_000, 60_000, angle_deg=0.3, t0=(0.01, 0.01, 0.01))
+    engine.set_pair(gold, comp)
+    monkeypatch.setenv("MAPALIGN_LISTS", "1")
+    a = engine.icp(40, 0.0, 0.10, with_trace=True)
+    st = engine.list_stats()
+    b = engine.icp(40, 0.0, 0.10, with_trace=True, count_work=True)
+    assert engine.list_stats() == st and st["uses"] >= 8
+    assert np.array_equal(a.T, b.T) and np.array_equal(a.trace[:, :18], b.trace[:, :18])
+    listed = b.trace[:, 18] == 0                 # a list launch reads no grid-table word ...
+    assert int(listed.sum()) == st["uses"]
+    per_query = b.trace[listed, 19] / len(comp)  # ... and examines the 1-8 gold points on each list
+    assert (per_query >= 1.0).all() and (per_query <= 8.0).all()
+    assert (b.trace[~listed, 18] > 0).all()
+
+
+def test_no_lists_for_short_runs_depth_sources_and_tolerance_runs(engine, monkeypatch):
+    monkeypatch.setenv("MAPALIGN_LISTS", "1")
+    gold, comp, _, _ = syn.make_pair(14, 50_000, 40_000, angle_deg=0.2, t0=(0.01, 0.0, 0.0))
+    engine.set_pair(gold, comp)
+    engine.icp(12, 0.0, 0.10)
+    assert engine.list_stats() == {"builds": 0, "uses": 0}          # three planning batches or fewer
+    engine.icp(60, 1e-7, 0.10)
+    assert engine.list_stats() == {"builds": 0, "uses": 0}          # a convergence test stops the loop in its own batches
+    depth, K, T = syn.make_depth_frame(0, width=320, height=240, fx=250.0, fy=250.0, cx=159.5, cy=119.5)
+    engine.set_source_from_depth(depth, K, T, 1000.0)
+    engine.icp(40, 0.0, 0.10)
+    assert engine.list_stats() == {"builds": 0, "uses": 0}          # no bounding box of an unprojected frame is known
+
+
+def test_a_loop_that_stops_degenerate_does_not_leave_the_planner_waiting(engine, monkeypatch):
+    monkeypatch.setenv("MAPALIGN_LISTS", "1")
+    gold, comp, _, _ = syn.make_pair(15, 20_000, 20_000)
+    engine.set_gold(gold)
+    engine.set_source(comp + np.float32(50.0))                      # nothing inside the gate: the first solve stops the loop
+    with pytest.raises(mapalign.MapAlignError):
+        engine.icp(40, 0.0, 0.10)
+    engine.set_source(comp)                                         # and the context works on
+    assert engine.icp(40, 0.0, 0.10).iterations == 40

@@ -34,9 +34,13 @@ print("   nn us/iteration, lists on : " + " ".join("%%.0f" %% (v * 1e3) for v in
 print("   nn us/iteration, lists off: " + " ".join("%%.0f" %% (v * 1e3) for v in off[3][:, 0]))
 print("   solve us mean on %%.2f off %%.2f" %% (on[3][:, 1].mean() * 1e3, off[3][:, 1].mean() * 1e3), flush=True)
 ''' % (ROOT, n)
+skins = [a for a in sys.argv[2:]]          # optional: skin divisors to sweep with the default build (MAPALIGN_SKIN_DIV)
 for rep in range(2):
     for nm in names:
         env = dict(os.environ, VAR=nm or "default")
         if nm:
             env["MAPALIGN_LIB"] = os.path.join(libdir, f"libmapalign_{nm}.so")
+        subprocess.run([sys.executable, "-c", code], env=env, check=False, timeout=300)
+    for sk in skins:
+        env = dict(os.environ, VAR=f"skin/{sk}", MAPALIGN_SKIN_DIV=sk)
         subprocess.run([sys.executable, "-c", code], env=env, check=False, timeout=300)
