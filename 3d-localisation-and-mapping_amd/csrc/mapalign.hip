@@ -2333,10 +2333,12 @@ struct ma_ctx {
   DevBuf lists, lrad, listctl;
   float src_rs = 0.f;                          // largest distance of a corner of the source cloud's box from the centring origin; 0: unknown, no lists
   float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // that box (centred frame)
+  bool src_box_pending = false;                // source from a depth frame: the box is computed by the first run that can use it
   bool lists_on = false;                       // set by ma_icp around its loop
   ListCtl* host_lc = nullptr;                  // pinned: the control block a run starts from
   ListReport* host_reports = nullptr;          // pinned, kMaxReports slots: what the last solve of each planning batch reports
   int list_builds = 0, list_uses = 0;          // launches of the last ma_icp that wrote / read the lists
+  std::vector<uint8_t> list_plan;              // per iteration of the last ma_icp: 0 searched, 1 searched and wrote the lists, 2 read them
   // The stepping state (DevState, prev[], partials, ...) is sized for the clouds that were set
   // when it was uploaded; installing another gold map or source cloud invalidates it
   // (ma_step_accumulate / ma_step_solve then return MA_ERR_STATE until ma_state_set).
@@ -3494,6 +3496,7 @@ static int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, 
       r2 += std::max(l * l, h * h);
     }
     ctx->src_rs = (float)(std::sqrt(r2) * 1.001 + 1e-4);
+    ctx->src_box_pending = false;
   }
   HIPCHK(ctx->src.ensure((size_t)n * sizeof(float4)));
   HIPCHK(ctx->src_perm.ensure((size_t)n * 4));
@@ -3609,7 +3612,8 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   ctx->src_sorted = false;
   ctx->src_holes = total != npx;
   ctx->src_map_ready = false;
-  ctx->src_rs = 0.f;                  // no bounds of this cloud are known: its loop keeps searching (no candidate lists)
+  ctx->src_rs = 0.f;                  // no bounds of this cloud are known yet: ma_icp finds them when a run is long enough for candidate lists
+  ctx->src_box_pending = true;
   ctx->have_src = true;
   return MA_OK;
   });
@@ -3865,6 +3869,20 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = ensure_levels_for(ctx, params->max_corr_dist))) return rc;
   if ((rc = ensure_loop_buffers(ctx, params->max_iter))) return rc;
+  if (ctx->src_box_pending && lists_enabled() && !(params->tol > 0.0) && params->max_iter > 3 * kPlan) {
+    // a source cloud from a depth frame: its box (stored, centred coordinates; holes skipped) for the candidate lists
+    float lo[3], hi[3];
+    if ((rc = cloud_bounds(ctx, ctx->src.as<float>(), ctx->n, lo, hi, 4, true))) return rc;
+    double r2 = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      const double pad = 1e-4 + 1e-6 * (std::fabs((double)lo[a]) + std::fabs((double)hi[a]));
+      ctx->src_lo[a] = (float)((double)lo[a] - pad);
+      ctx->src_hi[a] = (float)((double)hi[a] + pad);
+      r2 += std::max((double)lo[a] * lo[a], (double)hi[a] * hi[a]);
+    }
+    ctx->src_rs = (float)(std::sqrt(r2) * 1.001 + 1e-4);
+    ctx->src_box_pending = false;
+  }
   if ((rc = upload_state(ctx, init))) return rc;
   const float best2 = open_gate2(params->max_corr_dist);
   const bool timek = (params->flags & MA_FLAG_TIME_KERNELS) != 0;
@@ -3903,6 +3921,7 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   const int n_batches = (params->max_iter + kPlan - 1) / kPlan;
   ctx->lists_on = ctx->src_rs > 0.f && lists_enabled() && !early_exit && params->max_iter > 3 * kPlan && n_batches <= kMaxReports;
   ctx->list_builds = ctx->list_uses = 0;
+  ctx->list_plan.clear();
   if (ctx->lists_on) for (int b = 0; b < n_batches; ++b) ctx->host_reports[b].iter = -1;
   const double skin = (double)ctx->grid.c / (double)list_skin_div();
   const double use_max = 0.49 * skin;      // a query passes its check while it has moved less than skin / 2
@@ -3974,6 +3993,7 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
     const int kind = ctx->lists_on ? plan[k % kPlan] : 0;
     ctx->list_builds += kind == 1;
     ctx->list_uses += kind == 2;
+    ctx->list_plan.push_back((uint8_t)kind);
     if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr, MA_SCHED != 0, kind))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
     ListReport* report = (ctx->lists_on && (k + 1) % kPlan == 0) ? &ctx->host_reports[k / kPlan] : nullptr;
@@ -4011,6 +4031,13 @@ int ma_get_list_stats(ma_ctx* ctx, int32_t out[2]) {
   out[0] = ctx->list_builds;
   out[1] = ctx->list_uses;
   return MA_OK;
+}
+
+int ma_get_list_plan(ma_ctx* ctx, uint8_t* kinds, int max_iterations) {
+  if (!ctx || !kinds || max_iterations < 0) return MA_ERR_INVALID;
+  const int n = std::min<int>(max_iterations, (int)ctx->list_plan.size());
+  for (int i = 0; i < n; ++i) kinds[i] = ctx->list_plan[(size_t)i];
+  return n;
 }
 
 int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {

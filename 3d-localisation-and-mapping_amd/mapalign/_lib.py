@@ -114,6 +114,7 @@ ABI = {
     "ma_mem_info_get": (C.c_int, [_ctx_p, C.POINTER(ma_mem_info)]),
     "ma_search_geometry": (C.c_int, [_ctx_p, _u32p, _u32p]),
     "ma_get_list_stats": (C.c_int, [_ctx_p, C.POINTER(C.c_int32)]),
+    "ma_get_list_plan": (C.c_int, [_ctx_p, C.POINTER(C.c_uint8), C.c_int]),
     "ma_cloud_moments": (C.c_int, [_ctx_p, C.c_int, _f64p]),
     "ma_last_device_ms": (C.c_int, [_ctx_p, _f64p]),
     "ma_lift_boxes_batch": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, _f32p, _f64p,

@@ -537,6 +537,12 @@ class MapAligner:
         self._chk(self._lib.ma_get_list_stats(self._ctx, out))
         return {"builds": int(out[0]), "uses": int(out[1])}
 
+    def list_plan(self, max_iterations=4096):
+        """Per iteration of the last icp(): 0 searched, 1 searched and wrote the candidate lists, 2 read them."""
+        buf = np.zeros(max(int(max_iterations), 1), dtype=np.uint8)
+        n = self._chk(self._lib.ma_get_list_plan(self._ctx, buf.ctypes.data_as(C.POINTER(C.c_uint8)), buf.shape[0]))
+        return buf[:n].copy()
+
     def kernel_times(self):
         """{nn_ms, nn_launches, solve_ms, solve_launches} of the last icp(time_kernels=True)."""
         out = np.zeros(4, dtype=np.float64)

@@ -163,6 +163,10 @@ int ma_search_geometry(const ma_ctx* ctx, uint32_t* n_workgroups, uint32_t* bloc
  * Results do not depend on them: a list launch proves per query that the nearest neighbour is on its list
  * (triangle inequality over the motion since the list was written) and searches where it cannot. */
 int ma_get_list_stats(ma_ctx* ctx, int32_t out[2]);
+/* What each iteration of the last ma_icp run launched: 0 a search, 1 a search that also wrote the candidate lists,
+ * 2 a list launch.  Returns the number of entries written (<= max_iterations; launches enqueued, which for a loop that
+ * stopped early may exceed the iterations performed) or a negative status. */
+int ma_get_list_plan(ma_ctx* ctx, uint8_t* kinds, int max_iterations);
 /* Row N1 (coarse pre-alignment): number of valid points, centroid (frame of the coordinates handed in, minus the
  * large-coordinate shift if one is in force) and 3x3 sample covariance (row-major) of a cloud AS STORED on the
  * device: which = 0 the gold map, 1 the source cloud (holes of a depth frame are skipped).  out = {n, c[3], C[9]}.

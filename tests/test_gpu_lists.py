@@ -74,14 +74,17 @@ def test_list_launches_count_their_work_and_keep_results(engine, monkeypatch):
     b = engine.icp(40, 0.0, 0.10, with_trace=True, count_work=True)
     assert engine.list_stats() == st and st["uses"] >= 8
     assert np.array_equal(a.T, b.T) and np.array_equal(a.trace[:, :18], b.trace[:, :18])
-    listed = b.trace[:, 18] == 0                 # a list launch reads no grid-table word ...
-    assert int(listed.sum()) == st["uses"]
-    per_query = b.trace[listed, 19] / len(comp)  # ... and examines the 1-8 gold points on each list
-    assert (per_query >= 1.0).all() and (per_query <= 8.0).all()
-    assert (b.trace[~listed, 18] > 0).all()
+    plan = engine.list_plan()
+    assert len(plan) == 40 and int((plan == 2).sum()) == st["uses"] and int((plan == 1).sum()) == st["builds"]
+    listed = plan == 2
+    # a list launch examines the 1-8 gold points on each list and reads grid-table words only for the few queries that
+    # fail their check and search; a search launch reads several words for every query
+    per_query = b.trace[listed, 19] / len(comp)
+    assert (per_query >= 1.0).all() and (per_query <= 8.5).all()
+    assert (b.trace[listed, 18] < 0.5 * len(comp)).all() and (b.trace[~listed, 18] > 3.0 * len(comp)).all()
 
 
-def test_no_lists_for_short_runs_depth_sources_and_tolerance_runs(engine, monkeypatch):
+def test_no_lists_for_short_runs_and_tolerance_runs(engine, monkeypatch):
     monkeypatch.setenv("MAPALIGN_LISTS", "1")
     gold, comp, _, _ = syn.make_pair(14, 50_000, 40_000, angle_deg=0.2, t0=(0.01, 0.0, 0.0))
     engine.set_pair(gold, comp)
@@ -89,10 +92,24 @@ def test_no_lists_for_short_runs_depth_sources_and_tolerance_runs(engine, monkey
     assert engine.list_stats() == {"builds": 0, "uses": 0}          # three planning batches or fewer
     engine.icp(60, 1e-7, 0.10)
     assert engine.list_stats() == {"builds": 0, "uses": 0}          # a convergence test stops the loop in its own batches
+
+
+def test_list_launches_on_a_source_cloud_from_a_depth_frame(engine, monkeypatch):
+    """configs[2]'s shape: one slot per pixel, holes where the depth is invalid; the cloud's box is found by the first run
+    that is long enough to use it."""
     depth, K, T = syn.make_depth_frame(0, width=320, height=240, fx=250.0, fy=250.0, cx=159.5, cy=119.5)
-    engine.set_source_from_depth(depth, K, T, 1000.0)
-    engine.icp(40, 0.0, 0.10)
-    assert engine.list_stats() == {"builds": 0, "uses": 0}          # no bounding box of an unprojected frame is known
+    depth = depth.copy()
+    depth[::7, ::5] = 0.0                                            # holes
+    gold, _, _, _ = syn.make_pair(0, 200_000)
+    engine.set_gold(gold)
+    dT = np.eye(4)
+    dT[:3, :3] = syn.rotation_about_axis([0.2, 1.0, 0.1], np.deg2rad(0.2))
+    dT[:3, 3] = [0.01, -0.01, 0.01]
+    n = engine.set_source_from_depth(depth, K, dT @ T, 1000.0)
+    assert 0 < n < depth.size
+    (on, s_on), (off, s_off) = _both(engine, monkeypatch, 48)
+    assert s_off == {"builds": 0, "uses": 0} and s_on["uses"] >= 4, s_on
+    assert np.array_equal(on.T, off.T) and np.array_equal(on.trace[:, :18], off.trace[:, :18])
 
 
 def test_a_loop_that_stops_degenerate_does_not_leave_the_planner_waiting(engine, monkeypatch):

@@ -11,4 +11,11 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=
         gaps.append((int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3)
     last = nn[-50:]
     print("nn last-run per-iteration us:", " ".join(f"{x:.0f}" for x in last))
+    kind = lambda nm: "L" if ", 0, 2>" in nm else ("W" if ", 0, 1>" in nm else "S")      # k_nn_accum<COUNT, MODE, LISTS>: search / search + write lists / list launch
+    kinds = [kind(r["Kernel_Name"]) for r in rows if "k_nn_accum" in r["Kernel_Name"]][-50:]
+    print("launch kinds (S search, W search + write lists, L list launch):", "".join(kinds))
+    for kd in "SWL":
+        v = [x for x, y in zip(last, kinds) if y == kd]
+        if v:
+            print(f"  {kd}: {len(v)} launches, mean {sum(v) / len(v):.1f} us")
     print("nn mean %.1f  solve mean %.1f (n=%d)  median gap %.2f us" % (sum(last) / len(last), sum(sv[-50:]) / 50, len(sv), sorted(gaps[-99:])[49]))

@@ -14,7 +14,11 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recu
     for (did, k), vals in per_disp.items():
         by_kernel[k].append(vals)
     for k, lst in by_kernel.items():
-        short = "k_nn_accum" if "k_nn_accum" in k else ("k_reduce19" if "k_reduce19" in k else ("k_solve" if "k_solve" in k else None))
+        short = None
+        if "k_nn_accum<" in k:
+            short = k[k.index("k_nn_accum<"):k.index(">", k.index("k_nn_accum<")) + 1]      # one entry per instantiation (search / write lists / read lists)
+        elif "k_reduce19" in k or "k_solve" in k:
+            short = "k_reduce19" if "k_reduce19" in k else "k_solve"
         if not short:
             continue
         lst = lst[-50:]
