@@ -2671,6 +2671,11 @@ int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
   HIPCHK(ctx->acc19.ensure(kNAcc * sizeof(double)));
   HIPCHK(ctx->wg_cost.ensure((size_t)grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(uint32_t)));
   HIPCHK(ctx->listctl.ensure(sizeof(ListCtl)));
+  if (ctx->have_src && lists_enabled()) {      // candidate lists: sized with the other loop buffers, so that no later run allocates
+    const size_t slots = (size_t)grid_for(std::max<uint32_t>(ctx->n, 1)) * kNNBlock;
+    HIPCHK(ctx->lists.ensure(slots * kListLen * sizeof(uint32_t)));
+    HIPCHK(ctx->lrad.ensure(slots * sizeof(float)));
+  }
   if (!ctx->seg_order.p) {  // never read before the first ranking wrote it (order is used from iteration 1 on); zeroed anyway
     HIPCHK(ctx->seg_order.ensure((size_t)kMaxGroups * sizeof(uint32_t)));
     HIPCHK(hipMemsetAsync(ctx->seg_order.p, 0, (size_t)kMaxGroups * sizeof(uint32_t), ctx->stream));
