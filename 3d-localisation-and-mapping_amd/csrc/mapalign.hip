@@ -72,7 +72,7 @@ constexpr uint32_t kHoleBitsEarly = 0x7FC00000u;   // = kHoleBits (k_unproject):
 // in that list (triangle inequality, checked per query), and the launch reads 8 indices instead of searching.
 constexpr int kListLen = 8;
 constexpr int kPlan = 4;             // iterations per planning batch of ma_icp
-constexpr int kMaxReports = 1024;    // planning batches a run can report (longer runs search after that)
+constexpr int kMaxSlots = 4096;      // iterations of a run whose states the planner can read (longer runs search after that)
 struct ListCtl {
   int have;          // lists exist (written by the launch that ran with the transform Rb, tb)
   float skin;        // metres
@@ -81,14 +81,31 @@ struct ListCtl {
   float slack;       // rounding allowance of the per-query displacement, metres
   double Rb[9], tb[3];
 };
-// What the last solve of a planning batch leaves in pinned host memory for the host's planner (one slot per batch, so
-// that the host reads the values of one fixed iteration whatever the device has done since): bounds on how far that
-// solve moved any point of the source cloud, and on how far the cloud has moved since the lists were written.
-struct ListReport {
-  double step, since;
-  int have;
-  volatile int iter;    // written last: iterations solved; the host spins on it
+// What every solve of a loop that may use lists leaves in pinned host memory for the host's planner: the state it
+// produced, in a slot of its own (iteration k -> slot k), so that the host reads the transform of a fixed iteration
+// whatever the device has done since.  Posted writes: the solve does not wait for them.
+struct StateSlot {
+  ma::DevState s;
+  volatile unsigned long long chk;   // slot_check(R, t, seq): the host takes a slot only when it matches what it reads —
+  volatile int seq;                  // iterations solved (= s.iter) — so the solve needs no fence between the posted writes
+  int pad;                           // (a system-scope fence there cost 1.4 us of every iteration)
 };
+__host__ __device__ inline unsigned long long slot_check(const double* R, const double* t, int seq);
+// host: has the solve of iteration `want - 1` written this slot completely?  (every field read through volatile)
+inline bool slot_ready(const volatile StateSlot* sl, int want);
+__host__ __device__ inline unsigned long long slot_check(const double* R, const double* t, int seq) {
+  unsigned long long x = (unsigned long long)(unsigned)seq * 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < 9; ++i) { unsigned long long b; memcpy(&b, &R[i], 8); x = (x << 7 | x >> 57) ^ b; }
+  for (int i = 0; i < 3; ++i) { unsigned long long b; memcpy(&b, &t[i], 8); x = (x << 7 | x >> 57) ^ b; }
+  return x;
+}
+inline bool slot_ready(const volatile StateSlot* sl, int want) {
+  if (sl->seq != want) return false;
+  double R[9], t[3];
+  for (int i = 0; i < 9; ++i) R[i] = sl->s.R[i];
+  for (int i = 0; i < 3; ++i) t[i] = sl->s.t[i];
+  return sl->chk == slot_check(R, t, want);
+}
 
 // plain structs and host arithmetic shared with the CPU-side sanitizer test (host_math.h)
 using ma::DevState;
@@ -1681,11 +1698,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ 
 __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0, DevState* __restrict__ st,
                                            double* __restrict__ trace, const int trace_cap, const double tol,
                                            int* __restrict__ host_done, DevState* __restrict__ host_mirror = nullptr,
-                                           const ListCtl* __restrict__ lc = nullptr,
-                                           ListReport* __restrict__ report = nullptr) {
-  ListCtl lc0;
-  if (report) lc0 = *lc;      // read beside everything else, needed at the very end
-  const DevState s_in = s0;   // the transform this iteration's search launch ran with
+                                           StateSlot* __restrict__ slot = nullptr) {
   const int it = s0.iter;
   const double W = a[0];
   const double rmse = W > 0.0 ? sqrt(a[16] / W) : NAN;
@@ -1727,36 +1740,15 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
   }
   s0.prev_rmse = rmse;
   *st = s0;
-  if (report) {
-    // Last solve of a planning batch: tell the host how far this solve moved the cloud and how far it has moved
-    // since the candidate lists were written.  |(Ra - Rb) s + (ta - tb)| is convex in s, so over the source cloud's
-    // bounding box it is largest at one of the eight corners: an exact bound for the box, evaluated there.
-    auto moved = [&](const double* Ra, const double* ta, const double* Rb, const double* tb) -> double {
-      double d[9], v[3], m2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) d[i] = Ra[i] - Rb[i];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) v[r] = ta[r] - tb[r];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const double x = (c & 1) ? (double)lc0.bhi[0] : (double)lc0.blo[0];
-        const double y = (c & 2) ? (double)lc0.bhi[1] : (double)lc0.blo[1];
-        const double z = (c & 4) ? (double)lc0.bhi[2] : (double)lc0.blo[2];
-        const double a = d[0] * x + d[1] * y + d[2] * z + v[0], b = d[3] * x + d[4] * y + d[5] * z + v[1],
-                     e = d[6] * x + d[7] * y + d[8] * z + v[2];
-        m2 = fmax(m2, a * a + b * b + e * e);
-      }
-      return sqrt(m2);
-    };
-    report->step = moved(s0.R, s0.t, s_in.R, s_in.t);
-    report->since = lc0.have ? moved(s0.R, s0.t, lc0.Rb, lc0.tb) : INFINITY;
-    report->have = lc0.have;
-    __threadfence_system();
-    report->iter = s0.iter;
-  }
   // pinned host copy of the state (ma_icp): written with every solve, read by the host after its one
   // synchronisation — no device-to-host copy at the end of the loop (posted writes: the solve does not wait for them)
   if (host_mirror) *host_mirror = s0;
+  if (slot) {      // candidate lists: host_mirror is this iteration's own pinned slot, and the host's planner reads it (ma_icp)
+    // plain stores (the fields are volatile for the HOST's reads): a volatile store makes the wavefront wait for the
+    // posted write to be acknowledged, 0.7 us each; the checksum makes their order irrelevant
+    *const_cast<unsigned long long*>(&slot->chk) = slot_check(s0.R, s0.t, s0.iter);
+    *const_cast<int*>(&slot->seq) = s0.iter;
+  }
 }
 
 // The solve alone (sharded-source stepping: the 17 sums come back from the all-reduce).
@@ -1789,7 +1781,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
                                                          const uint32_t* __restrict__ wg_cost,
                                                          uint32_t* __restrict__ order, const uint32_t gshift,
                                                          int* __restrict__ host_done, DevState* __restrict__ host_mirror,
-                                                         const ListCtl* __restrict__ lc, ListReport* __restrict__ report) {
+                                                         StateSlot* __restrict__ slot) {
   // `done` is written only by the last arriver, after every workgroup has read it.  It is
   // tested AFTER the first loads have been issued: every dependent memory round trip of
   // this small kernel is ~1 us of the iteration.
@@ -1845,7 +1837,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   asm volatile("" :: "v"(a[0]), "v"(a[18]));
   if (dbg_it < 64) g_rs[dbg_it][k][3] = wall_clock64();
 #endif
-  solve_step(a, s0, st, trace, trace_cap, tol, host_done, host_mirror, lc, report);
+  solve_step(a, s0, st, trace, trace_cap, tol, host_done, host_mirror, slot);
 #if MA_WGTIMES
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (dbg_it < 64) g_rs[dbg_it][k][4] = wall_clock64();
@@ -2336,7 +2328,7 @@ struct ma_ctx {
   bool src_box_pending = false;                // source from a depth frame: the box is computed by the first run that can use it
   bool lists_on = false;                       // set by ma_icp around its loop
   ListCtl* host_lc = nullptr;                  // pinned: the control block a run starts from
-  ListReport* host_reports = nullptr;          // pinned, kMaxReports slots: what the last solve of each planning batch reports
+  StateSlot* host_slots = nullptr;             // pinned, kMaxSlots slots: the state every solve of a list-planning loop produced
   int list_builds = 0, list_uses = 0;          // launches of the last ma_icp that wrote / read the lists
   std::vector<uint8_t> list_plan;              // per iteration of the last ma_icp: 0 searched, 1 searched and wrote the lists, 2 read them
   // The stepping state (DevState, prev[], partials, ...) is sized for the clouds that were set
@@ -2771,12 +2763,12 @@ int launch_reduce(ma_ctx* ctx, bool with_rank = false) {
 }
 
 // the same sum plus the solve by the last-arriving workgroup, one launch
-int launch_reduce_solve(ma_ctx* ctx, double tol, ListReport* report = nullptr) {
+int launch_reduce_solve(ma_ctx* ctx, double tol, StateSlot* slot = nullptr) {
   hipLaunchKernelGGL(k_reduce_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
                      ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>(), ctx->ticket.as<uint32_t>(),
                      ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(),
                      ctx->seg_order.as<uint32_t>(), ctx->last_gshift, (tol > 0.0 || ctx->lists_on) ? ctx->host_done : (int*)nullptr,
-                     ctx->host_state_out, ctx->listctl.as<ListCtl>(), report);
+                     slot ? &slot->s : ctx->host_state_out, slot);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
@@ -3013,13 +3005,13 @@ int ma_create(int device, ma_ctx** out) {
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
   static_assert(sizeof(DevState) <= 256, "pinned state slots are 256 bytes apart");
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_done), 1280 + kMaxReports * sizeof(ListReport), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_done), 1280 + kMaxSlots * sizeof(StateSlot), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
   std::memset(ctx->host_done, 0, 1024);
   ctx->host_state_in = reinterpret_cast<DevState*>(reinterpret_cast<char*>(ctx->host_done) + 256);
   ctx->host_state_out = reinterpret_cast<DevState*>(reinterpret_cast<char*>(ctx->host_done) + 512);
   static_assert(sizeof(ListCtl) <= 256 && sizeof(DevState) <= 256, "pinned block slots");
   ctx->host_lc = reinterpret_cast<ListCtl*>(reinterpret_cast<char*>(ctx->host_done) + 1024);
-  ctx->host_reports = reinterpret_cast<ListReport*>(reinterpret_cast<char*>(ctx->host_done) + 1280);
+  ctx->host_slots = reinterpret_cast<StateSlot*>(reinterpret_cast<char*>(ctx->host_done) + 1280);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), 2 * kMailBytes, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
   std::memset(ctx->mailbox, 0, 2 * kMailBytes);
   for (DevBuf* b : ctx->all_bufs()) b->stats = &ctx->mem;
@@ -3917,25 +3909,45 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   if (timek) HIPCHK(hipEventRecord(ctx->kev[0], ctx->stream));
   struct ListsScope { ma_ctx* c; ~ListsScope() { c->lists_on = false; } } lists_scope{ctx};
   // Candidate lists (k_nn_accum<.,.,1|2>).  WHICH kernel an iteration launches is decided here, on the host, in
-  // batches of kPlan iterations: before batch b is enqueued the host waits until the last solve of batch b-2 has
-  // reported (batch b-1 stays queued behind it, so the device never idles) — how far that solve moved the cloud and
-  // how far the cloud has moved since the lists were written.  Every batch reports into its own pinned slot, so the
-  // values read are those of one fixed iteration whatever the device has done since: the plan is the same in every
-  // run.  It only has to be good, not right: a list launch proves every correspondence it takes from a list and
-  // searches for the others, and lists on / off give the same transform bit for bit (tools/lists_check.py).
-  const int n_batches = (params->max_iter + kPlan - 1) / kPlan;
-  ctx->lists_on = ctx->src_rs > 0.f && lists_enabled() && !early_exit && params->max_iter > 3 * kPlan && n_batches <= kMaxReports;
+  // batches of kPlan iterations.  Every solve of such a loop leaves the state it produced in a pinned slot of its own
+  // (iteration k -> slot k; a posted write the solve does not wait for).  Before batch b is enqueued the host waits
+  // (spinning on pinned memory: an event wait wakes up later than the queued batch lasts) until the last solve of
+  // batch b-2 has written its slot — batch b-1 stays queued behind it, so the device never idles — and then knows
+  // every transform up to there: how far each solve moved the cloud, and how far it has moved since the lists were
+  // written (largest displacement over the corners of the source cloud's bounding box: |dR s + dt| is convex in s, so
+  // the box's maximum is at a corner).  The slots belong to fixed iterations, so the plan is the same in every run.
+  // It only has to be good, not right: a list launch proves every correspondence it takes from a list and searches
+  // for the others, and lists on / off give the same transform bit for bit (tools/lists_check.py).
+  ctx->lists_on = ctx->src_rs > 0.f && lists_enabled() && !early_exit && params->max_iter > 3 * kPlan && params->max_iter <= kMaxSlots;
   ctx->list_builds = ctx->list_uses = 0;
   ctx->list_plan.clear();
-  if (ctx->lists_on) for (int b = 0; b < n_batches; ++b) ctx->host_reports[b].iter = -1;
+  if (ctx->lists_on) for (int i = 0; i < params->max_iter; ++i) { ctx->host_slots[i].seq = -1; ctx->host_slots[i].s.iter = -1; }
+  const bool slots_used = ctx->lists_on;      // the solves of this run mirror their state into the slots, not into host_state_out
+  int launched = 0;
   const double skin = (double)ctx->grid.c / (double)list_skin_div();
   const double use_max = 0.49 * skin;      // a query passes its check while it has moved less than skin / 2
   const double build_max = 0.25 * skin;    // a cloud still moving faster than this per iteration is not worth a list
   constexpr int kMinUses = 5;              // a list launch saves ~9 us, writing the lists costs ~26: build for >= 5 uses
+  const DevState T_first = *ctx->host_state_in;     // the transform launch 0 runs with
+  auto T_of = [&](int k) -> const DevState& {        // the transform launch k runs with (k <= the last slot read + 1)
+    return k == 0 ? T_first : const_cast<const DevState&>(ctx->host_slots[k - 1].s);
+  };
+  auto moved = [&](const DevState& A, const DevState& B) -> double {
+    double d[9], v[3], m2 = 0.0;
+    for (int i = 0; i < 9; ++i) d[i] = A.R[i] - B.R[i];
+    for (int r = 0; r < 3; ++r) v[r] = A.t[r] - B.t[r];
+    for (int c = 0; c < 8; ++c) {
+      const double x = (c & 1) ? ctx->src_hi[0] : ctx->src_lo[0], y = (c & 2) ? ctx->src_hi[1] : ctx->src_lo[1],
+                   z = (c & 4) ? ctx->src_hi[2] : ctx->src_lo[2];
+      const double a = d[0] * x + d[1] * y + d[2] * z + v[0], bb = d[3] * x + d[4] * y + d[5] * z + v[1],
+                   e = d[6] * x + d[7] * y + d[8] * z + v[2];
+      m2 = std::max(m2, a * a + bb * bb + e * e);
+    }
+    return std::sqrt(m2);
+  };
   int plan[kPlan] = {0, 0, 0, 0};
   bool lists_live = false;       // lists exist or are planned ...
   int built_at = -1;             // ... written by the launch of this iteration
-  double step_before = -1.0;     // step reported by the batch before the one just read (for the decay rate)
   for (int k = 0; k < params->max_iter; ++k) {
     if (early_exit && k % kBatch == 0 && k >= 2 * kBatch) {
       HIPCHK(hipEventSynchronize(ctx->batch_ev[k / kBatch - 2]));
@@ -3944,52 +3956,53 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
     if (ctx->lists_on && k % kPlan == 0) {
       for (int i = 0; i < kPlan; ++i) plan[i] = 0;
       if (k >= 2 * kPlan) {
-        const ListReport& rep = ctx->host_reports[k / kPlan - 2];
-        const int expect = k - kPlan;              // iterations solved at the end of batch b-2
+        const int j = k - kPlan - 1;               // the last iteration of batch b-2
+        const StateSlot& sl = ctx->host_slots[j];
         const auto t_wait = std::chrono::steady_clock::now();
         bool ok = true;
-        while (rep.iter != expect) {               // spin: an event wait wakes up later than the queued batch lasts
+        while (!slot_ready(&sl, j + 1)) {
           if (*static_cast<volatile int*>(ctx->host_done)) { ok = false; break; }   // the loop stopped (degenerate)
           if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(20)) { ok = false; break; }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        const int j = expect - 1;                  // the iteration whose solve reported
-        const double step = rep.step, since_j = rep.since;
-        // decay of the step from batch to batch, per iteration; never assumed faster than 0.85 (it slows down as the
-        // clouds settle), never growing
-        double rho = 1.0;
-        if (step_before > 0.0 && step >= 0.0) rho = std::min(1.0, std::max(0.85, std::pow(step / step_before, 1.0 / kPlan)));
-        step_before = step;
-        auto step_at = [&](int n) { return step * std::pow(rho, n); };                               // bound on the step of iteration j + n
-        auto cum = [&](int n) { double a = 0; for (int i = 1; i <= n; ++i) a += step_at(i); return a; };   // motion over iterations j+1 .. j+n
-        if (!ok || !(step >= 0.0) || !std::isfinite(step)) {
+        if (!ok) {
           lists_live = false;
-          ctx->lists_on = ok;                      // a stopped or silent loop: no more planning
-        } else if (step_at(k - j) > build_max) {
-          lists_live = false;                      // still moving too fast: search
+          ctx->lists_on = false;                   // a stopped or silent loop: no more planning
         } else {
-          if (lists_live && built_at <= j && !rep.have) lists_live = false;
-          for (int i = 0; i < kPlan && k + i < params->max_iter; ++i) {
-            const int kk = k + i;
-            // motion between the transform the lists were (or will be) written with and the one launch kk runs with
-            double since = INFINITY;
-            if (lists_live) since = built_at <= j ? since_j + cum(kk - j - 1) : cum(kk - j - 1) - cum(built_at - j - 1);
-            if (lists_live && since <= use_max) {
-              plan[i] = 2;
-              continue;
-            }
-            // write new lists here?  only if they will serve long enough
-            int uses = 0;
-            for (int n = 1; kk + n < params->max_iter && uses < kMinUses; ++n) {
-              if (cum(kk + n - j - 1) - cum(kk - j - 1) > use_max) break;
-              ++uses;
-            }
-            if (uses >= kMinUses) {
-              plan[i] = 1;
-              lists_live = true;
-              built_at = kk;
-            } else {
-              lists_live = false;
+          // steps of the last kPlan solves and their decay per iteration; never assumed faster than 0.85 (it slows
+          // down as the clouds settle), never growing
+          const double step = moved(T_of(j + 1), T_of(j));
+          const double step_old = moved(T_of(j + 2 - kPlan), T_of(j + 1 - kPlan));
+          double rho = 1.0;
+          if (step_old > 0.0) rho = std::min(1.0, std::max(0.85, std::pow(step / step_old, 1.0 / (kPlan - 1))));
+          auto step_at = [&](int n) { return step * std::pow(rho, n); };                               // bound on the step of iteration j + n
+          auto cum = [&](int n) { double a = 0; for (int i = 1; i <= n; ++i) a += step_at(i); return a; };   // motion over iterations j+1 .. j+n
+          if (!std::isfinite(step) || step_at(k - j) > build_max) {
+            lists_live = false;                    // still moving too fast: search
+          } else {
+            const double since_j = (lists_live && built_at <= j + 1) ? moved(T_of(j + 1), T_of(built_at)) : 0.0;
+            for (int i = 0; i < kPlan && k + i < params->max_iter; ++i) {
+              const int kk = k + i;
+              // motion between the transform the lists were (or will be) written with and the one launch kk runs with
+              double since = INFINITY;
+              if (lists_live) since = built_at <= j + 1 ? since_j + cum(kk - j - 1) : cum(kk - j - 1) - cum(built_at - j - 1);
+              if (lists_live && since <= use_max) {
+                plan[i] = 2;
+                continue;
+              }
+              // write new lists here?  only if they will serve long enough
+              int uses = 0;
+              for (int n = 1; kk + n < params->max_iter && uses < kMinUses; ++n) {
+                if (cum(kk + n - j - 1) - cum(kk - j - 1) > use_max) break;
+                ++uses;
+              }
+              if (uses >= kMinUses) {
+                plan[i] = 1;
+                lists_live = true;
+                built_at = kk;
+              } else {
+                lists_live = false;
+              }
             }
           }
         }
@@ -4001,13 +4014,18 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
     ctx->list_plan.push_back((uint8_t)kind);
     if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr, MA_SCHED != 0, kind))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
-    ListReport* report = (ctx->lists_on && (k + 1) % kPlan == 0) ? &ctx->host_reports[k / kPlan] : nullptr;
-    if ((rc = launch_reduce_solve(ctx, params->tol, report))) return rc;
+    if ((rc = launch_reduce_solve(ctx, params->tol, slots_used ? &ctx->host_slots[k] : nullptr))) return rc;
+    launched = k + 1;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 2], ctx->stream));
     if (early_exit && (k + 1) % kBatch == 0) HIPCHK(hipEventRecord(ctx->batch_ev[k / kBatch], ctx->stream));
   }
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (slots_used) {      // the state as the last solve that ran left it (a loop that stopped degenerate wrote no later slot)
+    *ctx->host_state_out = *ctx->host_state_in;
+    for (int i = launched - 1; i >= 0; --i)
+      if (ctx->host_slots[i].s.iter == i + 1) { *ctx->host_state_out = const_cast<const DevState&>(ctx->host_slots[i].s); break; }
+  }
   const DevState s = *ctx->host_state_out;     // the last solve's pinned copy of the state: no device-to-host copy
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
