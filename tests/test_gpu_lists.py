@@ -3,8 +3,8 @@ fraction of a cell per iteration, a search launch also writes, per query, every 
 and the following launches read those lists instead of searching.  Every correspondence taken from a list is proved by the
 triangle inequality, so the results must be those of the searching loop BIT FOR BIT — that is what is tested here, with
 ``MAPALIGN_LISTS=0`` (every launch searches) as the other arm — and against the CPU oracle.  (The one admissible difference
-is which of two gold points at the SAME fp32 distance from a query wins, as in the index-parity tests; it needs queries
-metres from the map — tools/fuzz_lists.py, profiles/r03_fuzz_lists.txt — and does not occur in these clouds.)"""
+is which of two gold points at the SAME fp32 distance from a query wins, as in the index-parity tests — about one query in
+10^7 query-iterations, tools/fuzz_lists.py, profiles/r03_fuzz_lists.txt; it does not occur in these seeded clouds.)"""
 import numpy as np
 import pytest
 
