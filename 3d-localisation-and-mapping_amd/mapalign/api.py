@@ -117,10 +117,11 @@ def align(gold_cloud, comparison_cloud, *, max_iter=DEFAULT_MAX_ITER, tol=DEFAUL
         res = eng.icp(max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist, init=init,
                       with_trace=return_info)
         mem = eng.mem_info() if return_info else None
+        lists = eng.list_stats() if return_info else None     # launches that wrote / read the candidate lists
     if return_info:
         info = {"iterations": res.iterations, "rmse": res.rmse, "inliers": res.inliers,
                 "converged": res.converged, "gpu_ms": res.gpu_ms, "grid": grid, "trace": res.trace,
-                "T": res.T, "mem": mem, "gate_schedule": widened}
+                "T": res.T, "mem": mem, "gate_schedule": widened, "list_launches": lists}
         return res.R, res.t, info
     return res.R, res.t
 
