@@ -1,0 +1,109 @@
+// Host-side planner of the candidate lists (rows a4-a7, DESIGN.md 5 "list launches"): WHICH kernel an iteration of
+// ma_icp launches — a search, a search that also writes the per-query candidate lists, or a launch that reads them.
+// Plain C++ (no HIP): built into libmapalign by mapalign.hip and, on the CPU box, into the driver of
+// tests/test_list_planner.py, which replays transform sequences through it.
+//
+// The plan only has to be GOOD, never right: a list launch proves every correspondence it takes from a list (triangle
+// inequality over the motion since the list was written) and searches for the others, so lists on / off give the same
+// transform bit for bit whatever is decided here.
+//
+// Protocol (ma_icp): iterations are planned in batches of kPlan.  Before batch b (first iteration k = b kPlan) is
+// enqueued the host knows every transform up to the one launch j + 1 runs with, j = k - kPlan - 1 being the last
+// iteration of batch b-2 (batch b-1 stays queued behind it, so the device never idles).  From the last steps and
+// their decay it bounds the steps to come, and from those the motion between the launch that writes the lists and each
+// launch that would read them: |dR s + dt| is convex in s, so its maximum over the source cloud's bounding box is at a
+// corner.
+#pragma once
+#include <algorithm>
+#include <cmath>
+
+namespace ma {
+
+constexpr int kPlan = 4;             // iterations per planning batch of ma_icp
+
+struct ListPlanner {
+  // set once per run
+  double use_max = 0.0;      // a query passes its check while it has moved less than skin / 2: 0.49 skin
+  double build_max = 0.0;    // a cloud still moving faster than this per iteration is not worth a list: 0.25 skin
+  int min_uses = 5;          // a list launch saves ~9 us, writing the lists costs ~26: build for >= 5 uses
+  int max_iter = 0;
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};      // box of the source cloud (stored, centred coordinates)
+  // carried from batch to batch
+  bool lists_live = false;   // lists exist or are planned ...
+  int built_at = -1;         // ... written by the launch of this iteration
+
+  void configure(double skin, int max_iterations, const float box_lo[3], const float box_hi[3]) {
+    use_max = 0.49 * skin;
+    build_max = 0.25 * skin;
+    max_iter = max_iterations;
+    for (int a = 0; a < 3; ++a) { lo[a] = box_lo[a]; hi[a] = box_hi[a]; }
+    lists_live = false;
+    built_at = -1;
+  }
+
+  // largest displacement, over the corners of the box, between the transforms A and B (anything with R[9], t[3])
+  template <class SA, class SB>
+  double moved(const SA& A, const SB& B) const {
+    double d[9], v[3], m2 = 0.0;
+    bool nan = false;          // std::max drops a NaN: a transform gone wrong must read as "moving", not as "at rest"
+    for (int i = 0; i < 9; ++i) d[i] = A.R[i] - B.R[i];
+    for (int r = 0; r < 3; ++r) v[r] = A.t[r] - B.t[r];
+    for (int c = 0; c < 8; ++c) {
+      const double x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
+      const double a = d[0] * x + d[1] * y + d[2] * z + v[0], b = d[3] * x + d[4] * y + d[5] * z + v[1],
+                   e = d[6] * x + d[7] * y + d[8] * z + v[2];
+      const double q = a * a + b * b + e * e;
+      nan |= q != q;
+      m2 = std::max(m2, q);
+    }
+    return nan ? NAN : std::sqrt(m2);
+  }
+
+  void stop() { lists_live = false; }
+
+  // Plan iterations k .. k + kPlan - 1 (k a multiple of kPlan, k >= 2 kPlan).  T_of(i) = the transform launch i runs with,
+  // valid for 0 <= i <= k - kPlan.  plan[i]: 0 search, 1 search and write the lists, 2 read the lists.
+  template <class TOf>
+  void plan_batch(int k, TOf&& T_of, int plan[kPlan]) {
+    for (int i = 0; i < kPlan; ++i) plan[i] = 0;
+    const int j = k - kPlan - 1;               // the last iteration of batch b-2
+    // steps of the last kPlan solves and their decay per iteration; never assumed faster than 0.85 (it slows
+    // down as the clouds settle), never growing
+    const double step = moved(T_of(j + 1), T_of(j));
+    const double step_old = moved(T_of(j + 2 - kPlan), T_of(j + 1 - kPlan));
+    double rho = 1.0;
+    if (step_old > 0.0) rho = std::min(1.0, std::max(0.85, std::pow(step / step_old, 1.0 / (kPlan - 1))));
+    auto step_at = [&](int n) { return step * std::pow(rho, n); };                               // bound on the step of iteration j + n
+    auto cum = [&](int n) { double a = 0; for (int i = 1; i <= n; ++i) a += step_at(i); return a; };   // motion over iterations j+1 .. j+n
+    if (!std::isfinite(step) || step_at(k - j) > build_max) {
+      lists_live = false;                      // still moving too fast: search
+      return;
+    }
+    const double since_j = (lists_live && built_at <= j + 1) ? moved(T_of(j + 1), T_of(built_at)) : 0.0;
+    for (int i = 0; i < kPlan && k + i < max_iter; ++i) {
+      const int kk = k + i;
+      // motion between the transform the lists were (or will be) written with and the one launch kk runs with
+      double since = INFINITY;
+      if (lists_live) since = built_at <= j + 1 ? since_j + cum(kk - j - 1) : cum(kk - j - 1) - cum(built_at - j - 1);
+      if (lists_live && since <= use_max) {
+        plan[i] = 2;
+        continue;
+      }
+      // write new lists here?  only if they will serve long enough
+      int uses = 0;
+      for (int n = 1; kk + n < max_iter && uses < min_uses; ++n) {
+        if (cum(kk + n - j - 1) - cum(kk - j - 1) > use_max) break;
+        ++uses;
+      }
+      if (uses >= min_uses) {
+        plan[i] = 1;
+        lists_live = true;
+        built_at = kk;
+      } else {
+        lists_live = false;
+      }
+    }
+  }
+};
+
+}  // namespace ma

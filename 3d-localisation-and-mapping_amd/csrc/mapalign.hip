@@ -55,6 +55,7 @@
 
 #include "host_math.h"
 #include "kabsch.h"
+#include "list_planner.h"
 #include "mapalign.h"
 
 namespace {
@@ -71,7 +72,7 @@ constexpr uint32_t kHoleBitsEarly = 0x7FC00000u;   // = kHoleBits (k_unproject):
 // the query's position; while a query has moved less than skin / 2 since then, its nearest neighbour is provably
 // in that list (triangle inequality, checked per query), and the launch reads 8 indices instead of searching.
 constexpr int kListLen = 8;
-constexpr int kPlan = 4;             // iterations per planning batch of ma_icp
+using ma::kPlan;                     // iterations per planning batch of ma_icp (list_planner.h)
 constexpr int kMaxSlots = 4096;      // iterations of a run whose states the planner can read (longer runs search after that)
 struct ListCtl {
   int have;          // lists exist (written by the launch that ran with the transform Rb, tb)
@@ -3866,7 +3867,7 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = ensure_levels_for(ctx, params->max_corr_dist))) return rc;
   if ((rc = ensure_loop_buffers(ctx, params->max_iter))) return rc;
-  if (ctx->src_box_pending && lists_enabled() && !(params->tol > 0.0) && params->max_iter > 3 * kPlan) {
+  if (ctx->src_box_pending && lists_enabled() && params->max_iter > 3 * kPlan) {
     // a source cloud from a depth frame: its box (stored, centred coordinates; holes skipped) for the candidate lists
     float lo[3], hi[3];
     if ((rc = cloud_bounds(ctx, ctx->src.as<float>(), ctx->n, lo, hi, 4, true))) return rc;
@@ -3895,9 +3896,12 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   // batches of kBatch iterations and, before batch b, waits for the end of batch b-2 and reads
   // the pinned word the solve sets when it stops: one batch always stays queued behind the one
   // being waited for, so the device never idles.  tol = 0 (the benchmark) takes no part in this.
+  // (A run long enough for the candidate lists stops through the planner's slots instead: see below.)
   constexpr int kBatch = 8;
   const bool early_exit = params->tol > 0.0 && !timek;
-  if (early_exit) {
+  const bool lists_wanted = ctx->src_rs > 0.f && lists_enabled() && params->max_iter > 3 * kPlan && params->max_iter <= kMaxSlots;
+  const bool batch_exit = early_exit && !lists_wanted;
+  if (batch_exit) {
     const int need = (params->max_iter + kBatch - 1) / kBatch;
     while ((int)ctx->batch_ev.size() < need) {
       hipEvent_t e;
@@ -3918,38 +3922,26 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   // the box's maximum is at a corner).  The slots belong to fixed iterations, so the plan is the same in every run.
   // It only has to be good, not right: a list launch proves every correspondence it takes from a list and searches
   // for the others, and lists on / off give the same transform bit for bit (tools/lists_check.py).
-  ctx->lists_on = ctx->src_rs > 0.f && lists_enabled() && !early_exit && params->max_iter > 3 * kPlan && params->max_iter <= kMaxSlots;
+  // A run with a convergence test (tol > 0) plans the same way, and the wait for batch b-2's slot doubles as its early
+  // exit: the solve that stops the loop sets the pinned `done` word, later solves write no slot, and the host stops
+  // enqueueing launches that would only find `done` set (at most 2 kPlan of them are already queued).
+  ctx->lists_on = lists_wanted;
   ctx->list_builds = ctx->list_uses = 0;
   ctx->list_plan.clear();
   if (ctx->lists_on) for (int i = 0; i < params->max_iter; ++i) { ctx->host_slots[i].seq = -1; ctx->host_slots[i].s.iter = -1; }
   const bool slots_used = ctx->lists_on;      // the solves of this run mirror their state into the slots, not into host_state_out
   int launched = 0;
   const double skin = (double)ctx->grid.c / (double)list_skin_div();
-  const double use_max = 0.49 * skin;      // a query passes its check while it has moved less than skin / 2
-  const double build_max = 0.25 * skin;    // a cloud still moving faster than this per iteration is not worth a list
-  constexpr int kMinUses = 5;              // a list launch saves ~9 us, writing the lists costs ~26: build for >= 5 uses
+  ma::ListPlanner planner;       // list_planner.h: the decisions themselves (CPU-tested by tests/test_list_planner.py)
+  planner.configure(skin, params->max_iter, ctx->src_lo, ctx->src_hi);
   const DevState T_first = *ctx->host_state_in;     // the transform launch 0 runs with
   auto T_of = [&](int k) -> const DevState& {        // the transform launch k runs with (k <= the last slot read + 1)
     return k == 0 ? T_first : const_cast<const DevState&>(ctx->host_slots[k - 1].s);
   };
-  auto moved = [&](const DevState& A, const DevState& B) -> double {
-    double d[9], v[3], m2 = 0.0;
-    for (int i = 0; i < 9; ++i) d[i] = A.R[i] - B.R[i];
-    for (int r = 0; r < 3; ++r) v[r] = A.t[r] - B.t[r];
-    for (int c = 0; c < 8; ++c) {
-      const double x = (c & 1) ? ctx->src_hi[0] : ctx->src_lo[0], y = (c & 2) ? ctx->src_hi[1] : ctx->src_lo[1],
-                   z = (c & 4) ? ctx->src_hi[2] : ctx->src_lo[2];
-      const double a = d[0] * x + d[1] * y + d[2] * z + v[0], bb = d[3] * x + d[4] * y + d[5] * z + v[1],
-                   e = d[6] * x + d[7] * y + d[8] * z + v[2];
-      m2 = std::max(m2, a * a + bb * bb + e * e);
-    }
-    return std::sqrt(m2);
-  };
   int plan[kPlan] = {0, 0, 0, 0};
-  bool lists_live = false;       // lists exist or are planned ...
-  int built_at = -1;             // ... written by the launch of this iteration
-  for (int k = 0; k < params->max_iter; ++k) {
-    if (early_exit && k % kBatch == 0 && k >= 2 * kBatch) {
+  bool stopped = false;          // tol > 0 with lists: the planner's wait saw the loop stop
+  for (int k = 0; k < params->max_iter && !stopped; ++k) {
+    if (batch_exit && k % kBatch == 0 && k >= 2 * kBatch) {
       HIPCHK(hipEventSynchronize(ctx->batch_ev[k / kBatch - 2]));
       if (*static_cast<volatile int*>(ctx->host_done)) break;
     }
@@ -3966,58 +3958,22 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         if (!ok) {
-          lists_live = false;
+          planner.stop();
           ctx->lists_on = false;                   // a stopped or silent loop: no more planning
+          if (early_exit && *static_cast<volatile int*>(ctx->host_done)) { stopped = true; break; }   // converged (or degenerate): nothing left to run
         } else {
-          // steps of the last kPlan solves and their decay per iteration; never assumed faster than 0.85 (it slows
-          // down as the clouds settle), never growing
-          const double step = moved(T_of(j + 1), T_of(j));
-          const double step_old = moved(T_of(j + 2 - kPlan), T_of(j + 1 - kPlan));
-          double rho = 1.0;
-          if (step_old > 0.0) rho = std::min(1.0, std::max(0.85, std::pow(step / step_old, 1.0 / (kPlan - 1))));
-          auto step_at = [&](int n) { return step * std::pow(rho, n); };                               // bound on the step of iteration j + n
-          auto cum = [&](int n) { double a = 0; for (int i = 1; i <= n; ++i) a += step_at(i); return a; };   // motion over iterations j+1 .. j+n
-          if (!std::isfinite(step) || step_at(k - j) > build_max) {
-            lists_live = false;                    // still moving too fast: search
-          } else {
-            const double since_j = (lists_live && built_at <= j + 1) ? moved(T_of(j + 1), T_of(built_at)) : 0.0;
-            for (int i = 0; i < kPlan && k + i < params->max_iter; ++i) {
-              const int kk = k + i;
-              // motion between the transform the lists were (or will be) written with and the one launch kk runs with
-              double since = INFINITY;
-              if (lists_live) since = built_at <= j + 1 ? since_j + cum(kk - j - 1) : cum(kk - j - 1) - cum(built_at - j - 1);
-              if (lists_live && since <= use_max) {
-                plan[i] = 2;
-                continue;
-              }
-              // write new lists here?  only if they will serve long enough
-              int uses = 0;
-              for (int n = 1; kk + n < params->max_iter && uses < kMinUses; ++n) {
-                if (cum(kk + n - j - 1) - cum(kk - j - 1) > use_max) break;
-                ++uses;
-              }
-              if (uses >= kMinUses) {
-                plan[i] = 1;
-                lists_live = true;
-                built_at = kk;
-              } else {
-                lists_live = false;
-              }
-            }
-          }
+          planner.plan_batch(k, T_of, plan);
         }
       }
     }
     const int kind = ctx->lists_on ? plan[k % kPlan] : 0;
-    ctx->list_builds += kind == 1;
-    ctx->list_uses += kind == 2;
     ctx->list_plan.push_back((uint8_t)kind);
     if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr, MA_SCHED != 0, kind))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
     if ((rc = launch_reduce_solve(ctx, params->tol, slots_used ? &ctx->host_slots[k] : nullptr))) return rc;
     launched = k + 1;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 2], ctx->stream));
-    if (early_exit && (k + 1) % kBatch == 0) HIPCHK(hipEventRecord(ctx->batch_ev[k / kBatch], ctx->stream));
+    if (batch_exit && (k + 1) % kBatch == 0) HIPCHK(hipEventRecord(ctx->batch_ev[k / kBatch], ctx->stream));
   }
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -4027,6 +3983,12 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
       if (ctx->host_slots[i].s.iter == i + 1) { *ctx->host_state_out = const_cast<const DevState&>(ctx->host_slots[i].s); break; }
   }
   const DevState s = *ctx->host_state_out;     // the last solve's pinned copy of the state: no device-to-host copy
+  // launches that ran as iterations (a loop stopped by its convergence test leaves up to 2 kPlan enqueued launches that
+  // only find `done` set; how many depends on when the host saw it, so they are not counted)
+  for (int i = 0; i < s.iter && i < (int)ctx->list_plan.size(); ++i) {
+    ctx->list_builds += ctx->list_plan[(size_t)i] == 1;
+    ctx->list_uses += ctx->list_plan[(size_t)i] == 2;
+  }
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   if (timek) {

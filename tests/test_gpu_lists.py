@@ -15,11 +15,11 @@ from oracle import icp_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def _both(engine, monkeypatch, iters, gate=0.10, **kw):
+def _both(engine, monkeypatch, iters, gate=0.10, tol=0.0, **kw):
     out = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("MAPALIGN_LISTS", mode)
-        res = engine.icp(iters, 0.0, gate, with_trace=True, **kw)
+        res = engine.icp(iters, tol, gate, with_trace=True, **kw)
         out[mode] = (res, engine.list_stats())
     return out["1"], out["0"]
 
@@ -86,14 +86,38 @@ def test_list_launches_count_their_work_and_keep_results(engine, monkeypatch):
     assert (b.trace[listed, 18] < 0.5 * len(comp)).all() and (b.trace[~listed, 18] > 3.0 * len(comp)).all()
 
 
-def test_no_lists_for_short_runs_and_tolerance_runs(engine, monkeypatch):
+def test_no_lists_for_short_runs(engine, monkeypatch):
     monkeypatch.setenv("MAPALIGN_LISTS", "1")
     gold, comp, _, _ = syn.make_pair(14, 50_000, 40_000, angle_deg=0.2, t0=(0.01, 0.0, 0.0))
     engine.set_pair(gold, comp)
     engine.icp(12, 0.0, 0.10)
     assert engine.list_stats() == {"builds": 0, "uses": 0}          # three planning batches or fewer
-    engine.icp(60, 1e-7, 0.10)
-    assert engine.list_stats() == {"builds": 0, "uses": 0}          # a convergence test stops the loop in its own batches
+    engine.icp(12, 1e-3, 0.10)                                      # ... with a convergence test as well
+    assert engine.list_stats() == {"builds": 0, "uses": 0}
+
+
+@pytest.mark.parametrize("tol", [1e-4, 1e-6, 1e-8, 3e-10])
+def test_tolerance_runs_plan_lists_too_and_stop_where_the_searching_loop_stops(engine, monkeypatch, tol):
+    """tol > 0 (a7's convergence test): the planner's wait for a slot doubles as the early exit.  Whether the loop stops
+    before the first lists, between list launches or not at all, it must stop at the searching loop's iteration with the
+    searching loop's bits."""
+    gold, comp, _, _ = syn.make_pair(11, 120_000, 100_000, angle_deg=0.4, t0=(0.02, -0.015, 0.01))
+    engine.set_pair(gold, comp)
+    (on, s_on), (off, s_off) = _both(engine, monkeypatch, 90, tol=tol)
+    assert s_off == {"builds": 0, "uses": 0}
+    assert on.iterations == off.iterations and on.converged == off.converged, (on.iterations, off.iterations)
+    assert np.array_equal(on.T, off.T) and on.inliers == off.inliers
+    k = on.iterations
+    assert np.array_equal(on.trace[:k, :18], off.trace[:k, :18])
+    monkeypatch.setenv("MAPALIGN_LISTS", "1")
+    again = engine.icp(90, tol, 0.10)
+    assert np.array_equal(again.T, on.T) and again.iterations == k and engine.list_stats() == s_on
+    plan = engine.list_plan()
+    assert k <= len(plan) <= min(90, k + 8)                         # at most two planning batches enqueued past the stop
+    assert on.converged == (k < 90) or k == 90
+    if k >= 56:                                                     # the same pair uses lists from iteration < 50 on (first test)
+        assert s_on["uses"] >= 1, s_on
+    print(f"tol {tol:g}: stopped after {k} iterations, converged {on.converged}, lists {s_on}")
 
 
 def test_list_launches_on_a_source_cloud_from_a_depth_frame(engine, monkeypatch):

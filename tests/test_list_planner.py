@@ -1,0 +1,250 @@
+"""The host-side planner of the candidate lists (csrc/list_planner.h, rows a4-a7) compiled with g++ and replayed on the
+CPU: which launch of ma_icp searches (0), searches and writes the per-query lists (1) or reads them (2).
+
+The planner can never make a result wrong — a list launch proves what it takes from a list and searches for the rest
+(tests/test_gpu_lists.py compares lists on / off bit for bit) — so what is pinned here is the protocol ma_icp relies on
+(which transforms a batch may look at, nothing planned before two batches have run, a read only after a write, a write
+only when enough reads can follow) and that its motion bound is a bound where the steps really decay geometrically."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from mapalign import synthetic as syn
+
+K_PLAN = 4
+
+SHIM = r"""
+#include <vector>
+#include "list_planner.h"
+struct Rt { double R[9]; double t[3]; };
+// Ts[i] = the transform launch i runs with (i = 0 .. max_iter).  Replays ma_icp's loop: batch b is planned from
+// Ts[0 .. k - kPlan] only; `seen` returns the largest index a batch asked for, relative to its k (must be <= -kPlan),
+// and the smallest absolute index (must be >= 0).
+extern "C" int plan_run(const double* Ts, int max_iter, double skin, const float* lo, const float* hi, int* out, int* seen) {
+  ma::ListPlanner P;
+  P.configure(skin, max_iter, lo, hi);
+  const Rt* T = reinterpret_cast<const Rt*>(Ts);
+  int plan[ma::kPlan] = {0, 0, 0, 0};
+  seen[0] = -1000000; seen[1] = 1000000;
+  for (int k = 0; k < max_iter; ++k) {
+    if (k % ma::kPlan == 0) {
+      for (int i = 0; i < ma::kPlan; ++i) plan[i] = 0;
+      if (k >= 2 * ma::kPlan) {
+        auto T_of = [&](int i) -> const Rt& {
+          if (i - k > seen[0]) seen[0] = i - k;
+          if (i < seen[1]) seen[1] = i;
+          return T[i];
+        };
+        P.plan_batch(k, T_of, plan);
+      }
+    }
+    out[k] = plan[k % ma::kPlan];
+  }
+  return P.built_at;
+}
+extern "C" double box_moved(const double* A, const double* B, const float* lo, const float* hi) {
+  ma::ListPlanner P;
+  P.configure(1.0, 0, lo, hi);
+  return P.moved(*reinterpret_cast<const Rt*>(A), *reinterpret_cast<const Rt*>(B));
+}
+extern "C" void limits(double skin, double* out) {
+  const float z[3] = {0, 0, 0};
+  ma::ListPlanner P;
+  P.configure(skin, 0, z, z);
+  out[0] = P.use_max; out[1] = P.build_max; out[2] = P.min_uses;
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def shim():
+    bdir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(bdir, exist_ok=True)
+    src = os.path.join(bdir, "list_planner.cpp")
+    so = os.path.join(bdir, "list_planner.so")
+    with open(src, "w") as f:
+        f.write(SHIM)
+    inc = os.path.join(ROOT, "3d-localisation-and-mapping_amd", "csrc")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-fPIC", "-shared", "-I", inc, "-o", so, src], check=True)
+    lib = C.CDLL(so)
+    dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
+    lib.plan_run.argtypes = [dp, C.c_int, C.c_double, fp, fp, ip, ip]
+    lib.plan_run.restype = C.c_int
+    lib.box_moved.argtypes = [dp, dp, fp, fp]
+    lib.box_moved.restype = C.c_double
+    lib.limits.argtypes = [C.c_double, dp]
+    return lib
+
+
+LO = np.array([-10.0, -1.5, -1.2], dtype=np.float32)
+HI = np.array([10.0, 1.5, 1.3], dtype=np.float32)
+SKIN = 0.005
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def pack(Rs, ts):
+    return np.ascontiguousarray(np.concatenate([np.asarray(Rs).reshape(len(Rs), 9), np.asarray(ts).reshape(len(ts), 3)], axis=1))
+
+
+def run(lib, Ts, max_iter, skin=SKIN, lo=LO, hi=HI):
+    assert Ts.shape == (max_iter + 1, 12)
+    out = np.zeros(max_iter, dtype=np.int32)
+    seen = np.zeros(2, dtype=np.int32)
+    lib.plan_run(_d(Ts), max_iter, skin, _f(lo), _f(hi), out.ctypes.data_as(C.POINTER(C.c_int)), seen.ctypes.data_as(C.POINTER(C.c_int)))
+    return out, seen
+
+
+def moved(lib, A, B, lo=LO, hi=HI):
+    return lib.box_moved(_d(np.ascontiguousarray(A)), _d(np.ascontiguousarray(B)), _f(lo), _f(hi))
+
+
+def limits(lib, skin=SKIN):
+    out = np.zeros(3)
+    lib.limits(skin, _d(out))
+    return out[0], out[1], int(out[2])
+
+
+def translations(steps, direction=(0.6, -0.64, 0.48)):
+    """Ts[i] for a cloud that iteration i moves by steps[i] along a fixed direction (steps add up exactly)."""
+    d = np.asarray(direction) / np.linalg.norm(direction)
+    pos = np.concatenate([[0.0], np.cumsum(steps)])
+    return pack(np.tile(np.eye(3), (len(pos), 1, 1)), pos[:, None] * d[None, :])
+
+
+def check_shape_of(plan, min_uses, max_iter):
+    """What every plan obeys: nothing before two batches have run; a read only while lists are live; a write only where
+    the planner expected min_uses reads to follow within the run."""
+    assert (plan[: 2 * K_PLAN] == 0).all()
+    live = False
+    for k, kind in enumerate(plan):
+        if kind == 1:
+            assert k + min_uses < max_iter
+            live = True
+        elif kind == 2:
+            assert live, (k, plan)
+        # a search between reads means the lists were dropped
+        elif kind == 0:
+            live = False
+    return True
+
+
+def test_box_motion_bound_is_the_maximum_over_the_box(shim):
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(LO, HI, size=(4000, 3))
+    corners = np.array([[(HI if c >> a & 1 else LO)[a] for a in range(3)] for c in range(8)], dtype=np.float64)
+    for it in range(50):
+        RA = syn.rotation_about_axis(rng.normal(size=3), rng.normal() * 0.01)
+        RB = syn.rotation_about_axis(rng.normal(size=3), rng.normal() * 0.01)
+        tA, tB = rng.normal(size=3) * 0.01, rng.normal(size=3) * 0.01
+        A, B = pack([RA], [tA])[0], pack([RB], [tB])[0]
+        m = moved(shim, A, B)
+        disp = lambda P: np.linalg.norm(P @ (RA - RB).T + (tA - tB), axis=1)
+        assert m >= disp(pts).max() - 1e-15                      # convex in the point: the maximum sits at a corner
+        assert abs(m - disp(corners).max()) <= 1e-12 * max(m, 1e-30)
+    I = pack([np.eye(3)], [np.zeros(3)])[0]
+    assert moved(shim, I, I) == 0.0
+
+
+def test_a_cloud_at_rest_writes_once_and_reads_to_the_end(shim):
+    use_max, build_max, min_uses = limits(shim)
+    assert use_max == pytest.approx(0.49 * SKIN) and build_max == pytest.approx(0.25 * SKIN) and min_uses == 5
+    n = 50
+    plan, seen = run(shim, translations(np.zeros(n)), n)
+    assert plan.tolist() == [0] * 8 + [1] + [2] * (n - 9)
+    assert seen[0] <= -K_PLAN and seen[1] >= 0                   # only transforms the host has when it plans the batch
+    # too close to the end of the run for min_uses reads: no lists at all; one iteration more and they pay
+    assert run(shim, translations(np.zeros(13)), 13)[0].tolist() == [0] * 13
+    assert run(shim, translations(np.zeros(14)), 14)[0].tolist() == [0] * 8 + [1] + [2] * 5
+
+
+def test_a_cloud_that_keeps_moving_fast_only_searches(shim):
+    _, build_max, _ = limits(shim)
+    n = 60
+    plan, _ = run(shim, translations(np.full(n, 1.5 * build_max)), n)
+    assert (plan == 0).all()
+    # NaN / inf transforms (a solve gone wrong) read as "moving", not as "at rest" (std::max would drop the NaN): no list
+    # from the batch on that sees one — batch 8 is planned from launches 0-4 and batch 12 from launches up to 8
+    for poison in (np.nan, np.inf):
+        bad = translations(np.zeros(n))
+        bad[5:, 9] = poison
+        assert run(shim, bad, n)[0].tolist() == [0] * 8 + [1, 2, 2, 2] + [0] * (n - 12)
+        bad[:, 9] = poison
+        assert (run(shim, bad, n)[0] == 0).all()
+
+
+@pytest.mark.parametrize("rho", [0.70, 0.86, 0.93, 0.98])
+@pytest.mark.parametrize("first_step", [0.05, 0.004])
+def test_geometric_decay_every_planned_read_is_inside_the_skin(shim, rho, first_step):
+    """Steps that decay geometrically along a line: the planner's bound on the motion to come is then a true bound (a
+    decay faster than 0.85 per iteration is never assumed), so no planned read is further than use_max from the transform
+    its lists were written with — a list launch at that distance still proves all of its queries."""
+    use_max, build_max, min_uses = limits(shim)
+    n = 400
+    steps = first_step * rho ** np.arange(n)
+    Ts = translations(steps)
+    plan, seen = run(shim, Ts, n)
+    assert seen[0] <= -K_PLAN and seen[1] >= 0
+    check_shape_of(plan, min_uses, n)
+    assert (plan == 2).sum() >= 20                               # every such run comes to rest well inside 400 iterations
+    built = None
+    for k, kind in enumerate(plan):
+        if kind == 1:
+            built = k
+            assert steps[k] <= build_max * (1 + 1e-9)            # the step of the writing iteration itself is small
+        elif kind == 2:
+            assert moved(shim, Ts[k], Ts[built]) <= use_max * (1 + 1e-9), (k, built)
+    # and the lists are not late: the first write comes within a few batches of the first iteration that is slow enough
+    # itself and is followed by min_uses steps that fit into use_max (the host plans batch b from the transforms of
+    # batch b-2, and bounds the steps to come from above)
+    fits = [k for k in range(n - min_uses - 1) if steps[k] <= build_max and steps[k + 1:k + 1 + min_uses].sum() <= use_max]
+    first_write = int(np.argmax(plan == 1))
+    assert first_write <= max(fits[0], 2 * K_PLAN) + 5 * K_PLAN, (fits[0], first_write)
+
+
+def test_rotating_settling_cloud_reads_stay_inside_half_a_skin(shim):
+    """The benchmark's shape: a rotation about a tilted axis plus a translation, both settling by 0.9 per iteration."""
+    use_max, build_max, min_uses = limits(shim)
+    n = 80
+    ang = np.deg2rad(0.05) * 0.9 ** np.arange(n)
+    shift = 0.004 * 0.9 ** np.arange(n)
+    Rs, ts = [np.eye(3)], [np.zeros(3)]
+    for i in range(n):
+        dR = syn.rotation_about_axis([0.2, 0.1, 1.0], ang[i])
+        Rs.append(dR @ Rs[-1])
+        ts.append(dR @ ts[-1] + shift[i] * np.array([0.6, 0.0, 0.8]))
+    Ts = pack(Rs, ts)
+    plan, seen = run(shim, Ts, n)
+    assert seen[0] <= -K_PLAN and seen[1] >= 0
+    check_shape_of(plan, min_uses, n)
+    assert (plan == 1).sum() >= 1 and (plan == 2).sum() >= 10
+    built = None
+    for k, kind in enumerate(plan):
+        built = k if kind == 1 else built
+        if kind == 2:
+            assert moved(shim, Ts[k], Ts[built]) <= 0.5 * SKIN, (k, built)
+    # the same sequence, the same plan (the slots belong to fixed iterations: ma_icp repeats its plan run after run)
+    assert np.array_equal(run(shim, Ts, n)[0], plan)
+
+
+def test_a_cloud_that_starts_moving_again_drops_its_lists(shim):
+    _, build_max, min_uses = limits(shim)
+    n = 64
+    steps = np.zeros(n)
+    steps[30:40] = 2.0 * build_max                               # e.g. the gate opened onto new correspondences
+    plan, _ = run(shim, translations(steps), n)
+    check_shape_of(plan, min_uses, n)
+    assert plan[8] == 1 and (plan[9:28] == 2).all()
+    # the host learns of iteration 30's step when it plans batch 36 (transforms up to launch 32): from there it searches
+    assert (plan[36:44] == 0).all()
+    assert (plan[52:] == 2).all() and (plan[44:52] == 1).sum() == 1      # and comes back once the cloud rests again
