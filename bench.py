@@ -223,6 +223,9 @@ def cpu_baseline_and_parity(eng, gold, comp, iters):
               "max_inlier_count_difference": float(np.abs(res.trace[:, 0] - np.array(inliers)).max()),
               "tolerance": {"R_fro": 1e-4, "t_m": 1e-3}}
     parity["within_tolerance"] = bool(parity["R_fro_vs_cpu"] <= 1e-4 and parity["t_m_vs_cpu"] <= 1e-3)
+    if iters < ITERS:
+        parity["note"] = (f"SHORTENED from {ITERS} iterations: this host's cores need {np.mean(times[:3]):.1f} s per oracle iteration; "
+                          f"both sides ran {iters} (tests/test_gpu_round2.py compares seed 0 after all {ITERS} whatever the host)")
     return cpu, parity
 
 
