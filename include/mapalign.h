@@ -260,10 +260,11 @@ int ma_get_source_stored(ma_ctx* ctx, double* xyz_out, uint64_t* n);
 
 /* Rows a4-a7: the whole ICP loop on the device.  init = NULL means identity.
  * T_out receives the composed comparison->gold transform.
- * A run with tol == 0 and more than 12 iterations lets the launches of its later iterations read per-query candidate
- * lists instead of searching once the cloud has come to rest (DESIGN.md 5 "List launches"; ma_get_list_stats /
- * ma_get_list_plan report them).  Every correspondence taken from a list is proved, and the result is the searching
- * loop's bit for bit; MAPALIGN_LISTS=0 in the environment makes every launch search. */
+ * A run of more than 12 iterations lets the launches of its later iterations read per-query candidate lists instead
+ * of searching once the cloud has come to rest (DESIGN.md 5 "List launches"; ma_get_list_stats / ma_get_list_plan
+ * report them).  Every correspondence taken from a list is proved, and the result is the searching loop's bit for bit
+ * — with tol > 0 as well: such a run stops at the searching loop's iteration, and at most 8 launches that only find
+ * the loop stopped are enqueued past it.  MAPALIGN_LISTS=0 in the environment makes every launch search. */
 int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16],
            ma_stats* stats);
 /* Per-iteration trace of the last ma_icp / stepping sequence: row k =
