@@ -20,21 +20,26 @@
 namespace ma {
 
 constexpr int kPlan = 4;             // iterations per planning batch of ma_icp
+// Defaults of a context's list configuration (ma_list_config).  skin = cell edge / kSkinDivDefault; a launch writes
+// lists only when at least kMinUsesDefault reads are predicted to follow.
+constexpr float kSkinDivDefault = 7.f;
+constexpr int kMinUsesDefault = 5;
 
 struct ListPlanner {
   // set once per run
   double use_max = 0.0;      // a query passes its check while it has moved less than skin / 2: 0.49 skin
   double build_max = 0.0;    // a cloud still moving faster than this per iteration is not worth a list: 0.25 skin
-  int min_uses = 5;          // a list launch saves ~9 us, writing the lists costs ~26: build for >= 5 uses
+  int min_uses = kMinUsesDefault;   // a read saves a search launch's surplus over a list launch, a write costs about one search launch more
   int max_iter = 0;
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};      // box of the source cloud (stored, centred coordinates)
   // carried from batch to batch
   bool lists_live = false;   // lists exist or are planned ...
   int built_at = -1;         // ... written by the launch of this iteration
 
-  void configure(double skin, int max_iterations, const float box_lo[3], const float box_hi[3]) {
+  void configure(double skin, int max_iterations, const float box_lo[3], const float box_hi[3], int min_uses_ = kMinUsesDefault) {
     use_max = 0.49 * skin;
     build_max = 0.25 * skin;
+    min_uses = min_uses_;
     max_iter = max_iterations;
     for (int a = 0; a < 3; ++a) { lo[a] = box_lo[a]; hi[a] = box_hi[a]; }
     lists_live = false;

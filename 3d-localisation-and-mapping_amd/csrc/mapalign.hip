@@ -72,6 +72,24 @@ constexpr uint32_t kHoleBitsEarly = 0x7FC00000u;   // = kHoleBits (k_unproject):
 // the query's position; while a query has moved less than skin / 2 since then, its nearest neighbour is provably
 // in that list (triangle inequality, checked per query), and the launch reads 8 indices instead of searching.
 constexpr int kListLen = 8;
+// Storage (round 4), every plane indexed by source slot.  Entries 0 and 1 are kept INLINE — the gold point's
+// coordinates and its position, 16 bytes each, one plane per entry so that a wavefront's read of either is one
+// contiguous kilobyte — so that the common list (<= 2 entries) costs a list launch no gather at all; entries 2-5
+// (plane b0, four positions per slot) and 6-7 (plane b1, two per slot) are positions that the few longer lists gather
+// through.  An unused inline entry is (inf, inf, inf, none): its distance never passes the gate.
+#ifndef MA_LIST_INLINE
+#define MA_LIST_INLINE 2
+#endif
+constexpr int kListInline = MA_LIST_INLINE;     // 0 or 2 entries with inline coordinates (A/B: csrc/Makefile `variant`)
+static_assert(kListInline == 0 || kListInline == 2, "inline entries");
+struct ListPlanes {
+  float4* __restrict__ a0;
+  float4* __restrict__ a1;
+  uint32_t* __restrict__ b0;     // [slots][4]: entries kListInline .. kListInline + 3
+  uint32_t* __restrict__ b1;     // [slots][4]: the entries behind them (2 or 4 in use)
+  float* __restrict__ rad;       // radius the list is complete for; low 4 bits: entries
+};
+constexpr size_t kListBytesPerSlot = 2 * sizeof(float4) + 4 * sizeof(uint32_t) + 4 * sizeof(uint32_t) + sizeof(float);
 using ma::kPlan;                     // iterations per planning batch of ma_icp (list_planner.h)
 constexpr int kMaxSlots = 4096;      // iterations of a run whose states the planner can read (longer runs search after that)
 struct ListCtl {
@@ -829,6 +847,18 @@ __device__ __forceinline__ u4_unaligned ld_cell4(const uint32_t* __restrict__ ba
   return *reinterpret_cast<const u4_unaligned*>(reinterpret_cast<const char*>(base) + (c << 2));
 }
 
+// The squared distance, in ONE association everywhere (search, per-lane search, list launches): which of two gold
+// points is nearer is decided on these bits, so every path must form them the same way.
+__device__ __forceinline__ float dist2(const float dx, const float dy, const float dz) {
+  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+}
+
+// ONE tie rule for every path (round 4): the nearest neighbour is the gold point with the smallest
+// (fp32 squared distance, position in level 0) in lexicographic order — the order of the packed 64-bit keys of the
+// cooperative search.  Which of two gold points at the SAME fp32 distance wins therefore no longer depends on the
+// order in which a search came across them, on last iteration's match, or on whether the launch searched or read
+// candidate lists.  (The open gate is a distance no real match may equal: a tie against it, with no match held, loses.)
+//
 // Four candidates per trip: the run is contiguous, so the four loads are in flight together
 // (indices past the end are clamped to the last point: a duplicate changes nothing).
 // Only (distance, position) of the winner are tracked; its coordinates are re-read once.
@@ -841,9 +871,9 @@ __device__ __forceinline__ void scan_run(const float px, const float py, const f
     for (int u = 0; u < 4; ++u) q[u] = ld_point(gold, min(j + (uint32_t)u, b - 1u));
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float dx = px - q[u].x, dy = py - q[u].y, dz = pz - q[u].z;
-      const float d = dx * dx + dy * dy + dz * dz;
-      if (d < best2) { best2 = d; bestj = __float_as_uint(q[u].w); }
+      const float d = dist2(px - q[u].x, py - q[u].y, pz - q[u].z);
+      const uint32_t pos = __float_as_uint(q[u].w);
+      if (d < best2 || (d == best2 && pos < bestj && bestj != kNoMatch)) { best2 = d; bestj = pos; }
     }
   }
 }
@@ -865,7 +895,7 @@ __device__ __forceinline__ void level_pass(const float px, const float py, const
     if ((unsigned)z >= (unsigned)V.nz) continue;
     const float zlo = S.oz + (float)z * V.c;
     const float dzq = fmaxf(0.f, fmaxf(zlo - S.delta - pz, pz - (zlo + V.c + S.delta)));
-    if (dzq * dzq >= best2) continue;
+    if (dzq * dzq > best2) continue;      // (>, <= below: a tie at distance 0 must still be examined)
     uint32_t a[3], b[3];
     // phase 1: the slab's three row tests + table reads, independent => one round trip
 #pragma unroll
@@ -877,7 +907,7 @@ __device__ __forceinline__ void level_pass(const float px, const float py, const
         const float ylo = S.oy + (float)y * V.c;
         const float dyq = fmaxf(0.f, fmaxf(ylo - S.delta - py, py - (ylo + V.c + S.delta)));
         const float d2yz = dyq * dyq + dzq * dzq;
-        if (d2yz < best2) {
+        if (d2yz <= best2) {
           const float rx = fast_sqrt(best2 - d2yz) + S.delta;  // +inf while ungated and unmatched
           const int x0 = (int)fmaxf(floorf((px - rx - S.ox) * V.inv_c), 0.f);
           const int x1 = (int)fminf(floorf((px + rx - S.ox) * V.inv_c), (float)(V.nx - 1));
@@ -947,7 +977,7 @@ __device__ __forceinline__ void ring_walk(const float px, const float py, const 
               const float dyq = fmaxf(0.f, fmaxf(ylo - S.delta - py, py - (ylo + V.c + S.delta)));
               const float dzq = fmaxf(0.f, fmaxf(zlo - S.delta - pz, pz - (zlo + V.c + S.delta)));
               const float d2yz = dyq * dyq + dzq * dzq;
-              if (d2yz < best2) {
+              if (d2yz <= best2) {
                 const float rx = fast_sqrt(best2 - d2yz) + S.delta;
                 const int x0 = (int)fmaxf(floorf((px - rx - S.ox) * V.inv_c), 0.f);
                 const int x1 = (int)fminf(floorf((px + rx - S.ox) * V.inv_c), (float)(V.nx - 1));
@@ -1058,6 +1088,17 @@ struct WaveLds {
 __device__ __forceinline__ unsigned long long pack_best(float d2, uint32_t j) {
   return ((unsigned long long)__float_as_uint(d2) << 32) | j;
 }
+// The key a wavefront keeps per query in LDS: (distance bits + 1, position) for a match held, (open gate, none) without
+// one.  The +1 — one ulp — is what lets a candidate at EXACTLY the distance of the match held compete on its position
+// (the tie rule, scan_run) at no cost in the candidate loop: the loop's bound is the key's high word as it stands, a
+// candidate passes it with d <= the distance held, and the 64-bit minimum over keys of the same form decides.  A tie
+// against the open gate, with no match held, still loses.
+__device__ __forceinline__ unsigned long long pack_held(float d2, uint32_t j) {
+  return ((unsigned long long)(__float_as_uint(d2) + (j != kNoMatch ? 1u : 0u)) << 32) | j;
+}
+__device__ __forceinline__ float held_d2(unsigned long long key) {
+  return __uint_as_float((uint32_t)(key >> 32) - ((uint32_t)key != kNoMatch ? 1u : 0u));
+}
 __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -1065,24 +1106,27 @@ __device__ __forceinline__ uint32_t lane_prefix(unsigned long long mask) {
 template <bool COUNT, bool BUILD>
 __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, const float4* __restrict__ gold0,
                                                 uint32_t& nchunk, uint32_t& ncand, const float skin,
-                                                uint32_t* __restrict__ lists_wave, const uint32_t list_plane) {
+                                                const ListPlanes& lp, const uint32_t slot0) {
   for (uint32_t j0 = 0; j0 < nchunk; j0 += kWave) {
     const uint32_t j = j0 + lane;
     if (j < nchunk) {
       const uint32_t lq = W.chunk_lane[j], a = W.chunk_a[j], cnt = W.chunk_cnt[j];
       const float4 p = W.pos[lq];
-      float b2 = __uint_as_float((uint32_t)(W.best[lq] >> 32));
-      const float b2_in = b2;
+      const unsigned long long cur = W.best[lq];
+      // the bound as the key holds it: one ulp above the distance of the match held (pack_held), so that a candidate at
+      // exactly that distance passes and competes on its position in the 64-bit minimum below
+      const float b2_in = __uint_as_float((uint32_t)(cur >> 32));
+      float b2 = b2_in;
       float reach2 = 0.f;      // list-writing launch: everything within (current best distance + skin) goes on the query's list
       if (BUILD) { const float r = fast_sqrt(b2_in) + skin; reach2 = r * r; }
-      uint32_t bj = kNoMatch;
       // Four candidates per trip at consecutive positions a+t .. a+t+3, WITHOUT clamping to the
       // chunk: the positions past its end hold other gold points (the next cells of the sorted
       // array; eight far-away pad entries follow the last point), and any gold point is a
       // legitimate candidate — the minimum over a superset that contains the true neighbour is
       // still the true neighbour.  One address per trip (the other three loads use immediate
       // offsets) and the winner is tracked as a small offset from `a`: 10 instead of 14 VALU
-      // instructions per candidate.
+      // instructions per candidate.  Positions ascend and only a strictly nearer candidate replaces
+      // the one held, so of equal candidates inside the chunk the smallest position stays.
       uint32_t bo = 0xFFFFFFFFu;
       for (uint32_t t = 0; t < cnt; t += 4u) {
         const char* __restrict__ at = reinterpret_cast<const char*>(gold0) + ((a + t) << 4);
@@ -1091,22 +1135,26 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
         for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float3*>(at + 16 * u);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float dx = p.x - q[u].x, dy = p.y - q[u].y, dz = p.z - q[u].z;
-          const float d = dx * dx + dy * dy + dz * dz;
+          const float d = dist2(p.x - q[u].x, p.y - q[u].y, p.z - q[u].z);
           if (d < b2) { b2 = d; bo = t + (uint32_t)u; }
           if (BUILD) {
             if (d <= reach2 && t + (uint32_t)u < cnt) {      // real members of the chunk only
               const uint32_t slot = atomicAdd(reinterpret_cast<uint32_t*>(&W.pos[lq]) + 3, 1u);
-              // entries 0-3 in the first plane (every list launch reads it), 4-7 in the second (read by the few queries with > 4)
-              if (slot < (uint32_t)kListLen) lists_wave[(slot < 4u ? 0u : list_plane - 4u) + lq * 4u + slot] = a + t + (uint32_t)u;
+              const uint32_t pos = a + t + (uint32_t)u, at_q = slot0 + lq;
+              constexpr uint32_t kIn = (uint32_t)kListInline;
+              if (slot < kIn) (slot == 0u ? lp.a0 : lp.a1)[at_q] = make_float4(q[u].x, q[u].y, q[u].z, __uint_as_float(pos));
+              else if (slot < kIn + 4u) lp.b0[at_q * 4u + (slot - kIn)] = pos;
+              else if (slot < (uint32_t)kListLen) lp.b1[at_q * 4u + (slot - kIn - 4u)] = pos;
               else atomicMin(&W.minx[lq], __float_as_uint(d));
             }
           }
         }
       }
-      bj = a + bo;
       if (COUNT) ncand += cnt;
-      if (b2 < b2_in) atomicMin(&W.best[lq], pack_best(b2, bj));
+      if (b2 < b2_in) {             // something at most as far as the match held (a real gold point: its key carries the +1)
+        const unsigned long long mine = ((unsigned long long)(__float_as_uint(b2) + 1u) << 32) | (a + bo);
+        if (mine < cur) atomicMin(&W.best[lq], mine);      // (the chunk that holds the match itself finds it again: equal keys, no atomic)
+      }
     }
   }
   nchunk = 0;
@@ -1116,7 +1164,7 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
 template <bool COUNT, bool BUILD>
 __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const LevelSet& S, uint32_t& nrow,
                                               uint32_t& nchunk, uint32_t& nrows_cnt, uint32_t& ncand, const float skin,
-                                              uint32_t* __restrict__ lists_wave, const uint32_t list_plane) {
+                                              const ListPlanes& lp, const uint32_t slot0) {
   const float4* __restrict__ gold0 = S.gold[0];
   const uint32_t* __restrict__ cs0 = S.cs[0];
   const float inv_c = S.inv_c[0];
@@ -1137,7 +1185,7 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
         const float4 p = W.pos[lq[u]];
         float b2 = __uint_as_float((uint32_t)(W.best[lq[u]] >> 32));
         if (BUILD) { const float r = fast_sqrt(b2) + skin; b2 = r * r; }
-        if (d2yz < b2) {
+        if (d2yz <= b2) {
           const float rx = fast_sqrt(b2 - d2yz) + S.delta;
           const int x0 = (int)fmaxf(floorf((p.x - rx - S.ox) * inv_c), 0.f);
           const int x1 = (int)fminf(floorf((p.x + rx - S.ox) * inv_c), (float)(nx - 1));
@@ -1165,7 +1213,7 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
         const unsigned long long mask = __ballot(has);
         if (mask == 0ull) break;
         const uint32_t cnt = (uint32_t)__popcll(mask);
-        if (nchunk + cnt > (uint32_t)kChunkCap) wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave, list_plane);
+        if (nchunk + cnt > (uint32_t)kChunkCap) wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lp, slot0);
         if (has) {
           const uint32_t pos = nchunk + lane_prefix(mask), ca = a[u] + k * kChunkLen;
           W.chunk_a[pos] = ca;
@@ -1185,14 +1233,13 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
                                             const float py, const float pz, const LevelSet& S, float& best2,
                                             uint32_t& bestj, uint32_t& nrows_cnt, uint32_t& ncand,
                                             uint32_t& ndismissed, const float skin = 0.f,
-                                            uint32_t* __restrict__ lists_wave = nullptr, float* list_radius = nullptr,
-                                            const uint32_t list_plane = 0) {
+                                            const ListPlanes& lp = ListPlanes{}, const uint32_t slot0 = 0) {
   const float c = S.c[0], inv_c = S.inv_c[0];
   const int nx = S.nx[0], ny = S.ny[0], nz = S.nz[0];
   const float4* __restrict__ gold0 = S.gold[0];
   const bool finite = has_query && isfinite(px) && isfinite(py) && isfinite(pz);
   W.pos[lane] = make_float4(px, py, pz, 0.f);
-  W.best[lane] = pack_best(best2, bestj);
+  W.best[lane] = pack_held(best2, bestj);
   if (BUILD) W.minx[lane] = 0x7F800000u;
   // list-writing launch: every pruning decision uses the sphere widened by the skin, so that everything within
   // (final match distance + skin) is examined — and put on the list by wq_flush_chunks
@@ -1212,7 +1259,7 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     const unsigned long long mask = __ballot(pred);
     const uint32_t cnt = (uint32_t)__popcll(mask);
     if (cnt == 0u) return;
-    if (nrow + cnt > (uint32_t)kRowCap) wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave, list_plane);
+    if (nrow + cnt > (uint32_t)kRowCap) wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lp, slot0);
     if (pred) {
       const uint32_t pos = nrow + lane_prefix(mask);
       W.row_cell[pos] = (uint32_t)((z * ny + y) * nx);
@@ -1230,7 +1277,7 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
   auto gap2 = [&](const int d, const float f, const int ci, const int n) -> float {
     const float lo = ((float)d * c - S.delta) - f, hi = f - ((float)(d + 1) * c + S.delta);
     const float t = fmaxf(0.f, fmaxf(lo, hi));
-    return (unsigned)(ci + d) < (unsigned)n ? t * t : INFINITY;
+    return (unsigned)(ci + d) < (unsigned)n ? t * t : NAN;     // outside the grid: no comparison with it holds (<= included)
   };
   {
     const float gy[3] = {gap2(0, fy, cy, ny), gap2(-1, fy, cy, ny), gap2(1, fy, cy, ny)};
@@ -1239,17 +1286,17 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     for (int k = 0; k < 9; ++k) {
       const int dy = (k % 3 == 0) ? 0 : (k % 3 == 1 ? -1 : 1), dz = (k / 3 == 0) ? 0 : (k / 3 == 1 ? -1 : 1);
       const float d2yz = gy[k % 3] + gz[k / 3];
-      push_row(finite && d2yz < bi, cy + dy, cz + dz, d2yz);
+      push_row(finite && d2yz <= bi, cy + dy, cz + dz, d2yz);
     }
   }
-  wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave, list_plane);
-  wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave, list_plane);
+  wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lp, slot0);
+  wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lp, slot0);
 #if MA_WGTIMES
   if (lane == 0) W.dbg_round0 = wall_clock64();
 #endif
   {
     const unsigned long long key = W.best[lane];
-    best2 = __uint_as_float((uint32_t)(key >> 32));
+    best2 = held_d2(key);
     bestj = (uint32_t)key;
     bi = reach(best2);
   }
@@ -1291,13 +1338,13 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
         const int dvar = side < 2 ? o - r : r - o;
         const float d2yz = gfix + gap2(dvar, fvar, cvar, nvar);
         const int dy = zfixed ? dvar : dfix, dz = zfixed ? dfix : dvar;
-        push_row(more && d2yz < bi, cy + dy, cz + dz, d2yz);
+        push_row(more && d2yz <= bi, cy + dy, cz + dz, d2yz);
       }
     }
-    wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lists_wave, list_plane);
-    wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lists_wave, list_plane);
+    wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lp, slot0);
+    wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lp, slot0);
     const unsigned long long key = W.best[lane];
-    best2 = __uint_as_float((uint32_t)(key >> 32));
+    best2 = held_d2(key);
     bestj = (uint32_t)key;
     bi = reach(best2);
   }
@@ -1315,11 +1362,19 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     if (!finite) L = INFINITY;
     const uint32_t kept = min(cnt, (uint32_t)kListLen);
     if (has_query) {
-      const uint32_t fill = bestj != kNoMatch ? bestj : 0u;     // any gold point may sit on a list: a superset stays exact
-      for (uint32_t sl = kept; sl < 4u; ++sl) lists_wave[lane * 4u + sl] = fill;
-      if (kept > 4u) for (uint32_t sl = kept; sl < (uint32_t)kListLen; ++sl) lists_wave[list_plane - 4u + lane * 4u + sl] = fill;
+      const uint32_t at_q = slot0 + (uint32_t)lane;
+      // unused inline entries never pass the gate; unused positions of a plane that is read repeat the match (any gold
+      // point may sit on a list: a superset stays exact)
+      constexpr uint32_t kIn = (uint32_t)kListInline;
+      const float4 none = make_float4(INFINITY, INFINITY, INFINITY, __uint_as_float(kNoMatch));
+      if (kIn > 0u && kept < 1u) lp.a0[at_q] = none;
+      if (kIn > 1u && kept < 2u) lp.a1[at_q] = none;
+      const uint32_t fill = bestj != kNoMatch ? bestj : 0u;
+      // plane b0 is read when the list has more than kIn entries (always, without inline entries), b1 beyond kIn + 4
+      if (kIn == 0u || kept > kIn) for (uint32_t sl = max(kept, kIn); sl < kIn + 4u; ++sl) lp.b0[at_q * 4u + (sl - kIn)] = fill;
+      if (kept > kIn + 4u) for (uint32_t sl = kept; sl < (uint32_t)kListLen; ++sl) lp.b1[at_q * 4u + (sl - kIn - 4u)] = fill;
+      lp.rad[at_q] = isfinite(L) ? __uint_as_float((__float_as_uint(L) & ~0xFu) | kept) : L;
     }
-    *list_radius = isfinite(L) ? __uint_as_float((__float_as_uint(L) & ~0xFu) | kept) : L;
   }
 }
 
@@ -1384,14 +1439,15 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     const float4* __restrict__ src, const uint32_t n, const LevelSet S,
     const uint32_t* __restrict__ perm0, const DevState* __restrict__ st, const float best2_init,
     double* __restrict__ partials, uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, const Sched sched, const ListCtl* __restrict__ lc, uint32_t* __restrict__ lists,
-    float* __restrict__ lrad) {
+    float* __restrict__ nn_d2, const Sched sched, const ListCtl* __restrict__ lc, const ListPlanes lp) {
   if (MODE == 0 && st->done) return;
   constexpr int lmode = MODE == 0 ? LISTS : 0;
   const unsigned long long wg_start = wall_clock64();
   constexpr int kNW = kNNBlock / kWave;
   const uint32_t G = gridDim.x;
   const bool warm = st->iter > 0;          // iteration 0 of a run: no schedule yet, and prev[] holds another run's matches
+  // (list launches too: an XCD that works on contiguous pieces of the cloud keeps the gold lines its gathers touch in
+  // its own L2 — chunks in plain launch order, dealt round-robin over the XCDs, cost 2.5 us of a 23-us launch)
   const uint32_t chunk = xcd_chunk(blockIdx.x, sched, sched.order != nullptr && warm);
   const uint32_t i = chunk * kNNBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
@@ -1413,9 +1469,12 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   double Px = 0.0, Py = 0.0, Pz = 0.0;
   auto image = [&](const uint32_t at) {
     s = src[at];
-    Px = st->R[0] * s.x + st->R[1] * s.y + st->R[2] * s.z + st->t[0];
-    Py = st->R[3] * s.x + st->R[4] * s.y + st->R[5] * s.z + st->t[1];
-    Pz = st->R[6] * s.x + st->R[7] * s.y + st->R[8] * s.z + st->t[2];
+    // one association, spelled out: the search launches form the image twice (before and after the search), a list
+    // launch once, and all of them must arrive at the same bits whatever the compiler would contract
+    const double x = s.x, y = s.y, z = s.z;
+    Px = __fma_rn(st->R[2], z, __fma_rn(st->R[1], y, __fma_rn(st->R[0], x, st->t[0])));
+    Py = __fma_rn(st->R[5], z, __fma_rn(st->R[4], y, __fma_rn(st->R[3], x, st->t[1])));
+    Pz = __fma_rn(st->R[8], z, __fma_rn(st->R[7], y, __fma_rn(st->R[6], x, st->t[2])));
   };
   float px = 0.f, py = 0.f, pz = 0.f, best2 = best2_init;
   uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
@@ -1438,16 +1497,24 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
 #if MA_WGTIMES
   const unsigned long long dbg_t1 = wall_clock64();
 #endif
+  float wqx = 0.f, wqy = 0.f, wqz = 0.f;      // list launch: the winner's coordinates, carried with the minimum
   if constexpr (lmode == 2) {
     // ---- list launch: the nearest of the (at most 8) gold points on the query's list IS the nearest neighbour
     // while (its distance, capped at the gate) + (how far the query has moved since the list was written) stays
     // inside the radius the list is complete for; a query that fails the check searches (per-lane, exact).
+    // Streams: the source point, the two inline entries and the radius — 52 bytes per query, every one of them
+    // coalesced; only a list of more than two entries reads positions and gathers.  No remembered match is read or
+    // written: the tie rule needs none, and a later search launch may start from an older one (any gold point is a
+    // valid first candidate).
     if (has) {
       const bool finite = isfinite(px) && isfinite(py) && isfinite(pz);
-      const uint4 l0 = reinterpret_cast<const uint4*>(lists)[i];
-      const float Lq = lrad[i];
-      const uint32_t nlist = __float_as_uint(Lq) & 0xFu;     // entries on the list; 5-8 live in the second plane
-      const uint32_t* __restrict__ lists_hi = lists + (size_t)gridDim.x * kNNBlock * 4u;
+      constexpr uint32_t kIn = (uint32_t)kListInline;
+      float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
+      uint4 lb0 = make_uint4(0u, 0u, 0u, 0u);
+      if (kIn > 0u) { e0 = lp.a0[i]; e1 = lp.a1[i]; }
+      else lb0 = reinterpret_cast<const uint4*>(lp.b0)[i];           // without inline entries the first plane is read by every query
+      const float Lq = lp.rad[i];
+      const uint32_t nlist = __float_as_uint(Lq) & 0xFu;     // entries on the list
       // how far this query has moved since its list was written: (R - Rb) s + (t - tb), wave-uniform differences
       float dRf[9], dtf[3];
 #pragma unroll
@@ -1459,41 +1526,48 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       const float mz = dRf[6] * s.x + dRf[7] * s.y + dRf[8] * s.z + dtf[2];
       const float moved = fast_sqrt(mx * mx + my * my + mz * mz) + lc->slack;
       unsigned long long key = pack_best(best2, kNoMatch);
-      // the search starts from last iteration's match and only a strictly nearer point replaces it: same rule here
-      const uint32_t pj = (prev && warm) ? prev[i] : kNoMatch;
-      float d_pj = INFINITY;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {          // four gathers in flight at a time (eight cost 12 more registers)
-        if (h == 1 && nlist <= 4u) break;
-        const uint4 lh = h == 0 ? l0 : reinterpret_cast<const uint4*>(lists_hi)[i];
-        const uint32_t idx[4] = {lh.x, lh.y, lh.z, lh.w};
+      auto consider = [&](const float qx, const float qy, const float qz, const uint32_t pos) {
+        const float d = dist2(px - qx, py - qy, pz - qz);
+        const unsigned long long ku = pack_best(d, pos);
+        if (d < best2_init && ku < key) { key = ku; wqx = qx; wqy = qy; wqz = qz; }      // the tie rule: smallest (distance, position)
+      };
+      if (kIn > 0u) {
+        consider(e0.x, e0.y, e0.z, __float_as_uint(e0.w));
+        consider(e1.x, e1.y, e1.z, __float_as_uint(e1.w));
+      }
+      if (kIn == 0u || nlist > kIn) {
+        if (kIn > 0u) lb0 = reinterpret_cast<const uint4*>(lp.b0)[i];
+        const uint32_t idx[4] = {lb0.x, lb0.y, lb0.z, lb0.w};
         float3 q[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) q[u] = ld_xyz(S.gold[0], idx[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float dx = px - q[u].x, dy = py - q[u].y, dz = pz - q[u].z;
-          const float d = dx * dx + dy * dy + dz * dz;
-          const unsigned long long ku = pack_best(d, idx[u]);
-          if (d < best2_init && ku < key) key = ku;      // equal distances: the smaller position, as in the search
-          if (idx[u] == pj) d_pj = d;
+        for (int u = 0; u < 4; ++u) consider(q[u].x, q[u].y, q[u].z, idx[u]);
+        if (nlist > kIn + 4u) {
+          const uint4 lb1 = reinterpret_cast<const uint4*>(lp.b1)[i];
+          const uint32_t idx1[4] = {lb1.x, lb1.y, kIn == 0u ? lb1.z : lb1.x, kIn == 0u ? lb1.w : lb1.y};     // (two in use beside inline entries)
+          float3 r[4];
+#pragma unroll
+          for (int u = 0; u < (kIn == 0u ? 4 : 2); ++u) r[u] = ld_xyz(S.gold[0], idx1[u]);
+#pragma unroll
+          for (int u = 0; u < (kIn == 0u ? 4 : 2); ++u) consider(r[u].x, r[u].y, r[u].z, idx1[u]);
         }
       }
-      if (d_pj < best2_init && __float_as_uint(d_pj) == (uint32_t)(key >> 32)) key = pack_best(d_pj, pj);
       best2 = __uint_as_float((uint32_t)(key >> 32));
       bestj = (uint32_t)key;
-      if (COUNT) ncand += nlist;
+      // work counters of a list launch: candidates = entries on the list; 4-byte words = the positions read from the
+      // planes b0 / b1 (each is followed by one 12-byte gather), plus what a failed check's search reads
+      if (COUNT) { ncand += nlist; nrows += nlist > kIn + 4u ? kListLen - kIn : ((kIn == 0u || nlist > kIn) ? 4u : 0u); }
       if (!finite) {
         bestj = kNoMatch;
       } else if (!(fast_sqrt(best2) + moved < Lq)) {
         nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
+        if (bestj != kNoMatch) { const float3 q = ld_xyz(S.gold[0], bestj); wqx = q.x; wqy = q.y; wqz = q.z; }
       }
     }
   } else if constexpr (lmode == 1) {
-    float Lr = 0.f;
     wave_search<COUNT, true>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand, ndismissed, lc->skin,
-                             lists + (size_t)(i - (uint32_t)lane) * 4u, &Lr, gridDim.x * (uint32_t)kNNBlock * 4u);
-    if (has) lrad[i] = Lr;
+                             lp, i - (uint32_t)lane);
     if (blockIdx.x == 0 && threadIdx.x == 0) {      // the transform these lists belong to
       ListCtl* __restrict__ w = const_cast<ListCtl*>(lc);
 #pragma unroll
@@ -1516,8 +1590,12 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
   if (has) {
+#if MA_DEBUG_FETCH      // debug build (tools/tie_debug.py): list launches leave their matches behind too
     if (prev) prev[i] = bestj;
-    if (MODE == 0) {
+#else
+    if (prev && lmode != 2) prev[i] = bestj;
+#endif
+    if (MODE == 0 && lmode != 2) {       // (a list launch has no search in between: its point stays in registers)
       uint32_t again = i;
       asm volatile("" : "+v"(again));   // opaque copy of the index: the compiler must not keep s, P live instead
       image(again);
@@ -1527,7 +1605,9 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       nn_d2[i] = bestj != kNoMatch ? best2 : INFINITY;
     }
     if (MODE == 0 && bestj != kNoMatch) {
-      const float3 q = ld_xyz(S.gold[0], bestj);   // the winner's coordinates (level 0 holds every point)
+      float3 q;
+      if constexpr (lmode == 2) q = make_float3(wqx, wqy, wqz);     // carried with the minimum: the very bits of the gold array
+      else q = ld_xyz(S.gold[0], bestj);           // the winner's coordinates (level 0 holds every point)
       const double w = (double)s.w;
       const double qx = q.x, qy = q.y, qz = q.z;
       const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
@@ -1538,7 +1618,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       acc[7] = wPx * qx;  acc[8] = wPx * qy;  acc[9] = wPx * qz;
       acc[10] = wPy * qx; acc[11] = wPy * qy; acc[12] = wPy * qz;
       acc[13] = wPz * qx; acc[14] = wPz * qy; acc[15] = wPz * qz;
-      acc[16] = w * (dx * dx + dy * dy + dz * dz);
+      acc[16] = w * __fma_rn(dz, dz, __fma_rn(dy, dy, dx * dx));
     }
     if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
   }
@@ -1718,7 +1798,11 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
     s0.done = 1;
     *st = s0;
     if (host_mirror) *host_mirror = s0;
-    if (host_done) *host_done = 1;
+    if (host_done) *host_done = s0.iter;     // iterations run when the loop stopped (never 0)
+    if (slot) {                              // every iteration up to and including the one that stops the loop writes its slot
+      *const_cast<unsigned long long*>(&slot->chk) = slot_check(s0.R, s0.t, s0.iter);
+      *const_cast<int*>(&slot->seq) = s0.iter;
+    }
     return;
   }
   double Rn[9], tn[3];
@@ -1736,8 +1820,9 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
   if (it >= 1 && fabs(rmse - s0.prev_rmse) < tol) {
     s0.converged = 1;
     s0.done = 1;
-    // pinned host word: lets ma_icp stop enqueueing launches that would only find `done` set
-    if (host_done) *host_done = 1;
+    // pinned host word: lets ma_icp stop enqueueing launches that would only find `done` set; its value is the number
+    // of iterations run, so that every rank of a sharded loop stops enqueueing at the same iteration
+    if (host_done) *host_done = s0.iter;
   }
   s0.prev_rmse = rmse;
   *st = s0;
@@ -1755,12 +1840,13 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
 // The solve alone (sharded-source stepping: the 17 sums come back from the all-reduce).
 __global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_in, DevState* __restrict__ st,
                                                  double* __restrict__ trace, const int trace_cap,
-                                                 const double tol, int* __restrict__ host_done) {
+                                                 const double tol, int* __restrict__ host_done,
+                                                 DevState* __restrict__ host_mirror, StateSlot* __restrict__ slot) {
   if (st->done || threadIdx.x != 0) return;
   double a[kNAcc];
 #pragma unroll
   for (int k = 0; k < kNAcc; ++k) a[k] = acc_in[k];
-  solve_step(a, *st, st, trace, trace_cap, tol, host_done);
+  solve_step(a, *st, st, trace, trace_cap, tol, host_done, host_mirror, slot);
 }
 
 // a5 (final sum) + a6 + a7 in ONE launch: the 19 reducing workgroups of k_reduce19, and the
@@ -2262,6 +2348,9 @@ struct DevBuf {
 };
 
 thread_local std::string g_create_error;
+// the message of the calling THREAD's last ma_ctx::fail: ma_set_pair runs two threads on one context, and which of two
+// failures a context reports must not depend on which thread wrote its message last
+thread_local std::string t_last_fail;
 
 }  // namespace
 
@@ -2314,20 +2403,28 @@ struct ma_ctx {
   bool gap_list_dirty = false;
   DevBuf probe_marks;            // mark tables of the occupancy probes: all-zero between calls (occupied_cells_multi)
   size_t probe_clean = 0;        //   bytes of it known to be zero
-  char* mailbox = nullptr;       // pinned host memory, 2 x kMailBytes: the small results of the build kernels land here (Mailbox below)
+  char* mailbox = nullptr;       // pinned host memory, 3 x kMailBytes: the small results of the build kernels land here (Mailbox below); the third block: k_unproject's counts
 
   // batched box lifting (a10 over many frames)
   DevBuf lift_poses, lift_frames;
-  DevBuf unproj_cnt;             // valid pixels per workgroup of the last k_unproject launch
+  DevBuf unproj_cnt;             // valid pixels per workgroup of the last k_unproject launch (frames too large for the pinned block)
+  bool unproj_pending = false;   // a k_unproject launch whose count of valid pixels has not been added up yet (finish_unproject)
+  bool unproj_is_source = false; //   ... and it wrote the source cloud: the count settles n_pts / src_holes / MA_ERR_EMPTY
+  uint32_t unproj_blocks = 0, unproj_total = 0;
 
   // loop state
   DevBuf state, partials, trace, acc19, ticket, wg_cost, seg_order, nn_idx, nn_d2, nn_tmp, prev;
   // candidate lists of the loop (k_nn_accum): 8 gold positions + one radius per source slot, and the control block
-  DevBuf lists, lrad, listctl;
+  DevBuf lists, listctl;      // lists: the five planes of ListPlanes, back to back
   float src_rs = 0.f;                          // largest distance of a corner of the source cloud's box from the centring origin; 0: unknown, no lists
   float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // that box (centred frame)
   bool src_box_pending = false;                // source from a depth frame: the box is computed by the first run that can use it
-  bool lists_on = false;                       // set by ma_icp around its loop
+  bool lists_on = false;                       // set by the loop (icp_loop) around its launches
+  bool cfg_lists = true;                       // ma_list_config: lists allowed at all; skin = cell edge / cfg_skin_div; a write must
+  float cfg_skin_div = ma::kSkinDivDefault;    //   be followed by >= cfg_min_uses predicted uses
+  int cfg_min_uses = ma::kMinUsesDefault;
+  int cfg_planner_timeout_us = 20 * 1000 * 1000;   // how long the planner waits for a slot before it falls back (MAPALIGN_PLANNER_TIMEOUT_US: tests)
+  int32_t plan_diag[4] = {0, 0, 0, 0};         // last loop: planner waits, waits that left the spin for yields, timeouts, iterations enqueued
   ListCtl* host_lc = nullptr;                  // pinned: the control block a run starts from
   StateSlot* host_slots = nullptr;             // pinned, kMaxSlots slots: the state every solve of a list-planning loop produced
   int list_builds = 0, list_uses = 0;          // launches of the last ma_icp that wrote / read the lists
@@ -2356,6 +2453,7 @@ struct ma_ctx {
 
   std::mutex err_mu;             // ma_set_pair stages the scan on a helper thread: both threads may report
   int fail(int code, const std::string& msg) {
+    t_last_fail = msg;
     std::lock_guard<std::mutex> lock(err_mu);
     err = msg;
     return code;
@@ -2377,7 +2475,7 @@ struct ma_ctx {
     std::vector<DevBuf*> v = {&map_pts, &map_keys_a, &map_keys_b, &map_flags, &map_seg, &map_acc, &map_pre, &map_heads, &perm0, &occ_a, &occ_b, &probe_marks, &gap_list,
                               &src, &src_perm, &raw, &raw_src, &raw64_src, &akeys_a, &akeys_b, &avals_a, &avals_b, &acub_tmp, &amisc, &raw64, &wts, &keys_a, &keys_b, &vals_a, &vals_b, &cub_tmp, &misc,
                               &depth_in, &lift_poses, &lift_frames, &unproj_cnt, &state, &partials, &trace, &acc19, &ticket,
-                              &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev, &lists, &lrad, &listctl};
+                              &wg_cost, &seg_order, &nn_idx, &nn_d2, &nn_tmp, &prev, &lists, &listctl};
     for (int l = 0; l < kLevels; ++l) { v.push_back(&gold[l]); v.push_back(&cstart[l]); }
     return v;
   }
@@ -2646,17 +2744,27 @@ int occupied_cells(ma_ctx* ctx, const float* d_xyz, uint32_t n, const GridP& g, 
   return occupied_cells_multi(ctx, d_xyz, n, &g, 1, o, out);
 }
 
-// MAPALIGN_LISTS=0 in the environment: every launch of the loop searches (A/B runs, and the tests that compare both)
-bool lists_enabled() {
+// Candidate lists are a per-context setting (ma_list_config; MA_FLAG_NO_LISTS switches them off for one run).  The
+// environment only supplies the defaults a context is created with: MAPALIGN_LISTS=0 every launch searches,
+// MAPALIGN_SKIN_DIV=<d> skin = cell edge / d, MAPALIGN_MIN_USES=<n> (sweeps).  Nothing is read from the environment
+// after ma_create.
+using ma::kSkinDivDefault;
+using ma::kMinUsesDefault;
+void list_config_from_env(ma_ctx* ctx) {
   const char* e = std::getenv("MAPALIGN_LISTS");
-  return !(e && e[0] == '0');
-}
-// skin of the candidate lists = cell edge / this (MAPALIGN_SKIN_DIV overrides it for sweeps)
-float list_skin_div() {
-  const char* e = std::getenv("MAPALIGN_SKIN_DIV");
+  ctx->cfg_lists = !(e && e[0] == '0');
+  e = std::getenv("MAPALIGN_SKIN_DIV");
   const float v = e ? (float)std::atof(e) : 0.f;
-  return v >= 2.f && v <= 64.f ? v : 7.f;
+  ctx->cfg_skin_div = v >= 2.f && v <= 64.f ? v : kSkinDivDefault;
+  e = std::getenv("MAPALIGN_MIN_USES");
+  const int u = e ? std::atoi(e) : 0;
+  ctx->cfg_min_uses = u >= 1 && u <= 64 ? u : kMinUsesDefault;
+  e = std::getenv("MAPALIGN_PLANNER_TIMEOUT_US");       // fault injection for the tests: make the planner's wait give up early
+  const long t = e ? std::atol(e) : 0;
+  if (t >= 1 && t <= 60L * 1000 * 1000) ctx->cfg_planner_timeout_us = (int)t;
 }
+bool lists_enabled(const ma_ctx* ctx) { return ctx->cfg_lists; }
+float list_skin_div(const ma_ctx* ctx) { return ctx->cfg_skin_div; }
 
 int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
   HIPCHK(ctx->state.ensure(sizeof(DevState)));
@@ -2664,10 +2772,9 @@ int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
   HIPCHK(ctx->acc19.ensure(kNAcc * sizeof(double)));
   HIPCHK(ctx->wg_cost.ensure((size_t)grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(uint32_t)));
   HIPCHK(ctx->listctl.ensure(sizeof(ListCtl)));
-  if (ctx->have_src && lists_enabled()) {      // candidate lists: sized with the other loop buffers, so that no later run allocates
+  if (ctx->have_src && lists_enabled(ctx)) {      // candidate lists: sized with the other loop buffers, so that no later run allocates
     const size_t slots = (size_t)grid_for(std::max<uint32_t>(ctx->n, 1)) * kNNBlock;
-    HIPCHK(ctx->lists.ensure(slots * kListLen * sizeof(uint32_t)));
-    HIPCHK(ctx->lrad.ensure(slots * sizeof(float)));
+    HIPCHK(ctx->lists.ensure(slots * kListBytesPerSlot));
   }
   if (!ctx->seg_order.p) {  // never read before the first ranking wrote it (order is used from iteration 1 on); zeroed anyway
     HIPCHK(ctx->seg_order.ensure((size_t)kMaxGroups * sizeof(uint32_t)));
@@ -2702,8 +2809,8 @@ int upload_state(ma_ctx* ctx, const double* T) {
     // candidate lists: none yet; the skin is a seventh of the cell edge (the density rule puts ~4.5 points into an
     // occupied cell, so a list then holds 2-3 points on average and overflows 8 for < 0.2 % of the queries)
     ListCtl c{};
-    c.skin = ctx->grid.c / list_skin_div();
-    c.rs = (ctx->have_src && lists_enabled()) ? ctx->src_rs : 0.f;
+    c.skin = ctx->grid.c / list_skin_div(ctx);
+    c.rs = (ctx->have_src && lists_enabled(ctx)) ? ctx->src_rs : 0.f;
     for (int a = 0; a < 3; ++a) { c.blo[a] = ctx->src_lo[a]; c.bhi[a] = ctx->src_hi[a]; }
     c.slack = 1e-5f + 4e-7f * ctx->src_rs;
     *ctx->host_lc = c;
@@ -2727,17 +2834,23 @@ int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float
   Sched sched{nullptr, nullptr, gshift};
   if (scheduled) { sched.wg_cost = ctx->wg_cost.as<uint32_t>(); sched.order = ctx->seg_order.as<uint32_t>(); }
   const bool with_lists = MODE == 0 && ctx->lists_on && list_kind != 0;
+  ListPlanes lp{};
   if (with_lists) {      // one list and one radius per slot of the launched grid
-    HIPCHK(ctx->lists.ensure((size_t)G * kNNBlock * kListLen * sizeof(uint32_t)));
-    HIPCHK(ctx->lrad.ensure((size_t)G * kNNBlock * sizeof(float)));
+    const size_t slots = (size_t)G * kNNBlock;
+    HIPCHK(ctx->lists.ensure(slots * kListBytesPerSlot));
+    char* base = ctx->lists.as<char>();
+    lp.a0 = reinterpret_cast<float4*>(base);
+    lp.a1 = reinterpret_cast<float4*>(base + slots * 16);
+    lp.b0 = reinterpret_cast<uint32_t*>(base + slots * 32);
+    lp.b1 = reinterpret_cast<uint32_t*>(base + slots * 48);
+    lp.rad = reinterpret_cast<float*>(base + slots * 64);
   }
   auto args = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(G), dim3(kNNBlock), 0, ctx->stream, ctx->src.as<float4>(), ctx->n,
                        ctx->levels, ctx->perm0.as<uint32_t>(), ctx->state.as<DevState>(), best2_init,
                        ctx->partials.as<double>(),
                        MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, nn_idx, nn_d2, sched,
-                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, ctx->lists.as<uint32_t>(),
-                       ctx->lrad.as<float>());
+                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, lp);
   };
   if (MODE == 0 && with_lists && list_kind == 1) {
     if (count) args(k_nn_accum<true, MODE == 0 ? 0 : 1, MODE == 0 ? 1 : 0>);
@@ -2768,15 +2881,18 @@ int launch_reduce_solve(ma_ctx* ctx, double tol, StateSlot* slot = nullptr) {
   hipLaunchKernelGGL(k_reduce_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
                      ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>(), ctx->ticket.as<uint32_t>(),
                      ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(),
-                     ctx->seg_order.as<uint32_t>(), ctx->last_gshift, (tol > 0.0 || ctx->lists_on) ? ctx->host_done : (int*)nullptr,
+                     ctx->seg_order.as<uint32_t>(), ctx->last_gshift, ctx->host_done,
                      slot ? &slot->s : ctx->host_state_out, slot);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
 
-int launch_solve(ma_ctx* ctx, double tol) {
+// in_loop: inside the sharded loop (pinned `done` word, pinned mirror of the state, planner slot)
+int launch_solve(ma_ctx* ctx, double tol, bool in_loop = false, StateSlot* slot = nullptr) {
   hipLaunchKernelGGL(k_solve, dim3(1), dim3(kWave), 0, ctx->stream, ctx->acc19.as<double>(),
-                     ctx->state.as<DevState>(), ctx->trace.as<double>(), ctx->trace_cap, tol, (int*)nullptr);
+                     ctx->state.as<DevState>(), ctx->trace.as<double>(), ctx->trace_cap, tol,
+                     in_loop ? ctx->host_done : (int*)nullptr,
+                     in_loop ? (slot ? &slot->s : ctx->host_state_out) : (DevState*)nullptr, slot);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
@@ -2799,28 +2915,76 @@ void fill_stats(const DevState& s, double gpu_ms, ma_stats* st) {
 }
 
 // Depth frame already in ctx->depth_in -> one slot per pixel at `out` (k_unproject: points and holes).
-// *total receives the number of valid pixels; ev0/ev1 bracket the device work.
-int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinhole& cam, float4* out, uint32_t* total) {
-  const uint32_t nb = div_up(npx, kPxPerBlock);
-  HIPCHK(ctx->unproj_cnt.ensure((size_t)nb * 4));
-  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-  if (dtype == 0)
-    hipLaunchKernelGGL(k_unproject<float>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(), width, npx, cam,
-                       ctx->unproj_cnt.as<uint32_t>(), out);
-  else
-    hipLaunchKernelGGL(k_unproject<uint16_t>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<uint16_t>(), width, npx,
-                       cam, ctx->unproj_cnt.as<uint32_t>(), out);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-  std::vector<uint32_t> h(nb);
-  HIPCHK(hipMemcpyAsync(h.data(), ctx->unproj_cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+// ev0/ev1 bracket the device work.  The kernel writes its per-workgroup counts of valid pixels straight into pinned
+// host memory (the third mailbox block), so the NUMBER of valid pixels costs no device-to-host copy — and no
+// synchronisation at all unless somebody asks for it: total != nullptr waits and adds the counts up; with nullptr the
+// call only enqueues, and finish_unproject() settles the count when it is first needed (round 3: a pageable copy
+// of the count array and a stream sync in every call, 0.21 ms of host wall for 14 us of device work).
+int finish_unproject(ma_ctx* ctx) {
+  if (!ctx->unproj_pending) return MA_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->unproj_pending = false;
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->last_op_ms = ms;
+  const uint32_t* h = reinterpret_cast<const uint32_t*>(ctx->mailbox + 2 * kMailBytes);
   uint64_t t = 0;
-  for (uint32_t c : h) t += c;
-  *total = (uint32_t)t;
+  for (uint32_t b = 0; b < ctx->unproj_blocks; ++b) t += h[b];
+  ctx->unproj_total = (uint32_t)t;
+  if (ctx->unproj_is_source) {          // the frame is the source cloud: what the count decides
+    ctx->n_pts = ctx->unproj_total;
+    ctx->src_holes = ctx->unproj_total != ctx->n;
+    if (ctx->unproj_total == 0) {
+      ctx->have_src = false;
+      return ctx->fail(MA_ERR_EMPTY, "depth image has no valid pixel");
+    }
+  }
+  return MA_OK;
+}
+
+int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinhole& cam, float4* out, uint32_t* total,
+                    bool is_source) {
+  const uint32_t nb = div_up(npx, kPxPerBlock);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(ctx->mailbox + 2 * kMailBytes);       // pinned: the kernel stores there
+  const bool pinned = (size_t)nb * 4 <= kMailBytes;
+  if (!pinned) {                     // a frame above 16.7 MP: counts in device memory, copied back
+    HIPCHK(ctx->unproj_cnt.ensure((size_t)nb * 4));
+    counts = ctx->unproj_cnt.as<uint32_t>();
+  }
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  if (dtype == 0)
+    hipLaunchKernelGGL(k_unproject<float>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(), width, npx, cam,
+                       counts, out);
+  else
+    hipLaunchKernelGGL(k_unproject<uint16_t>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<uint16_t>(), width, npx,
+                       cam, counts, out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  if (!pinned) {
+    std::vector<uint32_t> h(nb);
+    HIPCHK(hipMemcpyAsync(h.data(), ctx->unproj_cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->last_op_ms = ms;
+    uint64_t t = 0;
+    for (uint32_t c : h) t += c;
+    ctx->unproj_total = (uint32_t)t;
+    ctx->unproj_pending = false;
+    if (total) *total = ctx->unproj_total;
+    return MA_OK;
+  }
+  ctx->unproj_pending = true;
+  ctx->unproj_blocks = nb;
+  ctx->unproj_is_source = is_source;
+  if (total) {
+    const bool was_source = ctx->unproj_is_source;
+    ctx->unproj_is_source = false;          // the caller looks at the total itself
+    int rc = finish_unproject(ctx);
+    ctx->unproj_is_source = was_source;
+    if (rc) return rc;
+    *total = ctx->unproj_total;
+  }
   return MA_OK;
 }
 
@@ -2828,6 +2992,7 @@ int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinho
 // map of a cloud with holes (built here, once per cloud, when first needed), or null (identity).
 int source_map(ma_ctx* ctx, const uint32_t** map) {
   *map = nullptr;
+  { const int rc0 = finish_unproject(ctx); if (rc0) return rc0; }     // whether the cloud has holes is the count's to say
   if (ctx->src_sorted) { *map = ctx->src_perm.as<uint32_t>(); return MA_OK; }
   if (!ctx->src_holes) return MA_OK;
   if (!ctx->src_map_ready) {
@@ -3013,9 +3178,10 @@ int ma_create(int device, ma_ctx** out) {
   static_assert(sizeof(ListCtl) <= 256 && sizeof(DevState) <= 256, "pinned block slots");
   ctx->host_lc = reinterpret_cast<ListCtl*>(reinterpret_cast<char*>(ctx->host_done) + 1024);
   ctx->host_slots = reinterpret_cast<StateSlot*>(reinterpret_cast<char*>(ctx->host_done) + 1280);
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), 2 * kMailBytes, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-  std::memset(ctx->mailbox, 0, 2 * kMailBytes);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->mailbox), 3 * kMailBytes, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+  std::memset(ctx->mailbox, 0, 3 * kMailBytes);
   for (DevBuf* b : ctx->all_bufs()) b->stats = &ctx->mem;
+  list_config_from_env(ctx);
   *out = ctx;
   return MA_OK;
   });
@@ -3071,6 +3237,7 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
   HIPCHK(hipSetDevice(ctx->device));
   ctx->have_gold = false;
   ctx->have_src = false;
+  ctx->unproj_pending = false;
   ctx->state_valid = false;
   const uint32_t n = (uint32_t)m;
   HIPCHK(ctx->raw.ensure((size_t)n * 12));
@@ -3302,6 +3469,7 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
   if (n64 >= (1ull << 31)) return ctx->fail(MA_ERR_TOO_LARGE, "source cloud has 2^31 or more points (32-bit item counts of the sort)");
   HIPCHK(hipSetDevice(ctx->device));
   ctx->have_src = false;
+  ctx->unproj_pending = false;
   ctx->state_valid = false;
   const uint32_t n = (uint32_t)n64;
   HIPCHK(ctx->raw.ensure((size_t)n * 12));
@@ -3326,6 +3494,7 @@ static int set_pair_impl(ma_ctx* ctx, const void* gold_xyz, uint64_t m, float ce
   HIPCHK(hipSetDevice(ctx->device));
   ctx->have_gold = false;
   ctx->have_src = false;
+  ctx->unproj_pending = false;
   ctx->state_valid = false;
   const uint32_t mg = (uint32_t)m, n = (uint32_t)n64;
   const size_t in_bytes = f64 ? 24 : 12;
@@ -3365,7 +3534,9 @@ static int set_pair_impl(ma_ctx* ctx, const void* gold_xyz, uint64_t m, float ce
   // map's build is the longer chain, so its 12 MB go first and undisturbed.
   std::atomic<int> gold_uploaded{0};      // 0: wait, 1: go (shift[] is final), 2: give up
   int rc_src = MA_OK;
+  std::string msg_src;             // the helper's own failure message (reported once, by the calling thread, after the join)
   std::thread helper([&]() {
+    struct KeepMessage { std::string& m; int& rc; ~KeepMessage() { if (rc != MA_OK) m = t_last_fail; } } keep{msg_src, rc_src};
     try {
       MA_PT("scan: helper thread runs");
       hipError_t e = hipSetDevice(ctx->device);
@@ -3431,7 +3602,12 @@ static int set_pair_impl(ma_ctx* ctx, const void* gold_xyz, uint64_t m, float ce
   pt_dump();
 #endif
   if (rc_gold || rc_src) {
+    // ONE report, on the calling thread: the gold map's failure if it had one (its message is this thread's last), else
+    // the scan's, with the message the helper thread left behind
+    if (rc_gold) (void)ctx->fail(rc_gold, t_last_fail);
+    else if (!msg_src.empty()) (void)ctx->fail(rc_src, msg_src);
     ctx->have_src = false;
+    ctx->unproj_pending = false;
     if (rc_gold) ctx->have_gold = false;
     return rc_gold ? rc_gold : rc_src;
   }
@@ -3554,6 +3730,7 @@ int ma_set_gold_f64(ma_ctx* ctx, const double* xyz, uint64_t m, float cell, doub
   HIPCHK(hipSetDevice(ctx->device));
   ctx->have_gold = false;
   ctx->have_src = false;
+  ctx->unproj_pending = false;
   ctx->state_valid = false;
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   int rc = stage_f64(ctx, xyz, (uint32_t)m, true, shift_out);
@@ -3573,6 +3750,7 @@ int ma_set_source_f64(ma_ctx* ctx, const double* xyz, const float* weights, uint
   if (shift) for (int a = 0; a < 3; ++a) { if (!std::isfinite(shift[a])) return ctx->fail(MA_ERR_INVALID, "non-finite shift"); s[a] = shift[a]; }
   HIPCHK(hipSetDevice(ctx->device));
   ctx->have_src = false;
+  ctx->unproj_pending = false;
   ctx->state_valid = false;
   int rc = stage_f64(ctx, xyz, (uint32_t)n64, false, s);
   if (rc) return rc;
@@ -3592,6 +3770,7 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   for (int i = 0; i < 16; ++i) if (!std::isfinite(T[i])) return ctx->fail(MA_ERR_INVALID, "non-finite camera pose");
   HIPCHK(hipSetDevice(ctx->device));
   ctx->have_src = false;
+  ctx->unproj_pending = false;
   ctx->state_valid = false;
   const uint32_t npx = (uint32_t)((uint64_t)width * height);
   const size_t esz = dtype == 0 ? 4 : 2;
@@ -3600,16 +3779,21 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   ctx->depth_w = width; ctx->depth_h = height; ctx->depth_dtype = dtype;
   const Pinhole cam = make_pinhole(K, T, depth_scale, ctx->origin);
   HIPCHK(ctx->src.ensure((size_t)npx * sizeof(float4)));
-  uint32_t total = 0;
-  int rc = unproject_frame(ctx, dtype, width, npx, cam, ctx->src.as<float4>(), &total);
-  if (rc) return rc;
-  if (n_valid) *n_valid = total;
-  if (total == 0) return ctx->fail(MA_ERR_EMPTY, "depth image has no valid pixel");
   ctx->n = npx;                       // one slot per pixel; the invalid ones are holes the search skips
-  ctx->n_pts = total;
+  ctx->n_pts = npx;                   // (until the count is in: finish_unproject)
   ctx->src_sorted = false;
-  ctx->src_holes = total != npx;
+  ctx->src_holes = true;
   ctx->src_map_ready = false;
+  // n_valid == NULL: the caller does not want the number now — nothing is waited for, the alignment can be enqueued
+  // right behind the unprojection, and an image without a valid pixel shows as MA_ERR_EMPTY when the count is first
+  // needed (or as MA_ERR_DEGENERATE in ma_icp, which needs no count: the search skips holes)
+  int rc = unproject_frame(ctx, dtype, width, npx, cam, ctx->src.as<float4>(), nullptr, true);
+  if (rc) return rc;
+  if (n_valid) {
+    ctx->have_src = true;             // (finish_unproject takes it back for an empty frame)
+    if ((rc = finish_unproject(ctx))) return rc;
+    *n_valid = ctx->n_pts;
+  }
   ctx->src_rs = 0.f;                  // no bounds of this cloud are known yet: ma_icp finds them when a run is long enough for candidate lists
   ctx->src_box_pending = true;
   ctx->have_src = true;
@@ -3656,7 +3840,8 @@ int ma_map_add_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int h
   ctx->depth_w = width; ctx->depth_h = height; ctx->depth_dtype = dtype;
   const Pinhole cam = make_pinhole(K, T, depth_scale, ctx->map_origin);
   uint32_t total = 0;
-  int rc = unproject_frame(ctx, dtype, width, npx, cam, ctx->map_pts.as<float4>() + ctx->map_n, &total);
+  { const int rc0 = finish_unproject(ctx); if (rc0) return rc0; }      // an earlier frame's count still pending in the pinned block
+  int rc = unproject_frame(ctx, dtype, width, npx, cam, ctx->map_pts.as<float4>() + ctx->map_n, &total, false);
   if (rc) return rc;
   ctx->map_n += npx;                  // one slot per pixel (holes included: the voxel sort drops them)
   ctx->map_valid += total;
@@ -3738,6 +3923,7 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
     if (nvox >= (1u << 28)) return ctx->fail(MA_ERR_TOO_LARGE, "map has 2^28 or more voxels");
     ctx->have_gold = false;
     ctx->have_src = false;
+    ctx->unproj_pending = false;
     ctx->state_valid = false;
     return build_gold_from_raw(ctx, nvox, cell);   // ctx->raw already holds the voxel centroids
   }
@@ -3807,6 +3993,7 @@ int ma_get_source(ma_ctx* ctx, float* xyz_out, uint64_t* n) {
   return guarded(ctx, [&]() -> int {
   if (!ctx || !n) return MA_ERR_INVALID;
   if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set");
+  if (ctx->unproj_pending) { HIPCHK(hipSetDevice(ctx->device)); const int rc0 = finish_unproject(ctx); if (rc0) return rc0; }
   if (!xyz_out) { *n = ctx->n_pts; return MA_OK; }
   if (*n < ctx->n_pts) { *n = ctx->n_pts; return ctx->fail(MA_ERR_INVALID, "output capacity too small"); }
   HIPCHK(hipSetDevice(ctx->device));
@@ -3850,24 +4037,36 @@ int ma_get_source_stored(ma_ctx* ctx, double* xyz_out, uint64_t* n) {
   return guarded(ctx, [&]() -> int {
   if (!ctx || !n) return MA_ERR_INVALID;
   if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set");
+  if (ctx->unproj_pending) { HIPCHK(hipSetDevice(ctx->device)); const int rc0 = finish_unproject(ctx); if (rc0) return rc0; }
   const uint32_t* map = nullptr;
   if (xyz_out) { HIPCHK(hipSetDevice(ctx->device)); int rc = source_map(ctx, &map); if (rc) return rc; }
   return export_stored(ctx, ctx->src.as<float4>(), map, ctx->n, ctx->n_pts, xyz_out, n);
   });
 }
 
-int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16], ma_stats* stats) {
-  return guarded(ctx, [&]() -> int {
-  if (!ctx) return MA_ERR_INVALID;
+// The loop of ma_icp and ma_icp_sharded (rows a4-a7).  One pair on this context; `sharded`: this context holds a shard
+// of the comparison cloud and the 17 sums of every iteration are all-reduced over the communicator's ranks.
+//   per iteration, all on the ctx stream, no host synchronisation:
+//     unsharded   k_nn_accum (search | search + write lists | read lists)  ->  k_reduce_solve
+//     sharded     k_nn_accum (the same three kinds, local shard)  ->  k_reduce19 (+ schedule ranking)
+//                 ->  ncclAllReduce(sum, 17 x f64, in place)  ->  k_solve (redundantly on every rank)
+// Identical sums give identical states on all ranks, so nothing is broadcast; each rank plans its own list launches
+// (its shard has its own box) — which kernel a rank launches changes no bit of its sums, and every rank issues exactly
+// one collective per iteration.
+static int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16], ma_stats* stats,
+                    const bool sharded) {
   int rc;
   if ((rc = check_params(ctx, params))) return rc;
   if ((rc = need_ready(ctx))) return rc;
+  if (sharded && !ctx->comm) return ctx->fail(MA_ERR_STATE, "no communicator (ma_comm_init)");
   if (!T_out) return ctx->fail(MA_ERR_INVALID, "T_out is NULL");
   if (init) for (int i = 0; i < 16; ++i) if (!std::isfinite(init[i])) return ctx->fail(MA_ERR_INVALID, "non-finite init");
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = ensure_levels_for(ctx, params->max_corr_dist))) return rc;
   if ((rc = ensure_loop_buffers(ctx, params->max_iter))) return rc;
-  if (ctx->src_box_pending && lists_enabled() && params->max_iter > 3 * kPlan) {
+  const bool lists_allowed = lists_enabled(ctx) && !(params->flags & MA_FLAG_NO_LISTS);
+  const bool long_run = params->max_iter > 3 * kPlan && params->max_iter <= kMaxSlots;
+  if (ctx->src_box_pending && lists_allowed && long_run) {
     // a source cloud from a depth frame: its box (stored, centred coordinates; holes skipped) for the candidate lists
     float lo[3], hi[3];
     if ((rc = cloud_bounds(ctx, ctx->src.as<float>(), ctx->n, lo, hi, 4, true))) return rc;
@@ -3883,7 +4082,8 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   }
   if ((rc = upload_state(ctx, init))) return rc;
   const float best2 = open_gate2(params->max_corr_dist);
-  const bool timek = (params->flags & MA_FLAG_TIME_KERNELS) != 0;
+  const bool count = (params->flags & MA_FLAG_COUNT_WORK) != 0;
+  const bool timek = (params->flags & MA_FLAG_TIME_KERNELS) != 0 && !sharded;
   if (timek) {
     while ((int)ctx->kev.size() < 2 * params->max_iter + 1) {
       hipEvent_t e;
@@ -3891,16 +4091,25 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
       ctx->kev.push_back(e);
     }
   }
-  // With a convergence test (tol > 0) the loop usually stops long before max_iter, and every
-  // launch after that only finds `done` set (3-6 us each).  The host therefore enqueues in
-  // batches of kBatch iterations and, before batch b, waits for the end of batch b-2 and reads
-  // the pinned word the solve sets when it stops: one batch always stays queued behind the one
-  // being waited for, so the device never idles.  tol = 0 (the benchmark) takes no part in this.
-  // (A run long enough for the candidate lists stops through the planner's slots instead: see below.)
+  RcclApi* api = sharded ? rccl_api() : nullptr;
+  ncclComm_t comm = sharded ? static_cast<ncclComm_t>(ctx->comm) : nullptr;
+  // With a convergence test (tol > 0) the loop usually stops long before max_iter, and every launch after that only
+  // finds `done` set (3-6 us each).  Two ways out:
+  //  * SLOTS (runs of more than 3 kPlan iterations; the same mechanism plans the candidate lists): every solve leaves
+  //    the state it produced in a pinned slot of its own (iteration k -> slot k; posted writes the solve does not wait
+  //    for).  Before batch b (first iteration k = b kPlan) is enqueued the host waits until the last solve of batch b-2
+  //    — iteration j = k - kPlan - 1 — has written its slot; batch b-1 stays queued behind it, so the device never
+  //    idles.  The loop stops enqueueing before batch b exactly when it stopped at an iteration <= j: a rule on the
+  //    STATES, not on when the host happened to look, so every rank of a sharded loop issues the same launches and
+  //    the same collectives (a rank that enqueued one all-reduce more than its peers would hang them all).
+  //  * BATCHES of 8 with an event (short unsharded runs): before batch b, wait for the end of batch b-2 and read the
+  //    pinned word the solve sets when it stops.  A short sharded run simply runs its <= 12 iterations.
+  // tol = 0 without lists (and MA_FLAG_TIME_KERNELS runs) take part in neither.
   constexpr int kBatch = 8;
   const bool early_exit = params->tol > 0.0 && !timek;
-  const bool lists_wanted = ctx->src_rs > 0.f && lists_enabled() && params->max_iter > 3 * kPlan && params->max_iter <= kMaxSlots;
-  const bool batch_exit = early_exit && !lists_wanted;
+  const bool lists_wanted = ctx->src_rs > 0.f && lists_allowed && long_run;
+  const bool slots_used = long_run && (lists_wanted || early_exit);    // the solves mirror their state into the slots, not into host_state_out
+  const bool batch_exit = early_exit && !slots_used && !sharded;
   if (batch_exit) {
     const int need = (params->max_iter + kBatch - 1) / kBatch;
     while ((int)ctx->batch_ev.size() < need) {
@@ -3913,78 +4122,123 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   if (timek) HIPCHK(hipEventRecord(ctx->kev[0], ctx->stream));
   struct ListsScope { ma_ctx* c; ~ListsScope() { c->lists_on = false; } } lists_scope{ctx};
   // Candidate lists (k_nn_accum<.,.,1|2>).  WHICH kernel an iteration launches is decided here, on the host, in
-  // batches of kPlan iterations.  Every solve of such a loop leaves the state it produced in a pinned slot of its own
-  // (iteration k -> slot k; a posted write the solve does not wait for).  Before batch b is enqueued the host waits
-  // (spinning on pinned memory: an event wait wakes up later than the queued batch lasts) until the last solve of
-  // batch b-2 has written its slot — batch b-1 stays queued behind it, so the device never idles — and then knows
-  // every transform up to there: how far each solve moved the cloud, and how far it has moved since the lists were
-  // written (largest displacement over the corners of the source cloud's bounding box: |dR s + dt| is convex in s, so
-  // the box's maximum is at a corner).  The slots belong to fixed iterations, so the plan is the same in every run.
-  // It only has to be good, not right: a list launch proves every correspondence it takes from a list and searches
-  // for the others, and lists on / off give the same transform bit for bit (tools/lists_check.py).
-  // A run with a convergence test (tol > 0) plans the same way, and the wait for batch b-2's slot doubles as its early
-  // exit: the solve that stops the loop sets the pinned `done` word, later solves write no slot, and the host stops
-  // enqueueing launches that would only find `done` set (at most 2 kPlan of them are already queued).
+  // batches of kPlan iterations, from the slots: how far each solve moved the cloud, and how far it has moved since the
+  // lists were written (largest displacement over the corners of the source cloud's bounding box: |dR s + dt| is
+  // convex in s, so the box's maximum is at a corner).  The slots belong to fixed iterations, so the plan is the same in
+  // every run.  It only has to be good, not right: a list launch proves every correspondence it takes from a list and
+  // searches for the others, and lists on / off give the same transform bit for bit (tests/test_gpu_lists.py).
   ctx->lists_on = lists_wanted;
   ctx->list_builds = ctx->list_uses = 0;
   ctx->list_plan.clear();
-  if (ctx->lists_on) for (int i = 0; i < params->max_iter; ++i) { ctx->host_slots[i].seq = -1; ctx->host_slots[i].s.iter = -1; }
-  const bool slots_used = ctx->lists_on;      // the solves of this run mirror their state into the slots, not into host_state_out
+  for (int i = 0; i < 4; ++i) ctx->plan_diag[i] = 0;
+  if (slots_used) {
+    for (int i = 0; i < params->max_iter; ++i) {      // nothing of an earlier run may pass for this run's slot
+      StateSlot& sl = ctx->host_slots[i];
+      sl.seq = -1; sl.s.iter = -1; sl.chk = ~0ull; sl.s.R[0] = NAN;
+    }
+  }
   int launched = 0;
-  const double skin = (double)ctx->grid.c / (double)list_skin_div();
+  const double skin = (double)ctx->grid.c / (double)list_skin_div(ctx);
   ma::ListPlanner planner;       // list_planner.h: the decisions themselves (CPU-tested by tests/test_list_planner.py)
-  planner.configure(skin, params->max_iter, ctx->src_lo, ctx->src_hi);
+  planner.configure(skin, params->max_iter, ctx->src_lo, ctx->src_hi, ctx->cfg_min_uses);
   const DevState T_first = *ctx->host_state_in;     // the transform launch 0 runs with
   auto T_of = [&](int k) -> const DevState& {        // the transform launch k runs with (k <= the last slot read + 1)
     return k == 0 ? T_first : const_cast<const DevState&>(ctx->host_slots[k - 1].s);
   };
+  volatile int* const host_done = ctx->host_done;
   int plan[kPlan] = {0, 0, 0, 0};
-  bool stopped = false;          // tol > 0 with lists: the planner's wait saw the loop stop
-  for (int k = 0; k < params->max_iter && !stopped; ++k) {
+  bool slots_live = slots_used;   // false once a slot failed to arrive (or the loop stopped under MA_FLAG_TIME_KERNELS)
+  bool sync_mode = false;         // after a planner timeout: drain the stream before every batch
+  for (int k = 0; k < params->max_iter; ++k) {
     if (batch_exit && k % kBatch == 0 && k >= 2 * kBatch) {
       HIPCHK(hipEventSynchronize(ctx->batch_ev[k / kBatch - 2]));
-      if (*static_cast<volatile int*>(ctx->host_done)) break;
+      if (*host_done) break;
     }
-    if (ctx->lists_on && k % kPlan == 0) {
+    if (slots_live && k % kPlan == 0) {
       for (int i = 0; i < kPlan; ++i) plan[i] = 0;
       if (k >= 2 * kPlan) {
         const int j = k - kPlan - 1;               // the last iteration of batch b-2
         const StateSlot& sl = ctx->host_slots[j];
+        // Wait for slot j: spin for ~20 us (an event wait wakes up later than the queued batch lasts), then yield the
+        // core between looks — under a CPU quota or with several contexts per core a spinning planner starves the
+        // very threads that feed the other streams; a descheduled planner only idles the device two batches later.
+        ++ctx->plan_diag[0];
         const auto t_wait = std::chrono::steady_clock::now();
-        bool ok = true;
-        while (!slot_ready(&sl, j + 1)) {
-          if (*static_cast<volatile int*>(ctx->host_done)) { ok = false; break; }   // the loop stopped (degenerate)
-          if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(20)) { ok = false; break; }
+        int state = 0;                             // 1: slot j is here; 2: the loop stopped before j; 3: timeout
+        bool yielding = false;
+        for (uint32_t spins = 0;; ++spins) {
+          if (slot_ready(&sl, j + 1)) { state = 1; break; }
+          const int hd = *host_done;               // iterations run when the loop stopped; 0 while it runs
+          if (hd != 0 && hd - 1 < j) { state = 2; break; }      // (stopped AT j: its slot is still to come, with done set)
+          if (yielding || (spins & 63u) == 63u) {
+            const auto waited = std::chrono::steady_clock::now() - t_wait;
+            if (waited > std::chrono::microseconds(ctx->cfg_planner_timeout_us)) { state = 3; break; }
+            if (waited > std::chrono::microseconds(20)) {
+              if (!yielding) { yielding = true; ++ctx->plan_diag[1]; }
+              if (waited > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+              else std::this_thread::yield();
+            }
+          }
+          __builtin_ia32_pause();
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (!ok) {
+        bool stop_here = false;                    // the loop stopped at an iteration <= j
+        if (state == 3) {
+          // no sign of iteration j for 20 s: the posted writes are not arriving (or the device is wedged).  Not
+          // silent: counted in the diagnostics (ma_get_planner_diag); the device is waited for, and the rest of the
+          // run searches and decides its exit with everything enqueued so far complete (sync_mode).
+          ++ctx->plan_diag[2];
           planner.stop();
-          ctx->lists_on = false;                   // a stopped or silent loop: no more planning
-          if (early_exit && *static_cast<volatile int*>(ctx->host_done)) { stopped = true; break; }   // converged (or degenerate): nothing left to run
-        } else {
+          ctx->lists_on = false;
+          slots_live = false;
+          sync_mode = true;
+        } else if (state == 2 || const_cast<const DevState&>(sl.s).done) {
+          stop_here = true;
+        } else if (ctx->lists_on) {
           planner.plan_batch(k, T_of, plan);
+        }
+        if (stop_here) {
+          if (!timek) break;                       // (a timed run keeps its launch count: the rest only find `done` set)
+          planner.stop();
+          ctx->lists_on = false;
+          slots_live = false;
         }
       }
     }
+    if (sync_mode && k % kPlan == 0 && k >= 2 * kPlan) {
+      // after a planner timeout: the same rule as above — stop before this batch iff the loop stopped at an iteration
+      // <= j — decided with the stream drained, so that a sharded rank still stops where its peers stop
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      const int hd = *host_done;
+      if (hd != 0 && hd - 1 <= k - kPlan - 1 && !timek) break;
+    }
     const int kind = ctx->lists_on ? plan[k % kPlan] : 0;
     ctx->list_plan.push_back((uint8_t)kind);
-    if ((rc = launch_nn<0>(ctx, (params->flags & MA_FLAG_COUNT_WORK) != 0, best2, nullptr, nullptr, MA_SCHED != 0, kind))) return rc;
+    if ((rc = launch_nn<0>(ctx, count, best2, nullptr, nullptr, MA_SCHED != 0, kind))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
-    if ((rc = launch_reduce_solve(ctx, params->tol, slots_used ? &ctx->host_slots[k] : nullptr))) return rc;
+    StateSlot* slot = slots_used ? &ctx->host_slots[k] : nullptr;
+    if (sharded) {
+      if ((rc = launch_reduce(ctx, MA_SCHED != 0))) return rc;
+      NCCLCHK(api->AllReduce(ctx->acc19.p, ctx->acc19.p, MA_ACC_LEN, ncclDouble, ncclSum, comm, ctx->stream));
+      if ((rc = launch_solve(ctx, params->tol, true, slot))) return rc;
+    } else {
+      if ((rc = launch_reduce_solve(ctx, params->tol, slot))) return rc;
+    }
     launched = k + 1;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 2], ctx->stream));
     if (batch_exit && (k + 1) % kBatch == 0) HIPCHK(hipEventRecord(ctx->batch_ev[k / kBatch], ctx->stream));
   }
+  ctx->plan_diag[3] = launched;
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (slots_used) {      // the state as the last solve that ran left it (a loop that stopped degenerate wrote no later slot)
+  if (slots_used) {      // the state as the last solve that ran left it (the solve that stops a loop writes the last slot)
     *ctx->host_state_out = *ctx->host_state_in;
     for (int i = launched - 1; i >= 0; --i)
       if (ctx->host_slots[i].s.iter == i + 1) { *ctx->host_state_out = const_cast<const DevState&>(ctx->host_slots[i].s); break; }
   }
   const DevState s = *ctx->host_state_out;     // the last solve's pinned copy of the state: no device-to-host copy
   // launches that ran as iterations (a loop stopped by its convergence test leaves up to 2 kPlan enqueued launches that
-  // only find `done` set; how many depends on when the host saw it, so they are not counted)
+  // only find `done` set)
   for (int i = 0; i < s.iter && i < (int)ctx->list_plan.size(); ++i) {
     ctx->list_builds += ctx->list_plan[(size_t)i] == 1;
     ctx->list_uses += ctx->list_plan[(size_t)i] == 2;
@@ -4008,21 +4262,51 @@ int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T
   fill_stats(s, ms, stats);
   if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "no correspondence inside max_corr_dist, or rank-deficient covariance (fewer than 3 non-collinear pairs)");
   return MA_OK;
+}
+
+int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16], ma_stats* stats) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  return icp_loop(ctx, params, init, T_out, stats, false);
+  });
+}
+
+int ma_list_config(ma_ctx* ctx, int enabled, float skin_div, int min_uses) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (skin_div != 0.f && !(skin_div >= 2.f && skin_div <= 64.f)) return ctx->fail(MA_ERR_INVALID, "skin_div must be 0 (keep) or in [2, 64]");
+  if (min_uses != 0 && (min_uses < 1 || min_uses > 64)) return ctx->fail(MA_ERR_INVALID, "min_uses must be 0 (keep) or in [1, 64]");
+  if (enabled >= 0) ctx->cfg_lists = enabled != 0;
+  if (skin_div != 0.f) ctx->cfg_skin_div = skin_div;
+  if (min_uses != 0) ctx->cfg_min_uses = min_uses;
+  return MA_OK;
+  });
+}
+
+int ma_get_planner_diag(ma_ctx* ctx, int32_t out[4]) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx || !out) return MA_ERR_INVALID;
+  for (int i = 0; i < 4; ++i) out[i] = ctx->plan_diag[i];
+  return MA_OK;
   });
 }
 
 int ma_get_list_stats(ma_ctx* ctx, int32_t out[2]) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx || !out) return MA_ERR_INVALID;
   out[0] = ctx->list_builds;
   out[1] = ctx->list_uses;
   return MA_OK;
+  });
 }
 
 int ma_get_list_plan(ma_ctx* ctx, uint8_t* kinds, int max_iterations) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx || !kinds || max_iterations < 0) return MA_ERR_INVALID;
   const int n = std::min<int>(max_iterations, (int)ctx->list_plan.size());
   for (int i = 0; i < n; ++i) kinds[i] = ctx->list_plan[(size_t)i];
   return n;
+  });
 }
 
 int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {
@@ -4046,6 +4330,18 @@ int ma_get_trace(ma_ctx* ctx, double* out, int max_rows) {
   return rows;
   });
 }
+
+#if MA_DEBUG_FETCH   // debug build only (tools/tie_debug.py): what 0 = prev[] (match of every source slot, position in the gold map's
+// cell order), 1 = src_perm (slot -> caller's index; identity if unsorted), 2 = perm0 (position -> caller's gold index)
+int ma_debug_fetch(ma_ctx* ctx, int what, uint32_t* out, uint64_t count) {
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const void* src = what == 0 ? ctx->prev.p : (what == 1 ? ctx->src_perm.p : ctx->perm0.p);
+  if (!src) return ctx->fail(MA_ERR_STATE, "nothing to fetch");
+  HIPCHK(hipMemcpy(out, src, count * 4, hipMemcpyDeviceToHost));
+  return MA_OK;
+}
+#endif
 
 #if MA_WGTIMES
 int ma_debug_wgphases(ma_ctx* ctx, uint32_t* ph) {
@@ -4138,6 +4434,7 @@ int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_o
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = ensure_levels_for(ctx, max_corr_dist))) return rc;
   if ((rc = upload_state(ctx, T))) return rc;
+  if ((rc = finish_unproject(ctx))) return rc;
   const size_t n = ctx->n, n_out = ctx->n_pts;     // slots searched; points reported (holes of a depth frame are not)
   HIPCHK(ctx->nn_idx.ensure(n * 4));
   HIPCHK(ctx->nn_d2.ensure(n * 4));
@@ -4235,10 +4532,18 @@ int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out) {
   return MA_OK;
 }
 
-int ma_last_device_ms(const ma_ctx* ctx, double* ms) {
+int ma_last_device_ms(const ma_ctx* ctx_c, double* ms) {
+  ma_ctx* ctx = const_cast<ma_ctx*>(ctx_c);
+  return guarded(ctx, [&]() -> int {
   if (!ctx || !ms) return MA_ERR_INVALID;
+  if (ctx->unproj_pending) {          // the launch may still be running: wait for it (and settle its count on the way)
+    HIPCHK(hipSetDevice(ctx->device));
+    const int rc = finish_unproject(ctx);
+    if (rc && rc != MA_ERR_EMPTY) return rc;
+  }
   *ms = ctx->last_op_ms;
   return MA_OK;
+  });
 }
 
 int ma_lift_boxes_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int width, int height, uint32_t n_frames,
@@ -4379,44 +4684,13 @@ int ma_comm_allreduce_f64(ma_ctx* ctx, double* inout, uint64_t count, int op) {
 
 // One pair over the ranks of the communicator: gold map + grids replicated (every rank called
 // ma_set_gold with the same cloud), this rank's shard of the comparison cloud in ma_set_source.
-// Per iteration, all on the ctx stream and with the loop here in C (no host code between the
-// iterations, no host sync):
-//   k_nn_accum (a4+a5, local shard) -> k_reduce19 (+ schedule ranking) ->
-//   ncclAllReduce(sum, 17 x f64, in place) -> k_solve (a6+a7, redundantly on every rank).
-// Identical inputs give identical states on all ranks, so nothing is broadcast.
+// The loop is icp_loop above — the same planner, list launches, pinned slots and early exit as ma_icp, with
+//   k_reduce19 (+ schedule ranking) -> ncclAllReduce(sum, 17 x f64, in place) -> k_solve
+// in the place of k_reduce_solve.
 int ma_icp_sharded(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16], ma_stats* stats) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
-  int rc;
-  if ((rc = check_params(ctx, params))) return rc;
-  if ((rc = need_ready(ctx))) return rc;
-  if (!ctx->comm) return ctx->fail(MA_ERR_STATE, "no communicator (ma_comm_init)");
-  if (!T_out) return ctx->fail(MA_ERR_INVALID, "T_out is NULL");
-  if (init) for (int i = 0; i < 16; ++i) if (!std::isfinite(init[i])) return ctx->fail(MA_ERR_INVALID, "non-finite init");
-  HIPCHK(hipSetDevice(ctx->device));
-  if ((rc = ensure_levels_for(ctx, params->max_corr_dist))) return rc;
-  if ((rc = ensure_loop_buffers(ctx, params->max_iter))) return rc;
-  if ((rc = upload_state(ctx, init))) return rc;
-  const float best2 = open_gate2(params->max_corr_dist);
-  const bool count = (params->flags & MA_FLAG_COUNT_WORK) != 0;
-  RcclApi* api = rccl_api();
-  ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
-  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-  for (int k = 0; k < params->max_iter; ++k) {
-    if ((rc = launch_nn<0>(ctx, count, best2, nullptr, nullptr, MA_SCHED != 0))) return rc;
-    if ((rc = launch_reduce(ctx, MA_SCHED != 0))) return rc;
-    NCCLCHK(api->AllReduce(ctx->acc19.p, ctx->acc19.p, MA_ACC_LEN, ncclDouble, ncclSum, comm, ctx->stream));
-    if ((rc = launch_solve(ctx, params->tol))) return rc;
-  }
-  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-  DevState s;
-  if ((rc = fetch_state(ctx, &s))) return rc;
-  float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-  centred_to_world(s, ctx->origin, T_out);
-  fill_stats(s, ms, stats);
-  if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "no correspondence inside max_corr_dist, or rank-deficient covariance");
-  return MA_OK;
+  return icp_loop(ctx, params, init, T_out, stats, true);
   });
 }
 

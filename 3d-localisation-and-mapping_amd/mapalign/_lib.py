@@ -19,6 +19,7 @@ MA_TRACE_STRIDE = 20
 MA_NO_MATCH = 0xFFFFFFFF
 MA_FLAG_COUNT_WORK = 1
 MA_FLAG_TIME_KERNELS = 2
+MA_FLAG_NO_LISTS = 4
 
 MA_OK = 0
 MA_ERR_INVALID = -1
@@ -115,6 +116,8 @@ ABI = {
     "ma_search_geometry": (C.c_int, [_ctx_p, _u32p, _u32p]),
     "ma_get_list_stats": (C.c_int, [_ctx_p, C.POINTER(C.c_int32)]),
     "ma_get_list_plan": (C.c_int, [_ctx_p, C.POINTER(C.c_uint8), C.c_int]),
+    "ma_list_config": (C.c_int, [_ctx_p, C.c_int, C.c_float, C.c_int]),
+    "ma_get_planner_diag": (C.c_int, [_ctx_p, C.POINTER(C.c_int32)]),
     "ma_cloud_moments": (C.c_int, [_ctx_p, C.c_int, _f64p]),
     "ma_last_device_ms": (C.c_int, [_ctx_p, _f64p]),
     "ma_lift_boxes_batch": (C.c_int, [_ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, _f32p, _f64p,

@@ -165,11 +165,24 @@ class MapAligner:
             raise MapAlignError(st, msg)
         self.device = int(device)
         self.n_gold = 0
-        self.n_source = 0
+        self._n_source = 0
         self._shift = np.zeros(3)
         self._map_shift = None
         self._comm_ranks = 0
         self.gold_token = None          # set by callers that want to know whether "their" gold map is still installed (api.align_many)
+
+    @property
+    def n_source(self):
+        """Points of the comparison cloud (valid pixels of a depth frame; asked of the library if not known yet)."""
+        if self._n_source is None:
+            n = C.c_uint64(0)
+            self._chk(self._lib.ma_get_source(self._ctx, None, C.byref(n)))
+            self._n_source = int(n.value)
+        return self._n_source
+
+    @n_source.setter
+    def n_source(self, v):
+        self._n_source = v
 
     # -- lifetime -------------------------------------------------------------------
     def close(self):
@@ -193,8 +206,10 @@ class MapAligner:
         return _lib.check(self._lib, self._ctx, status)
 
     @staticmethod
-    def _params(max_iter, tol, max_corr_dist, count_work=False, time_kernels=False):
+    def _params(max_iter, tol, max_corr_dist, count_work=False, time_kernels=False, lists=None):
         flags = (_lib.MA_FLAG_COUNT_WORK if count_work else 0) | (_lib.MA_FLAG_TIME_KERNELS if time_kernels else 0)
+        if lists is not None and not lists:
+            flags |= _lib.MA_FLAG_NO_LISTS
         return ma_params(int(max_iter), flags, float(tol), float(max_corr_dist))
 
     def set_stream(self, hip_stream, external=True):
@@ -347,8 +362,10 @@ class MapAligner:
         self.n_gold, self.n_source = vg[1], vc[1]
         return self.grid_info()
 
-    def set_source_from_depth(self, depth, K, T_cam_to_world, depth_scale=1000.0):
-        """Fused depth -> world unprojection into the source buffer (row a8).  Returns #valid pixels."""
+    def set_source_from_depth(self, depth, K, T_cam_to_world, depth_scale=1000.0, count=True):
+        """Fused depth -> world unprojection into the source buffer (row a8).  Returns #valid pixels — or, with
+        ``count=False``, nothing: the call then only enqueues the upload and the kernel (no wait for the device; an
+        ``icp()`` may follow at once) and ``n_source`` is settled when first asked for."""
         d_p, dtype, width, height, _keep = _depth_image(depth, self.device)
         Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
         T = np.array(T_cam_to_world, dtype=np.float64).reshape(4, 4)
@@ -357,9 +374,9 @@ class MapAligner:
         nv = C.c_uint64(0)
         self._chk(self._lib.ma_set_source_from_depth(
             self._ctx, d_p, dtype, width, height,
-            Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T), float(depth_scale), C.byref(nv)))
-        self.n_source = int(nv.value)
-        return self.n_source
+            Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T), float(depth_scale), C.byref(nv) if count else None))
+        self._n_source = int(nv.value) if count else None
+        return self._n_source
 
     # -- map builder (N4): depth frames + poses -> one voxel-deduplicated cloud on the device
     def map_begin(self, voxel, capacity_points):
@@ -520,8 +537,10 @@ class MapAligner:
 
     # -- the loop -------------------------------------------------------------------
     def icp(self, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None, count_work=False, with_trace=False,
-            time_kernels=False):
-        p = self._params(max_iter, tol, max_corr_dist, count_work, time_kernels)
+            time_kernels=False, lists=None):
+        """The whole loop (rows a4-a7).  ``lists=False``: every launch of this run searches (``MA_FLAG_NO_LISTS``);
+        ``None`` / ``True``: the context's setting (:meth:`list_config`).  Same bits either way."""
+        p = self._params(max_iter, tol, max_corr_dist, count_work, time_kernels, lists)
         Tin = _conj_shift(_as_T(init), self._shift, inverse=True)
         Tout = np.empty((4, 4), dtype=np.float64)
         st = ma_stats()
@@ -530,6 +549,18 @@ class MapAligner:
         tr = self.trace(st.iterations) if with_trace else None
         return AlignResult(Tout, int(st.iterations), float(st.rmse), float(st.inliers), bool(st.converged),
                            float(st.gpu_ms), tr)
+
+    def list_config(self, enabled=None, skin_div=None, min_uses=None):
+        """Per-context setting of the candidate lists (``ma_list_config``): on / off, skin = cell edge / ``skin_div``,
+        reads that must be predicted to follow a write.  ``None`` keeps a value.  Speed only, never results."""
+        self._chk(self._lib.ma_list_config(self._ctx, -1 if enabled is None else int(bool(enabled)),
+                                           0.0 if skin_div is None else float(skin_div), 0 if min_uses is None else int(min_uses)))
+
+    def planner_diag(self):
+        """{waits, yielded, timeouts, enqueued} of the host-side planner of the last icp() / icp_sharded()."""
+        out = (C.c_int32 * 4)()
+        self._chk(self._lib.ma_get_planner_diag(self._ctx, out))
+        return {"waits": int(out[0]), "yielded": int(out[1]), "timeouts": int(out[2]), "enqueued": int(out[3])}
 
     def list_stats(self):
         """{builds, uses}: launches of the last icp() that wrote / read the per-query candidate lists."""
@@ -622,10 +653,11 @@ class MapAligner:
     def comm_destroy(self):
         self._chk(self._lib.ma_comm_destroy(self._ctx))
 
-    def icp_sharded(self, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None, count_work=False, with_trace=False):
-        """The whole sharded-source loop in the library: per iteration search -> 19-way sum ->
-        ncclAllReduce(17 doubles) -> solve, all enqueued from C on the context stream."""
-        p = self._params(max_iter, tol, max_corr_dist, count_work)
+    def icp_sharded(self, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None, count_work=False, with_trace=False, lists=None):
+        """The whole sharded-source loop in the library: per iteration search (or list launch) -> 19-way sum ->
+        ncclAllReduce(17 doubles) -> solve, all enqueued from C on the context stream; planner, candidate lists and
+        early exit as in :meth:`icp`."""
+        p = self._params(max_iter, tol, max_corr_dist, count_work, False, lists)
         Tin = _conj_shift(_as_T(init), self._shift, inverse=True)
         Tout = np.empty((4, 4), dtype=np.float64)
         st = ma_stats()

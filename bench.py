@@ -137,14 +137,18 @@ def kernel_source_sha():
 def algorithmic_bytes(trace, n_src, n_blocks, plan=None, kind=0):
     """bytes one k_nn_accum launch must move, from the exact work counters.
 
-    16 B per source point (float4) + 8 B per point for the remembered match (4 B read +
-    4 B write) + 4 B per grid-table word read + 12 B per candidate gold point examined
-    (coordinates only, the remembered match included: SURVEY.md §8d's 12*C) + 12 B per
-    matched point (re-read of the winner) + 19 fp64 partials per workgroup.  A list launch
-    (kind 2: DESIGN.md 5 "List launches") reads 16 B of list and 4 B of radius per point on top
-    (the second list plane, read by the few queries with 5-8 entries, is left out); what a
-    list-writing launch (kind 1) stores is left out too.  Averaged over the launches of ``kind``
-    (``plan`` = engine.list_plan(): what each iteration launched; None: every launch searched)."""
+    Search launches (kinds 0 and 1): 16 B per source point (float4) + 8 B per point for the
+    remembered match (4 B read + 4 B write) + 4 B per grid-table word read + 12 B per candidate
+    gold point examined (coordinates only, the remembered match included: SURVEY.md §8d's 12*C)
+    + 12 B per matched point (re-read of the winner) + 19 fp64 partials per workgroup; what a
+    list-writing launch (kind 1) stores is left out.
+    A list launch (kind 2: DESIGN.md 5 "List launches", round-4 layout) is a stream: 16 B source
+    point + 2 x 16 B inline list entries + 4 B radius = 52 B per point, every byte coalesced; no
+    remembered match is read or written and the winner is not re-read (its coordinates travel
+    with the minimum).  Only lists of more than two entries read 4-byte positions (the kernel's
+    word counter in these launches) and gather 12 B through each: 16 B per counted word.
+    Averaged over the launches of ``kind`` (``plan`` = engine.list_plan(): what each iteration
+    launched; None: every launch searched)."""
     if plan is not None:
         sel = np.asarray(plan[:len(trace)]) == kind
         trace = trace[:len(sel)][sel]
@@ -153,7 +157,7 @@ def algorithmic_bytes(trace, n_src, n_blocks, plan=None, kind=0):
     words, cands, matched = trace[:, 18], trace[:, 19], trace[:, 0]
     per_launch = 24.0 * n_src + 4.0 * words + 12.0 * cands + 12.0 * matched + 19 * 8.0 * n_blocks
     if kind == 2:
-        per_launch = per_launch + 20.0 * n_src
+        per_launch = 52.0 * n_src + 16.0 * words + 19 * 8.0 * n_blocks
     # SURVEY.md 8d's literal formula — 12 N (source xyz) + 4 per table word + 12 C — without the storage actually
     # used (float4 source points), the remembered-match words and the winner re-read: the strictest reading
     strict = 12.0 * n_src + 4.0 * words + 12.0 * cands
@@ -312,19 +316,30 @@ def config_c3(eng, gold):
     dT[:3, 3] = [0.03, -0.02, 0.025]
     Tp = dT @ T                      # the pose the mapper believes: 1 degree / 4.4 cm off
     eng.set_gold(gold)
-    walls, kern, icp_ms = [], [], []
-    for _ in range(4):
+    walls, kern, icp_ms, walls_async, frame_to_T = [], [], [], [], []
+    for _ in range(5):
         t0 = time.perf_counter()
-        n = eng.set_source_from_depth(depth, K, Tp, 1000.0)
+        n = eng.set_source_from_depth(depth, K, Tp, 1000.0)          # with the count of valid pixels: waits for the device
         walls.append((time.perf_counter() - t0) * 1e3)
         kern.append(eng.last_device_ms())
         r = eng.icp(ITERS, 0.0, GATE)
         icp_ms.append(r.gpu_ms)
+        # the caller that wants the transform, not the count: upload + unprojection enqueued, the alignment right behind
+        t0 = time.perf_counter()
+        eng.set_source_from_depth(depth, K, Tp, 1000.0, count=False)
+        walls_async.append((time.perf_counter() - t0) * 1e3)
+        eng.icp(ITERS, 0.0, GATE)
+        frame_to_T.append((time.perf_counter() - t0) * 1e3)
     res_c = eng.icp(ITERS, 0.0, GATE, count_work=True, with_trace=True)
     unproj_bytes = depth.size * depth.itemsize + 16.0 * depth.size   # depth read once + one float4 slot per pixel written (in place)
     k_us = float(np.min(kern[1:])) * 1e3
     return {"workload": "configs[2]: 1280x960 float32 depth frame -> k_unproject -> 50 ICP iterations against the 1M-point gold map",
-            "valid_pixels": int(n), "upload_plus_unproject_ms_host_wall": float(np.median(walls[1:])),
+            "valid_pixels": int(n), "upload_plus_unproject_ms_host_wall": float(np.median(walls_async[1:])),
+            "upload_plus_unproject_ms_host_wall_note": "the call as a pipeline uses it (n_valid not asked for: upload and kernel "
+                                                       "enqueued, nothing waited for); with the count of valid pixels returned: "
+                                                       "upload_plus_unproject_with_count_ms_host_wall",
+            "upload_plus_unproject_with_count_ms_host_wall": float(np.median(walls[1:])),
+            "depth_frame_to_transform_ms_host_wall": float(np.median(frame_to_T[1:])),
             "unproject_device_us": k_us, "icp_ms": float(np.median(icp_ms[1:])),
             "it_per_s": ITERS / (float(np.median(icp_ms[1:])) * 1e-3),
             "rmse_mm": float(r.rmse * 1e3), "inliers": float(r.inliers),
@@ -446,8 +461,10 @@ def config_concurrent(gold, comp, device, R0):
     return out
 
 
-def config_c5(eng, seed=0):
-    """The per-GPU workload of configs[4] (8 pairs x 2M points, one pair per GPU): one 2M pair here."""
+def config_c5(eng, seed=0, cpu_iters=12):
+    """The per-GPU workload of configs[4] (8 pairs x 2M points, one pair per GPU): one 2M pair here — timed over its
+    50 iterations, checked against the ground truth, and compared with the CPU oracle after the SAME `cpu_iters`
+    iterations of this independently resampled pair (a bounded sample: an oracle iteration costs 4-9 s at 2M points)."""
     from mapalign import synthetic as syn
 
     gold, comp, R0, t0 = syn.make_pair(seed, 2_000_000)
@@ -458,10 +475,28 @@ def config_c5(eng, seed=0):
         eng.icp(ITERS, 0.0, GATE)
     ms = [eng.icp(ITERS, 0.0, GATE).gpu_ms for _ in range(5)]
     res = eng.icp(ITERS, 0.0, GATE)
-    return {"workload": "configs[4] per-GPU share: one 2M-point pair, 50 ICP iterations (the 8-GPU run is 8 such pairs, one per GPU)",
-            "icp_ms": float(np.median(ms)), "it_per_s": ITERS / (float(np.median(ms)) * 1e-3), "grid_build_ms": grid["build_ms"],
-            "grid_cell_m": grid["cell"],
-            "final_error_vs_truth": {"R_fro": float(np.linalg.norm(res.R - R0)), "t_m": float(np.linalg.norm(res.t - t0))}}
+    out = {"workload": "configs[4] per-GPU share: one 2M-point pair, 50 ICP iterations (the 8-GPU run is 8 such pairs, one per GPU)",
+           "icp_ms": float(np.median(ms)), "it_per_s": ITERS / (float(np.median(ms)) * 1e-3), "grid_build_ms": grid["build_ms"],
+           "grid_cell_m": grid["cell"], "list_launches": eng.list_stats(),
+           "final_error_vs_truth": {"R_fro": float(np.linalg.norm(res.R - R0)), "t_m": float(np.linalg.norm(res.t - t0))}}
+    if cpu_iters > 0:
+        from oracle import icp_oracle as orc
+        t_0 = time.perf_counter()
+        index = orc.GoldIndex(gold, n_jobs=-1)
+        R, t = np.eye(3), np.zeros(3)
+        inl = []
+        for _ in range(cpu_iters):
+            acc, _, _, R, t, ok = orc.icp_step(index, comp, R, t, GATE)
+            inl.append(float(acc[0]))
+        wall = time.perf_counter() - t_0
+        g = eng.icp(cpu_iters, 0.0, GATE, with_trace=True)
+        out["parity_vs_cpu"] = {"iterations": cpu_iters, "R_fro_vs_cpu": float(np.linalg.norm(g.R - R)),
+                                "t_m_vs_cpu": float(np.linalg.norm(g.t - t)),
+                                "max_inlier_count_difference": float(np.abs(g.trace[:, 0] - np.array(inl)).max()),
+                                "tolerance": {"R_fro": 1e-4, "t_m": 1e-3}, "oracle_wall_s": wall,
+                                "note": f"the first {cpu_iters} iterations of the pair on both sides (a bounded sample of the oracle)"}
+        out["parity_vs_cpu"]["within_tolerance"] = bool(out["parity_vs_cpu"]["R_fro_vs_cpu"] <= 1e-4 and out["parity_vs_cpu"]["t_m_vs_cpu"] <= 1e-3)
+    return out
 
 
 def run_guarded(fn, seconds, device=None):
@@ -682,11 +717,18 @@ def main():
                     tk = float(sel(k).mean()) * 1e-3
                     lists[name] = {"launch_us": tk * 1e6, "bytes_per_launch": bk, "candidates_per_point": ck,
                                    "table_words_per_point": wk, "frac": bk / tk / 1e9 / HBM_PEAK_GBPS}
-            all_b, _, _, all_strict = algorithmic_bytes(res_c.trace, len(comp), n_blocks)
+            # the loop-wide figure: every launch with the bytes of ITS kind, over the time of all launches
             all_t = kt["nn_ms"] / max(kt["nn_launches"], 1) * 1e-3
-            lists["all_launches"] = {"launch_us": all_t * 1e6, "bytes_per_launch_counting_every_launch_as_a_search": all_b,
-                                     "note": "average over all 50 launches of the loop, whichever kernel; list launches avoid "
-                                             "the search's bytes, so an 'achieved GB/s' over them is not a roofline figure"}
+            frac_all = None
+            if same_plan and len(it_ms):
+                tot_b = sum(algorithmic_bytes(res_c.trace, len(comp), n_blocks, plan, k)[0] * int((plan == k).sum()) for k in (0, 1, 2))
+                tot_t = float(it_ms[:len(plan_t), 0].sum()) * 1e-3
+                frac_all = tot_b / tot_t / 1e9 / HBM_PEAK_GBPS
+                lists["all_launches"] = {"launch_us": all_t * 1e6, "bytes_all_launches": tot_b, "time_all_launches_us": tot_t * 1e6,
+                                         "achieved": tot_b / tot_t / 1e9, "frac": frac_all,
+                                         "note": "every launch of the loop with the algorithmic bytes of its own kind / the summed launch "
+                                                 "times; list launches ask for a fifth of a search's bytes (work avoided), so this figure "
+                                                 "falls as more of the loop runs on lists while iterations/s rise"}
             # HBM-side traffic comes from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh);
             # it is only quoted while the kernel sources are the ones it was measured on
             traffic, traffic_note = None, "not measured for this workload"
@@ -704,7 +746,11 @@ def main():
                     traffic = None
             measured_gbps = traffic / t_launch_s / 1e9 if traffic else None
             roof = {"bound": "hbm", "kernel": "k_nn_accum", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                    "frac_scope": (f"the {int((plan == 0).sum())} of {len(plan)} launches that search (k_nn_accum<false,0,0>); "
+                                   f"BENCH_r02 and earlier graded all 50 (every launch searched then) - compare frac_all_launches"),
+                    "frac_all_launches": frac_all,
+                    "traffic": traffic, "traffic_note": traffic_note,
                     # how to read `frac`: algorithmic bytes are mostly served by L1/L2 at this size (working set ~80 MB);
                     # what reaches the fabric is `traffic`, and the kernel is bound by instruction issue / L1 lookups, not HBM
                     "frac_survey_8d": b_strict / t_launch_s / 1e9 / HBM_PEAK_GBPS,
@@ -739,7 +785,7 @@ def main():
                 cpu, parity = cpu_baseline_and_parity(eng, gold, comp, args.cpu_iters)
             if not args.no_extra_configs and args.points == N_POINTS:
                 for name, fn in (("c3", lambda: config_c3(eng, gold)), ("c4", lambda: config_c4(eng, local_rank)),
-                                 ("c5_per_gpu", lambda: config_c5(eng)),
+                                 ("c5_per_gpu", lambda: config_c5(eng, cpu_iters=0 if args.no_cpu_baseline else 12)),
                                  ("concurrent_pairs", lambda: config_concurrent(gold, comp, local_rank, R0))):
                     try:
                         extra[name] = fn()
@@ -782,16 +828,24 @@ def main():
             line["sharded"] = sharded_leg
             line["config"]["library_rccl"] = (sharded_leg or {}).get("library_rccl") or (sharded_leg or {}).get("error") \
                 or (sharded_leg or {}).get("skipped")
-    if not wedged:
+    # The line goes out BEFORE any teardown or collective: a peer that wedged in RCCL would otherwise hold rank 0 in the
+    # barrier below until the process-group timeout, and the line — complete since before the sharded leg — would be lost.
+    if line is not None:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if wedged:                 # a stuck collective cannot be cancelled: leave without the interpreter's shutdown, and NOT with
+        os._exit(3)            # success — the launcher (and self_launch, which still relays the line) must see that a rank hung
+
+    def teardown():
         eng.close()
         if world > 1 or args.rehearse_sharded:
             barrier()
             dist.destroy_process_group()
-    if line is not None:
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
-    if wedged:                 # a stuck collective cannot be cancelled: leave without the interpreter's shutdown
-        os._exit(0)
+        return {}
+
+    _, stuck = run_guarded(teardown, 60.0, local_rank)
+    if stuck:                  # a PEER wedged: this rank's barrier never returns
+        os._exit(3)
 
 
 if __name__ == "__main__":

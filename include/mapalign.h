@@ -30,12 +30,13 @@
 extern "C" {
 #endif
 
-#define MA_VERSION 300 /* 0.3.0: z_rule argument of ma_lift_boxes / ma_lift_boxes_batch */
+#define MA_VERSION 400 /* 0.4.0: ma_list_config, ma_get_planner_diag, MA_FLAG_NO_LISTS; one tie rule (smallest position) on every path */
 #define MA_ACC_LEN 17  /* W, s_p[3], s_q[3], S[9] row-major (S_ab = sum w p'_a q_b), E */
 #define MA_TRACE_STRIDE 20 /* per-iteration trace row: acc[17], rmse, table_words_read, candidates */
 #define MA_NO_MATCH 0xFFFFFFFFu
 #define MA_FLAG_COUNT_WORK 1   /* also count 4-byte grid-table words read / candidates examined (slower kernel) */
 #define MA_FLAG_TIME_KERNELS 2 /* bracket every kernel launch of ma_icp with hipEvents (perturbs the loop) */
+#define MA_FLAG_NO_LISTS 4     /* this run: every launch of the loop searches (no candidate lists); results are the same bits */
 
 typedef struct ma_ctx ma_ctx;
 
@@ -157,16 +158,31 @@ int ma_mem_info_get(const ma_ctx* ctx, ma_mem_info* out);
  * (padded to whole XCD segments and scheduling groups) and threads (= points) per workgroup.  What a roofline
  * computation needs for the per-workgroup terms (19 fp64 partials each). */
 int ma_search_geometry(const ma_ctx* ctx, uint32_t* n_workgroups, uint32_t* block_threads);
-/* Candidate lists of the last ma_icp run (rows a4-a7): out = {launches that searched and wrote the
- * per-query candidate lists, launches that read them instead of searching}.  Both 0 when the loop never came to rest
- * enough for lists to pay, for a source cloud from a depth frame, or with MAPALIGN_LISTS=0 in the environment.
- * Results do not depend on them: a list launch proves per query that the nearest neighbour is on its list
- * (triangle inequality over the motion since the list was written) and searches where it cannot. */
+/* Candidate lists of the last ma_icp / ma_icp_sharded run (rows a4-a7): out = {launches that searched and
+ * wrote the per-query candidate lists, launches that read them instead of searching}.  Both 0 when the loop never came
+ * to rest enough for lists to pay, in a run of <= 12 iterations, with MA_FLAG_NO_LISTS, or on a context whose lists are
+ * switched off (ma_list_config).  Results do not depend on them: a list launch proves per query that the nearest
+ * neighbour is on its list (triangle inequality over the motion since the list was written) and searches where it
+ * cannot, and every path resolves equal fp32 distances the same way (the smaller position in the gold map's cell order),
+ * so lists on and off give the same sums in every iteration and the same transform, bit for bit. */
 int ma_get_list_stats(ma_ctx* ctx, int32_t out[2]);
 /* What each iteration of the last ma_icp run launched: 0 a search, 1 a search that also wrote the candidate lists,
  * 2 a list launch.  Returns the number of entries written (<= max_iterations; launches enqueued, which for a loop that
  * stopped early may exceed the iterations performed) or a negative status. */
 int ma_get_list_plan(ma_ctx* ctx, uint8_t* kinds, int max_iterations);
+/* Per-context configuration of the candidate lists.  enabled: 1 / 0, or -1 to keep; skin_div: the lists' skin is the
+ * grid's cell edge / skin_div (2..64), 0 to keep; min_uses: a launch writes lists only if at least this many reads are
+ * predicted to follow (1..64), 0 to keep.  A context is created with lists enabled, cell / 7 and 5 — or with what
+ * MAPALIGN_LISTS (0 = off), MAPALIGN_SKIN_DIV and MAPALIGN_MIN_USES say in the environment AT ma_create; nothing is read
+ * from the environment afterwards.  The settings change how fast the loop runs, never what it returns. */
+int ma_list_config(ma_ctx* ctx, int enabled, float skin_div, int min_uses);
+/* Diagnostics of the host-side planner of the last ma_icp / ma_icp_sharded run (the thread that decides, every 4
+ * iterations, which kernel the next ones launch, from the states the solves leave in pinned host memory):
+ * out = {waits for a state, waits that outlasted the ~20 us spin and went on yielding the core, waits that TIMED OUT,
+ * iterations enqueued}.  A timeout (20 s without the state of an iteration enqueued two batches earlier) is not an
+ * error — the run goes on searching, drains the stream before every further batch and returns the same bits — but it
+ * means posted writes to pinned memory are not arriving, and it is reported here rather than passed over. */
+int ma_get_planner_diag(ma_ctx* ctx, int32_t out[4]);
 /* Row N1 (coarse pre-alignment): number of valid points, centroid (frame of the coordinates handed in, minus the
  * large-coordinate shift if one is in force) and 3x3 sample covariance (row-major) of a cloud AS STORED on the
  * device: which = 0 the gold map, 1 the source cloud (holes of a depth frame are skipped).  out = {n, c[3], C[9]}.
@@ -184,7 +200,13 @@ int ma_cloud_moments(ma_ctx* ctx, int which, double out[13]);
  * valid pixels, and everything that hands points or per-point results back (ma_get_source,
  * ma_get_source_stored, ma_nn) reports exactly those, in row-major pixel order.  (Inside, every
  * pixel keeps its slot and an invalid one is a hole the search skips; the compaction happens
- * only where points are handed back.) */
+ * only where points are handed back.)
+ * n_valid == NULL: the call only ENQUEUES the upload and the kernel and returns without waiting for
+ * the device — an alignment can follow on the same stream at once (ma_icp needs no count).  The
+ * count is then settled by the first call that needs it (ma_get_source(ctx, NULL, &n) returns it),
+ * and an image without a single valid pixel is reported there (MA_ERR_EMPTY) or by ma_icp
+ * (MA_ERR_DEGENERATE: nothing to match).  The depth buffer is borrowed for the duration of the call
+ * in both cases (it is copied before the call returns). */
 int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height,
                              const float K[4], const double T_cam_to_world[16],
                              float depth_scale, uint64_t* n_valid);
@@ -264,7 +286,8 @@ int ma_get_source_stored(ma_ctx* ctx, double* xyz_out, uint64_t* n);
  * of searching once the cloud has come to rest (DESIGN.md 5 "List launches"; ma_get_list_stats / ma_get_list_plan
  * report them).  Every correspondence taken from a list is proved, and the result is the searching loop's bit for bit
  * — with tol > 0 as well: such a run stops at the searching loop's iteration, and at most 8 launches that only find
- * the loop stopped are enqueued past it.  MAPALIGN_LISTS=0 in the environment makes every launch search. */
+ * the loop stopped are enqueued past it.  MA_FLAG_NO_LISTS makes every launch of one run search; ma_list_config sets
+ * the context's default. */
 int ma_icp(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16],
            ma_stats* stats);
 /* Per-iteration trace of the last ma_icp / stepping sequence: row k =
@@ -311,7 +334,10 @@ int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev);
  * north_star "RCCL-over-xGMI all-reduce only of the per-pair accumulators"): librccl is
  * loaded with dlopen on first use and, per iteration, the library enqueues on the ctx stream
  *   search+accumulate (local shard) -> 19-way sum -> ncclAllReduce(sum, 17 doubles) -> solve
- * with the loop in C and no host synchronisation.  Bootstrap: rank 0 obtains an id with
+ * with the loop in C and no host synchronisation — the loop of ma_icp: the same candidate lists (each rank plans
+ * its own shard's; which kernel a rank launches changes no bit of its sums), the same early exit with tol > 0 (decided
+ * from the iteration at which the loop stopped, so that every rank issues the same number of collectives), the final
+ * state read from pinned host memory.  Bootstrap: rank 0 obtains an id with
  * ma_comm_unique_id and hands the MA_COMM_ID_BYTES bytes to the other ranks by any channel
  * (torch.distributed broadcast, a file, MPI ...); every rank then calls ma_comm_init
  * (collective).  A 1-rank communicator is valid and makes ma_icp_sharded equal ma_icp bit

@@ -17,6 +17,25 @@ R_TOL_FRO = 1e-4
 T_TOL_M = 1e-3
 
 
+# Wall-clock budget of the -m gpu suite.  The CPU oracle dominates it (1.2-4 s per 1M-point iteration on the GPU box's
+# host cores, depending on the box's load), so the tests that run the oracle for many iterations ask how much time is
+# left instead of guessing from a fixed per-iteration threshold (round 3: seeds 1-2 of the headline test dropped to 20
+# iterations on a box where the suite then finished with 495 s to spare).
+SUITE_BUDGET_S = float(os.environ.get("MAPALIGN_SUITE_BUDGET_S", "840"))
+_suite_t0 = [None]
+
+
+def suite_seconds_left():
+    import time
+    if _suite_t0[0] is None:
+        _suite_t0[0] = time.perf_counter()
+    return SUITE_BUDGET_S - (time.perf_counter() - _suite_t0[0])
+
+
+def pytest_sessionstart(session):
+    suite_seconds_left()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -31,6 +31,13 @@ def test_self_launch_relays_one_line_and_the_childs_return_code(capfd):
     assert bench.self_launch([], 2, command=failing) == 7
     silent = [sys.executable, "-c", "pass"]
     assert bench.self_launch([], 2, command=silent) == 1               # rc 0 without a result line is a failure
+    # a rank that wedged in a collective leaves with a non-zero code AFTER rank 0 wrote the line: the line is
+    # still relayed, and the failure is still reported
+    capfd.readouterr()
+    wedged = [sys.executable, "-c", "import os, sys; print('{\"metric\": \"m\", \"n_gpus\": 2}'); sys.stdout.flush(); os._exit(3)"]
+    assert bench.self_launch([], 2, command=wedged) == 3
+    out, _ = capfd.readouterr()
+    assert out.count("\n") == 1 and json.loads(out)["metric"] == "m"
 
 
 def test_plain_shell_run_with_gpus_2_goes_through_the_launcher_before_any_gpu_use():

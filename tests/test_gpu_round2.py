@@ -25,13 +25,21 @@ NO_MATCH = 0xFFFFFFFF
 
 
 # ----------------------------------------------------------------------------- headline parity
+# what the oracle-heavy tests that run AFTER the headline test need (tests/test_gpu_round4.py: two 2M-point pairs of >= 12
+# oracle iterations each, the sharding and planner tests), seconds
+RESERVE_AFTER_HEADLINE_S = 300.0
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_config2_1m_50_iterations_vs_oracle(engine, seed):
     """north_star: "(R,t) must match the reference CPU path to <= 1e-4 Frobenius on R and
     <= 1 mm on t for identical inputs" — the 1M-point pair, all 50 iterations, tol = 0, gate
     0.10 m.  The oracle runs its 50 KD-tree iterations on the host cores
-    (1.2-3 s each on the 256-core GPU boxes, depending on their load); on a host that needs more
-    than 2 s per iteration, seeds 1 and 2 stop after 20 iterations (still compared at equal iteration count) so the suite stays in budget."""
+    (1.2-4 s each on the 256-core GPU boxes, depending on their load).  Seed 0 always runs all 50.  Seeds 1 and 2 run
+    all 50 whenever the suite's wall-clock budget (conftest.suite_seconds_left) has room for them, and never fewer
+    than 40 — the list launches of this pair begin at iteration ~20-28, so every seed compares them with the oracle
+    (still at equal iteration count)."""
+    from conftest import suite_seconds_left
     gold, comp, R0, t0 = syn.make_pair(seed, 1_000_000)
     engine.set_gold(gold)
     engine.set_source(comp)
@@ -47,8 +55,11 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
         inliers.append(acc[0])
         rmse.append(np.sqrt(acc[16] / acc[0]))
         k += 1
-        if seed > 0 and k == 5 and (time.perf_counter() - t_start) / 5 > 2.0:
-            iters = 20
+        if seed > 0 and k == 5:
+            per_it = (time.perf_counter() - t_start) / 5
+            # what is left for this seed: the budget minus the reserve of the later tests, minus (for seed 1) seed 2's 40
+            room = suite_seconds_left() - RESERVE_AFTER_HEADLINE_S - (40 * per_it if seed == 1 else 0.0)
+            iters = int(min(50, max(40, k + room / per_it)))
     res = engine.icp(iters, 0.0, 0.10, with_trace=True)
     assert res.iterations == iters
     eR, et = orc.rt_error(res.R, res.t, R, t)
@@ -58,7 +69,7 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
     print(msg)
     if iters != 50:
         import warnings
-        warnings.warn(msg + " — SHORTENED from 50: this host is too slow for the full oracle run of seeds 1-2")
+        warnings.warn(msg + " — SHORTENED from 50: the suite's wall-clock budget has no room for the full oracle run of this seed")
     assert eR <= R_TOL_FRO and et <= T_TOL_M, (eR, et)
     # measured: 1e-7 / 1e-6 m; keep a tighter regression bar than the contract
     assert eR <= 1e-5 and et <= 1e-4, (eR, et)

@@ -1,0 +1,442 @@
+"""GPU parity tests added in round 4 (run with -m gpu on an MI355X), all through the C ABI:
+
+* BASELINE configs[4]'s per-GPU workload — an independently RESAMPLED 2M-point pair — against the CPU oracle at equal
+  iteration count (as many iterations as the suite's wall-clock budget allows, never fewer than 12);
+* the sharded-source partition at 2, 4 and 8 shards of the 1M-point pair on one GPU: the shards' 17 sums added in rank
+  order (what the RCCL all-reduce does across GPUs) against the single-context loop (world sizes 1, 2, 4, 8);
+* ONE tie rule on every path: 200 random cases with lists on and off, bit for bit (the fuzz that used to live in tools/),
+  and clouds MADE of ties (every gold point several times, lattice clouds) through the searching loop, the list launches
+  and the per-lane multi-level search;
+* the sharded loop inside the library with candidate lists and the planner's early exit (1-rank communicator);
+* the host-side planner under contention (four contexts on two host cores) and when its wait times out (fault injection).
+"""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import mapalign
+from mapalign import synthetic as syn
+from oracle import icp_oracle as orc
+
+from conftest import R_TOL_FRO, T_TOL_M, suite_seconds_left
+
+pytestmark = pytest.mark.gpu
+
+NO_MATCH = 0xFFFFFFFF
+
+
+# ----------------------------------------------------------------------------- configs[4]: the resampled 2M pair
+@pytest.mark.parametrize("seed", [0, 1])
+def test_config5_2m_resampled_pair_vs_oracle(engine, seed):
+    """BASELINE configs[4]: "8 scan-pairs x 2M points each, one pair per GPU" — seeds 0-7, comparison cloud an independent
+    resample of the gold surfaces.  One GPU's share of that, through ma_icp, against the oracle at EQUAL
+    iteration count with per-iteration inlier counts and squared-distance sums, as for the 1M headline pair.  An oracle
+    iteration costs 4-9 s at this size, so the iteration count follows the suite's wall-clock budget: at least 12 (the
+    expensive, far-apart iterations, where most of the kernel's code paths run), more when there is room."""
+    n = 2_000_000
+    gold, comp, R0, t0 = syn.make_pair(seed, n)
+    engine.set_pair(gold, comp)
+    index = orc.GoldIndex(gold, n_jobs=-1)
+    R, t = np.eye(3), np.zeros(3)
+    inliers, E = [], []
+    # this seed's share of what is left (seed 0 leaves half to seed 1; 60 s stay for the tests after these two)
+    share = max(0.0, suite_seconds_left() - 60.0) / (2 - seed)
+    t_start = time.perf_counter()
+    k, iters = 0, 30
+    while k < iters:
+        acc, _, _, R, t, ok = orc.icp_step(index, comp, R, t, 0.10)
+        assert ok
+        inliers.append(acc[0])
+        E.append(acc[16])
+        k += 1
+        if k == 3:
+            per_it = (time.perf_counter() - t_start) / 3
+            iters = int(min(30, max(12, share / per_it)))
+    res = engine.icp(iters, 0.0, 0.10, with_trace=True)
+    assert res.iterations == iters
+    eR, et = orc.rt_error(res.R, res.t, R, t)
+    print(f"config5 seed {seed}: 2M-point resampled pair compared after {iters} iterations "
+          f"({(time.perf_counter() - t_start) / iters:.2f} s per oracle iteration): |dR|_F = {eR:.2e}, |dt| = {et:.2e} m")
+    assert eR <= R_TOL_FRO and et <= T_TOL_M, (eR, et)
+    assert eR <= 1e-5 and et <= 1e-4, (eR, et)                    # measured: 1e-7 / 1e-6 m
+    gpu_inl = res.trace[:, 0]
+    d_inl = np.abs(gpu_inl - np.array(inliers))
+    assert d_inl.max() <= 40, d_inl.max()                         # points within the fp32 storage error of the gate (2e-5 of the cloud)
+    E_gpu, E_cpu = res.trace[:, 16], np.array(E)
+    assert (np.abs(E_gpu - E_cpu) <= (d_inl + 1.0) * 0.10 ** 2 + 2e-4 * E_cpu).all(), np.abs(E_gpu - E_cpu).max()
+    # candidate lists change nothing at this size either
+    off = engine.icp(iters, 0.0, 0.10, with_trace=True, lists=False)
+    assert np.array_equal(off.T, res.T) and np.array_equal(off.trace[:, :18], res.trace[:, :18])
+
+
+# ----------------------------------------------------------------------------- world sizes 2, 4, 8 on one GPU
+@pytest.mark.parametrize("shards", [2, 4, 8])
+def test_split_stepping_n_shards_of_the_1m_pair_equal_one_context(lib_built, shards):
+    """"world_size in {1,2,4,8} equality of accumulators vs 1-GPU".  The 1M-point benchmark pair, the
+    comparison cloud block-partitioned over `shards` contexts on this one GPU (the partition of mapalign.dist), every
+    context stepping its shard, the 17 sums ADDED IN RANK ORDER and handed back to every context's solve — the data path
+    of ma_icp_sharded with the all-reduce spelled out.  Every iteration's inlier count must be the single context's
+    exactly (the correspondences do not depend on the partition), the sums agree to rounding (another summation order),
+    every shard ends on the same bits as every other, and the transform is the single context's to 1e-11."""
+    import torch
+    from mapalign import dist as mdist
+
+    iters = 30
+    gold, comp, R0, t0 = syn.make_pair(0, 1_000_000)
+    with mapalign.MapAligner(0) as full:
+        full.set_pair(gold, comp)
+        ref = full.icp(iters, 0.0, 0.10, with_trace=True, lists=False)
+    engs, accs = [], []
+    for r in range(shards):
+        lo, hi = mdist.shard_bounds(len(comp), shards, r)
+        a = mapalign.MapAligner(0)
+        a.set_gold(gold)
+        a.set_source(comp[lo:hi])
+        he = mdist.HipShardEngine(a, 0.10, 0.0)
+        he.bind_current_stream()
+        he.state_set(None)
+        engs.append(he)
+        accs.append(he.new_acc())
+    sums = []
+    for _ in range(iters):
+        for he, acc in zip(engs, accs):
+            he.accumulate_into(acc)
+        total = accs[0].clone()
+        for acc in accs[1:]:
+            total += acc                                         # rank order
+        sums.append(total.cpu().numpy().copy())
+        for he, acc in zip(engs, accs):
+            acc.copy_(total)
+            he.solve_from(acc)
+    states = [he.state_get() for he in engs]
+    for he in engs:
+        he.aligner.use_own_stream()
+        he.aligner.close()
+    for T, info in states[1:]:
+        assert np.array_equal(T, states[0][0]) and info == states[0][1]
+    T, info = states[0]
+    assert info["iterations"] == iters and info["inliers"] == ref.inliers
+    assert np.allclose(T, ref.T, atol=1e-11, rtol=0)
+    eR, et = orc.rt_error(T[:3, :3], T[:3, 3], ref.R, ref.t)
+    assert eR <= 1e-11 and et <= 1e-11, (eR, et)
+    # the sums are in the contexts' centred frame; W and E do not depend on the frame
+    sums = np.array(sums)
+    assert np.array_equal(sums[:, 0], ref.trace[:, 0])            # inlier counts, every iteration, exactly
+    assert np.allclose(sums[:, 16], ref.trace[:, 16], rtol=1e-11, atol=0)
+
+
+# ----------------------------------------------------------------------------- one tie rule: the promoted fuzz
+def _fuzz_case(rng, case):
+    m, n = int(rng.integers(300, 120000)), int(rng.integers(300, 120000))
+    kind = case % 4
+    if kind == 0:
+        gold = rng.uniform(-1, 1, (m, 3)) * rng.uniform(0.3, 5.0, 3)
+    elif kind == 1:
+        gold = rng.uniform(-3, 3, (m, 3))
+        gold[:, rng.integers(0, 3)] *= 0.01
+    elif kind == 2:
+        c = rng.uniform(-2, 2, (max(m // 300, 2), 3))
+        gold = c[rng.integers(0, len(c), m)] + rng.normal(0, 0.05, (m, 3))
+    else:
+        gold = syn.sample_rectangles(syn.carriage_rectangles(rng), m, rng)
+    gold = gold.astype(np.float32)
+    pick = rng.integers(0, m, n)
+    comp_in_gold = gold[pick].astype(np.float64) + rng.normal(0, 0.003, (n, 3))
+    if case % 5 == 0:       # strays and far points: queries without a gold point inside the gate
+        k = n // 10
+        comp_in_gold[:k] += rng.normal(0, 0.08, (k, 3))
+        comp_in_gold[k:k + k // 2] += 3.0
+    R0 = syn.rotation_about_axis(rng.normal(size=3), rng.uniform(0, 0.01))
+    t0 = rng.normal(0, 0.006, 3)
+    comp = ((comp_in_gold - t0) @ R0).astype(np.float32)
+    gate = [0.02, 0.05, 0.1, 0.5, np.inf][int(rng.integers(0, 5))]
+    w = rng.uniform(0.0, 3.0, n).astype(np.float32) if case % 3 == 0 else None
+    cell = [0.0, 0.0, 0.0, 0.02, 0.2][int(rng.integers(0, 5))]
+    iters = int(rng.integers(40, 65))
+    return gold, comp, w, gate, cell, iters
+
+
+def test_lists_on_and_off_bitwise_over_200_random_cases(engine):
+    """Random shapes (boxes, thin slabs, clumps, the carriage shell), sizes, gates — down to ones that leave most points
+    unmatched, up to NONE, where far strays sit 3 m off the map and one fp32 ulp of d^2 is 1e-6 m^2: ties are common
+    there — weights, cell edges and starts; 40-64 iterations with lists on and with every launch searching must give
+    the same transform and the same 17 sums in EVERY iteration, bit for bit, in all 200 cases.  (Round 3: 197 of 200,
+    the three others one tie each; the tie rule is now the same on every path.)"""
+    rng = np.random.default_rng(31)
+    bad, used, done, degenerate, uses_total, ungated_used = [], 0, 0, 0, 0, 0
+    for case in range(200):
+        gold, comp, w, gate, cell, iters = _fuzz_case(rng, case)
+        try:
+            engine.set_gold(gold, cell)
+            engine.set_source(comp, w)
+            on = engine.icp(iters, 0.0, gate, with_trace=True)
+            st = engine.list_stats()
+            off = engine.icp(iters, 0.0, gate, with_trace=True, lists=False)
+        except mapalign.MapAlignError:
+            degenerate += 1
+            continue
+        done += 1
+        used += st["uses"] > 0
+        uses_total += st["uses"]
+        ungated_used += (st["uses"] > 0) and not np.isfinite(gate)
+        if not (np.array_equal(on.T, off.T) and np.array_equal(on.trace[:, :18], off.trace[:, :18])):
+            first = int(np.argmax((on.trace[:, :18] != off.trace[:, :18]).any(1)))
+            bad.append((case, gate, cell, iters, st, first, float(np.abs(on.T - off.T).max())))
+    print(f"{done} cases compared ({degenerate} degenerate), lists used in {used} of them ({uses_total} list launches, "
+          f"{ungated_used} ungated cases among them), {len(bad)} differ")
+    assert done >= 180 and used >= 60 and ungated_used >= 5
+    assert not bad, bad
+
+
+# ----------------------------------------------------------------------------- clouds made of ties
+@pytest.mark.parametrize("gate", [0.10, np.inf])
+def test_clouds_made_of_ties_one_rule_on_every_path(engine, gate):
+    """Every gold point FOUR times (exact duplicates scattered over the array), so that every query has four nearest
+    neighbours at the same fp32 distance, plus a block of queries far off the map that only the per-lane multi-level
+    search serves (ungated) — the searching loop, the list launches and ma_nn must all name the duplicate with the
+    smallest index, in every iteration: lists on and off on the same bits, and the indices ma_nn reports are the
+    first-minimum indices of a brute-force search."""
+    rng = np.random.default_rng(77)
+    base = syn.sample_rectangles(syn.carriage_rectangles(rng), 30_000, rng).astype(np.float32)
+    order = np.concatenate([rng.permutation(len(base)) for _ in range(4)])
+    gold = base[order]
+    first = np.full(len(base), len(gold), dtype=np.int64)
+    np.minimum.at(first, order, np.arange(len(gold)))
+    pick = rng.integers(0, len(base), 40_000)
+    comp_in_gold = base[pick].astype(np.float64) + rng.normal(0, 0.002, (len(pick), 3))
+    comp_in_gold[:2000] += np.array([0.0, 0.0, 2.5])                # far off the map: matched only without a gate
+    R0 = syn.rotation_about_axis([0.2, -0.4, 0.9], np.deg2rad(0.15))
+    t0 = np.array([0.004, -0.003, 0.002])
+    comp = ((comp_in_gold - t0) @ R0).astype(np.float32)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    on = engine.icp(56, 0.0, gate, with_trace=True)
+    st = engine.list_stats()
+    off = engine.icp(56, 0.0, gate, with_trace=True, lists=False)
+    assert st["uses"] >= 8, st
+    assert np.array_equal(on.T, off.T) and np.array_equal(on.trace[:, :18], off.trace[:, :18])
+    # the index rule itself, at the final transform: every reported neighbour is the FIRST of its four duplicates
+    idx, d2 = engine.nn(on.T, gate)
+    m = idx != NO_MATCH
+    assert m.sum() >= len(comp) - 2000
+    assert (first[order[idx[m].astype(np.int64)]] == idx[m].astype(np.int64)).all()
+    # ... and the distances are the brute-force minima on the stored coordinates (sample)
+    sg, ss = engine.get_gold(), engine.get_source_stored()
+    sample = rng.choice(np.nonzero(m)[0], 300, replace=False)
+    p_t = ss[sample] @ on.T[:3, :3].T + on.T[:3, 3]
+    oidx, od2 = orc.nn_bruteforce(sg, p_t)
+    assert np.allclose(d2[sample], od2, rtol=2e-3, atol=1e-9)          # fp32 differences of ~10 m coordinates: 1e-6 m each
+    assert (first[order[oidx]] == idx[sample].astype(np.int64)).all()
+
+
+def test_lattice_cloud_ties_between_distinct_points(engine):
+    """Ties between DIFFERENT gold points: a regular lattice and queries on its mid-planes (coordinates exact in fp32),
+    so that two or four lattice points are nearest at bitwise the same distance and sit in different rows / cells of
+    the grid.  ma_nn must report one of the tied points for every query (brute force on the stored coordinates, fp32
+    distances), and the loop — where such a tie is met by the cooperative search in one launch, by a list launch in the
+    next and by the per-lane search after a failed certificate — gives the same bits with lists on and off, on two
+    grids with different cell edges (two different position orders, each consistent across its own paths)."""
+    g = np.arange(0, 24, dtype=np.float32) * np.float32(0.0625)
+    gx, gy, gz = np.meshgrid(g, g[:12], g[:6], indexing="ij")
+    gold = np.stack([gx.ravel(), gy.ravel(), gz.ravel()], 1).astype(np.float32)
+    rng = np.random.default_rng(3)
+    gold = gold[rng.permutation(len(gold))]
+    q = gold[rng.integers(0, len(gold), 6000)].copy()
+    q[:, 0] += np.float32(0.03125)                                   # midway between two lattice points along x
+    q[3000:, 1] += np.float32(0.03125)                               # ... and along y: midway between four
+    q = q[(q[:, 0] < g[-1]) & (q[:, 1] < g[11])]
+    engine.set_gold(gold, 0.05)
+    engine.set_source(q)
+    idx, d2 = engine.nn(None, np.inf)
+    sg, ss = engine.get_gold().astype(np.float32), engine.get_source_stored().astype(np.float32)
+    ties_seen = 0
+    for i in rng.choice(len(q), 400, replace=False):
+        df = sg - ss[i]
+        d = (df[:, 2] * df[:, 2] + (df[:, 1] * df[:, 1] + df[:, 0] * df[:, 0])).astype(np.float32)
+        cand = np.nonzero(d == d.min())[0]
+        ties_seen += len(cand) > 1
+        assert idx[i] in cand, (i, idx[i], cand)
+    assert ties_seen >= 300
+    moved = (q + np.float32(0.001)).astype(np.float32)
+    engine.set_source(moved)
+    on = engine.icp(48, 0.0, 0.10, with_trace=True)
+    st = engine.list_stats()
+    off = engine.icp(48, 0.0, 0.10, with_trace=True, lists=False)
+    assert st["uses"] >= 4, st
+    assert np.array_equal(on.T, off.T) and np.array_equal(on.trace[:, :18], off.trace[:, :18])
+    with mapalign.MapAligner(0) as other:
+        other.set_gold(gold, 0.11)
+        other.set_source(moved)
+        a = other.icp(48, 0.0, 0.10, with_trace=True)
+        b = other.icp(48, 0.0, 0.10, with_trace=True, lists=False)
+        assert np.array_equal(a.T, b.T) and np.array_equal(a.trace[:, :18], b.trace[:, :18])
+
+
+# ----------------------------------------------------------------------------- the sharded loop in the library, level with ma_icp
+def test_icp_sharded_plans_lists_and_stops_early_like_icp(lib_built):
+    """ma_icp_sharded runs the loop of ma_icp (round 4): the same planner and list launches, the planner's slots as its
+    early exit, the final state from pinned memory.  With a 1-rank communicator (the collective still runs every
+    iteration) it must give ma_icp's bits with lists in use, stop at ma_icp's iteration with a convergence test, and
+    enqueue the same launches whatever the host's timing (the stop is decided from the iteration at which the loop
+    stopped — what keeps the collective counts of several ranks equal)."""
+    gold, comp, _, _ = syn.make_pair(11, 120_000, 100_000, angle_deg=0.4, t0=(0.02, -0.015, 0.01))
+    with mapalign.MapAligner(0) as eng:
+        eng.set_pair(gold, comp)
+        ref = eng.icp(60, 0.0, 0.10, with_trace=True)
+        s_ref = eng.list_stats()
+        assert s_ref["uses"] >= 10
+        eng.comm_init(eng.comm_unique_id(), 1, 0)
+        res = eng.icp_sharded(60, 0.0, 0.10, with_trace=True)
+        assert eng.list_stats() == s_ref                              # the same plan: same slots, same box
+        assert np.array_equal(res.T, ref.T) and np.array_equal(res.trace[:, :18], ref.trace[:, :18])
+        off = eng.icp_sharded(60, 0.0, 0.10, with_trace=True, lists=False)
+        assert eng.list_stats() == {"builds": 0, "uses": 0}
+        assert np.array_equal(off.T, ref.T) and np.array_equal(off.trace[:, :18], ref.trace[:, :18])
+        for tol in (1e-4, 1e-6, 1e-8):
+            a = eng.icp(90, tol, 0.10)
+            plan_a = len(eng.list_plan())
+            b = eng.icp_sharded(90, tol, 0.10)
+            plan_b = len(eng.list_plan())
+            assert a.iterations == b.iterations and a.converged == b.converged and np.array_equal(a.T, b.T), tol
+            k = a.iterations
+            # launches enqueued: a function of the stopping iteration alone — the whole batches up to the first one
+            # whose slot wait (iteration 4 b - 5) sees the stop
+            if a.converged:
+                expect = min(90, 4 * ((k - 1 + 5 + 3) // 4))
+                assert plan_a == plan_b == expect, (tol, k, plan_a, plan_b, expect)
+            diag = eng.planner_diag()
+            assert diag["timeouts"] == 0 and diag["enqueued"] == plan_b
+        eng.comm_destroy()
+
+
+# ----------------------------------------------------------------------------- the host-side planner
+def _run_contexts(pairs, iters, n_threads):
+    out = [None] * len(pairs)
+    engs = []
+    for gold, comp in pairs:
+        e = mapalign.MapAligner(0)
+        e.set_pair(gold, comp)
+        e.icp(iters, 0.0, 0.10)                                       # warm
+        engs.append(e)
+
+    def work(i):
+        r = engs[i].icp(iters, 0.0, 0.10, with_trace=True)
+        out[i] = (r, engs[i].list_stats(), engs[i].planner_diag())
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    for e in engs:
+        e.close()
+    return out, wall
+
+
+def test_planner_with_four_contexts_on_two_host_cores(lib_built):
+    """Four contexts iterate at once, each with its own planner thread, while the process may run on TWO host cores only
+    (os.sched_setaffinity): a planner that spun without pause would hold a core the other three need to enqueue their
+    batches.  Results must be bitwise those of the unpinned run (they cannot depend on the plan), no wait may time out,
+    and the four alignments must not take more than 1.5x as long as unpinned."""
+    pairs = [syn.make_pair(20 + i, 300_000, 300_000, angle_deg=0.5, t0=(0.02, -0.01, 0.01))[:2] for i in range(4)]
+    iters = 60
+    free, wall_free = _run_contexts(pairs, iters, 4)
+    free2, wall_free2 = _run_contexts(pairs, iters, 4)
+    cores = sorted(os.sched_getaffinity(0))
+    assert len(cores) >= 2
+    os.sched_setaffinity(0, set(cores[:2]))
+    try:
+        pinned, wall_pinned = _run_contexts(pairs, iters, 4)
+        pinned2, wall_pinned2 = _run_contexts(pairs, iters, 4)
+    finally:
+        os.sched_setaffinity(0, set(cores))
+    for (a, sa, da), (b, sb, db) in zip(free, pinned):
+        assert np.array_equal(a.T, b.T) and np.array_equal(a.trace, b.trace)
+        assert sa["uses"] >= 10 and sb == sa                          # the plan belongs to fixed iterations: the same
+        assert da["timeouts"] == 0 and db["timeouts"] == 0
+    wf, wp = min(wall_free, wall_free2), min(wall_pinned, wall_pinned2)
+    yielded = sum(d["yielded"] for _, _, d in pinned)
+    print(f"4 contexts x {iters} iterations: {wf * 1e3:.2f} ms unpinned, {wp * 1e3:.2f} ms on 2 cores; planner waits that "
+          f"left the spin for yields (pinned run): {yielded}")
+    assert wp <= 1.5 * wf + 2e-3, (wf, wp)
+
+
+def test_planner_timeout_is_reported_and_changes_no_bit(lib_built, monkeypatch):
+    """Fault injection: a context created with MAPALIGN_PLANNER_TIMEOUT_US=1 gives up its first wait for a slot at once
+    (the 1M-point pair: four of its early iterations take ~0.4 ms, the host has enqueued two batches after ~0.1 ms, so
+    the slot is not there yet).  The run must then go on searching with the stream drained before every batch, return
+    the bits of an undisturbed run — with a convergence test too, at the same iteration — and REPORT the timeout
+    (ma_get_planner_diag)."""
+    gold, comp, _, _ = syn.make_pair(0, 1_000_000)
+    with mapalign.MapAligner(0) as eng:
+        eng.set_pair(gold, comp)
+        ref = eng.icp(50, 0.0, 0.10, with_trace=True)
+        ref_tol = eng.icp(90, 1e-5, 0.10)
+        assert eng.planner_diag()["timeouts"] == 0 and ref_tol.converged
+    monkeypatch.setenv("MAPALIGN_PLANNER_TIMEOUT_US", "1")
+    with mapalign.MapAligner(0) as eng:
+        monkeypatch.delenv("MAPALIGN_PLANNER_TIMEOUT_US")
+        eng.set_pair(gold, comp)
+        res = eng.icp(50, 0.0, 0.10, with_trace=True)
+        d = eng.planner_diag()
+        assert d["timeouts"] == 1 and d["enqueued"] == 50, d
+        assert eng.list_stats() == {"builds": 0, "uses": 0}            # planning stopped with the timeout
+        assert np.array_equal(res.T, ref.T) and np.array_equal(res.trace[:, :18], ref.trace[:, :18])
+        res_tol = eng.icp(90, 1e-5, 0.10)
+        assert res_tol.iterations == ref_tol.iterations and res_tol.converged
+        assert np.array_equal(res_tol.T, ref_tol.T)
+        eng.comm_init(eng.comm_unique_id(), 1, 0)
+        sh = eng.icp_sharded(90, 1e-5, 0.10)
+        assert sh.iterations == ref_tol.iterations and np.array_equal(sh.T, ref_tol.T)
+        assert eng.planner_diag()["timeouts"] == 1
+        eng.comm_destroy()
+
+
+# ----------------------------------------------------------------------------- a8 without the count (configs[2]'s call overhead)
+def test_depth_source_without_the_count_only_enqueues_and_gives_the_same_cloud(engine):
+    """ma_set_source_from_depth with n_valid == NULL (count=False): upload and kernel are enqueued, nothing is waited
+    for, and the alignment behind it gives the bits of the counted call; the count, the compacted points and the
+    per-point results are settled when first asked for.  An image without a valid pixel is reported by whoever needs
+    the cloud first: ma_icp as MA_ERR_DEGENERATE (nothing to match), the count as MA_ERR_EMPTY."""
+    from mapalign import _lib
+    depth, K, T = syn.make_depth_frame(0, width=320, height=240, fx=250.0, fy=250.0, cx=159.5, cy=119.5)
+    depth = depth.copy()
+    depth[::5, ::3] = 0.0
+    depth[100:110] = np.nan
+    gold, _, _, _ = syn.make_pair(0, 200_000)
+    engine.set_gold(gold)
+    n = engine.set_source_from_depth(depth, K, T, 1000.0)
+    assert 0 < n < depth.size
+    ref = engine.icp(30, 0.0, 0.10, with_trace=True)
+    pts = engine.get_source()
+    idx, d2 = engine.nn(None, 0.10)
+    assert engine.set_source_from_depth(depth, K, T, 1000.0, count=False) is None
+    res = engine.icp(30, 0.0, 0.10, with_trace=True)                # straight behind the unprojection, no count taken yet
+    assert np.array_equal(res.T, ref.T) and np.array_equal(res.trace[:, :18], ref.trace[:, :18])
+    assert engine.n_source == n                                     # settled on demand
+    assert np.array_equal(engine.get_source(), pts)
+    engine.set_source_from_depth(depth, K, T, 1000.0, count=False)
+    idx2, d22 = engine.nn(None, 0.10)                               # ... by ma_nn as well (it sizes its outputs by the count)
+    assert np.array_equal(idx2, idx) and np.array_equal(d22, d2)
+    assert engine.last_device_ms() > 0.0
+    # a frame without a valid pixel
+    empty = np.zeros_like(depth)
+    with pytest.raises(mapalign.MapAlignError) as e:
+        engine.set_source_from_depth(empty, K, T, 1000.0)
+    assert e.value.status == _lib.MA_ERR_EMPTY
+    engine.set_source_from_depth(empty, K, T, 1000.0, count=False)
+    with pytest.raises(mapalign.MapAlignError) as e:
+        engine.icp(20, 0.0, 0.10)
+    assert e.value.status == _lib.MA_ERR_DEGENERATE
+    engine.set_source_from_depth(empty, K, T, 1000.0, count=False)
+    with pytest.raises(mapalign.MapAlignError) as e:
+        engine.n_source
+    assert e.value.status == _lib.MA_ERR_EMPTY
+    # and the context works on
+    assert engine.set_source_from_depth(depth, K, T, 1000.0) == n
+    assert np.array_equal(engine.icp(30, 0.0, 0.10).T, ref.T)
