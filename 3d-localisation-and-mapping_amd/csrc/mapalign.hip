@@ -78,9 +78,11 @@ constexpr int kListLen = 8;
 // (plane b0, four positions per slot) and 6-7 (plane b1, two per slot) are positions that the few longer lists gather
 // through.  An unused inline entry is (inf, inf, inf, none): its distance never passes the gate.
 #ifndef MA_LIST_INLINE
-#define MA_LIST_INLINE 2
+#define MA_LIST_INLINE 0
 #endif
-constexpr int kListInline = MA_LIST_INLINE;     // 0 or 2 entries with inline coordinates (A/B: csrc/Makefile `variant`)
+constexpr int kListInline = MA_LIST_INLINE;     // 0 or 2 entries with inline coordinates (A/B: csrc/Makefile `variant`; 2 measured
+                                                // SLOWER, 25.7 against 22.8 us per list launch: 16 more streamed bytes per query cost more
+                                                // than the gathers they save, which hit the XCD's L2 — profiles/r04_variants_ab.txt)
 static_assert(kListInline == 0 || kListInline == 2, "inline entries");
 struct ListPlanes {
   float4* __restrict__ a0;
@@ -848,9 +850,28 @@ __device__ __forceinline__ u4_unaligned ld_cell4(const uint32_t* __restrict__ ba
 }
 
 // The squared distance, in ONE association everywhere (search, per-lane search, list launches): which of two gold
-// points is nearer is decided on these bits, so every path must form them the same way.
-__device__ __forceinline__ float dist2(const float dx, const float dy, const float dz) {
-  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+// points is nearer is decided on these bits, so every path must form them the same way — spelled out, with
+// contraction off, instead of left to what the compiler makes of `dx*dx + dy*dy + dz*dz` in each context.
+// Form (A/B in profiles/r04_variants_ab.txt): (x, y) as ONE packed pair — v_pk_add_f32 for the two differences,
+// v_pk_mul_f32 for their squares (IEEE products) — then one fma and one add:  d = fma(dz, dz, dx*dx) + dy*dy.
+// A chain of three fused multiply-adds is one instruction per candidate more and cost the converged search launches
+// 10 % when the association was first pinned that way.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef MA_DIST_FORM
+#define MA_DIST_FORM 1
+#endif
+__device__ __forceinline__ float dist2(const float px, const float py, const float pz, const float qx, const float qy,
+                                       const float qz) {
+#pragma clang fp contract(off)
+#if MA_DIST_FORM == 1
+  const f32x2 d = f32x2{px, py} - f32x2{qx, qy};
+  const f32x2 sq = d * d;
+  const float dz = pz - qz;
+  return __builtin_fmaf(dz, dz, sq.x) + sq.y;
+#else
+  const float dx = px - qx, dy = py - qy, dz = pz - qz;
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+#endif
 }
 
 // ONE tie rule for every path (round 4): the nearest neighbour is the gold point with the smallest
@@ -871,9 +892,11 @@ __device__ __forceinline__ void scan_run(const float px, const float py, const f
     for (int u = 0; u < 4; ++u) q[u] = ld_point(gold, min(j + (uint32_t)u, b - 1u));
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float d = dist2(px - q[u].x, py - q[u].y, pz - q[u].z);
+      const float d = dist2(px, py, pz, q[u].x, q[u].y, q[u].z);
       const uint32_t pos = __float_as_uint(q[u].w);
-      if (d < best2 || (d == best2 && pos < bestj && bestj != kNoMatch)) { best2 = d; bestj = pos; }
+      const bool take = (d < best2) | ((d == best2) & (pos < bestj) & (bestj != kNoMatch));     // (no short circuit: selects, not branches)
+      best2 = take ? d : best2;
+      bestj = take ? pos : bestj;
     }
   }
 }
@@ -1135,7 +1158,7 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
         for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float3*>(at + 16 * u);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float d = dist2(p.x - q[u].x, p.y - q[u].y, p.z - q[u].z);
+          const float d = dist2(p.x, p.y, p.z, q[u].x, q[u].y, q[u].z);
           if (d < b2) { b2 = d; bo = t + (uint32_t)u; }
           if (BUILD) {
             if (d <= reach2 && t + (uint32_t)u < cnt) {      // real members of the chunk only
@@ -1426,10 +1449,14 @@ __device__ uint32_t g_wgph[64][4096][4];   // wave 0: ticks from the start to: s
 __device__ unsigned long long g_rs[64][20][5];   // k_reduce_solve, per iteration and workgroup: entry, sum stored, ticket back, 19 sums read, solve done
 #endif
 
+// Waves per SIMD the register allocator must make room for: 8 (<= 64 VGPRs) for the search and the list launch — every
+// build that let the search cross 64 VGPRs lost 5-10 % — and whatever it takes for the list-writing launch (2 of an
+// alignment's 50 launches), the work-counting instantiations and ma_nn's (forced to 64 VGPRs they spill).
+// MA_NN_WAVES overrides all of them (A/B).
 #ifdef MA_NN_WAVES
 #define MA_NN_ATTR __attribute__((amdgpu_waves_per_eu(MA_NN_WAVES, MA_NN_WAVES)))
 #else
-#define MA_NN_ATTR
+#define MA_NN_ATTR __attribute__((amdgpu_waves_per_eu((MODE == 0 && LISTS != 1 && !COUNT) ? 8 : 4, 8)))
 #endif
 // LISTS (compile time, so that the plain search launch keeps its 63 VGPRs — a run-time switch between the three bodies
 // cost 6 VGPRs, a wavefront per SIMD and 10 % of every search launch): 0 search; 1 search and write the candidate lists;
@@ -1439,16 +1466,24 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     const float4* __restrict__ src, const uint32_t n, const LevelSet S,
     const uint32_t* __restrict__ perm0, const DevState* __restrict__ st, const float best2_init,
     double* __restrict__ partials, uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, const Sched sched, const ListCtl* __restrict__ lc, const ListPlanes lp) {
-  if (MODE == 0 && st->done) return;
+    float* __restrict__ nn_d2, const Sched sched, const ListCtl* __restrict__ lc, const ListPlanes lp,
+    const int warm_hint) {
+  // a stopped loop: nothing to do.  A list launch tests this only after its loads are on their way (below): every
+  // dependent round trip in front of the first load is ~1 us of each of a launch's two generations of workgroups
+  if (MODE == 0 && LISTS != 2 && st->done) return;
   constexpr int lmode = MODE == 0 ? LISTS : 0;
   const unsigned long long wg_start = wall_clock64();
   constexpr int kNW = kNNBlock / kWave;
   const uint32_t G = gridDim.x;
-  const bool warm = st->iter > 0;          // iteration 0 of a run: no schedule yet, and prev[] holds another run's matches
-  // (list launches too: an XCD that works on contiguous pieces of the cloud keeps the gold lines its gathers touch in
-  // its own L2 — chunks in plain launch order, dealt round-robin over the XCDs, cost 2.5 us of a 23-us launch)
-  const uint32_t chunk = xcd_chunk(blockIdx.x, sched, sched.order != nullptr && warm);
+  // iteration 0 of a run: no schedule yet, and prev[] holds another run's matches.  The loop knows which iteration it
+  // enqueues and says so (warm_hint 0 / 1: one dependent scalar load less in front of the first data load); the stepping
+  // entry points leave it to the state (-1)
+  const bool warm = warm_hint >= 0 ? warm_hint != 0 : st->iter > 0;
+  // The chunk of this workgroup.  Search launches: XCD segments in longest-first order (the order is a dependent load).
+  // List launches: the same segments in cloud order — their work is uniform, so no order is needed, and the first loads
+  // depend on nothing but the kernel arguments; what must stay is the XCD's contiguous piece of the cloud (the gold lines
+  // its gathers touch live in its own L2: chunks in plain launch order cost 2.5 us of a 23-us launch).
+  const uint32_t chunk = xcd_chunk(blockIdx.x, sched, lmode != 2 && sched.order != nullptr && warm);
   const uint32_t i = chunk * kNNBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   // per-wavefront LDS: the work queues during the search, the group sums afterwards
@@ -1478,6 +1513,20 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   };
   float px = 0.f, py = 0.f, pz = 0.f, best2 = best2_init;
   uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
+  // list launch: the query's list (first plane, or the two inline entries) and its radius — issued here, beside the
+  // source point and in front of everything that depends on the state
+  float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
+  uint4 lb0 = make_uint4(0u, 0u, 0u, 0u);
+  float Lq = 0.f;
+  if constexpr (lmode == 2) {
+    if (has) {
+      if (kListInline > 0) { e0 = lp.a0[i]; e1 = lp.a1[i]; }
+      else lb0 = reinterpret_cast<const uint4*>(lp.b0)[i];           // without inline entries the first plane is read by every query
+      Lq = lp.rad[i];
+      s = src[i];
+    }
+    if (st->done) return;
+  }
   if (has) {
     image(i);
     px = (float)Px; py = (float)Py; pz = (float)Pz;
@@ -1486,8 +1535,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       const uint32_t pj = prev[i];
       if (pj != kNoMatch) {
         const float3 c = ld_xyz(S.gold[0], pj);
-        const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
+        const float d2 = dist2(px, py, pz, c.x, c.y, c.z);     // (the one association: a remembered match must not tie-break on a rounding of its own)
         if (COUNT) ncand += 1u;
         if (d2 < best2) { best2 = d2; bestj = pj; }
       }
@@ -1509,11 +1557,6 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     if (has) {
       const bool finite = isfinite(px) && isfinite(py) && isfinite(pz);
       constexpr uint32_t kIn = (uint32_t)kListInline;
-      float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
-      uint4 lb0 = make_uint4(0u, 0u, 0u, 0u);
-      if (kIn > 0u) { e0 = lp.a0[i]; e1 = lp.a1[i]; }
-      else lb0 = reinterpret_cast<const uint4*>(lp.b0)[i];           // without inline entries the first plane is read by every query
-      const float Lq = lp.rad[i];
       const uint32_t nlist = __float_as_uint(Lq) & 0xFu;     // entries on the list
       // how far this query has moved since its list was written: (R - Rb) s + (t - tb), wave-uniform differences
       float dRf[9], dtf[3];
@@ -1527,9 +1570,11 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       const float moved = fast_sqrt(mx * mx + my * my + mz * mz) + lc->slack;
       unsigned long long key = pack_best(best2, kNoMatch);
       auto consider = [&](const float qx, const float qy, const float qz, const uint32_t pos) {
-        const float d = dist2(px - qx, py - qy, pz - qz);
+        const float d = dist2(px, py, pz, qx, qy, qz);
         const unsigned long long ku = pack_best(d, pos);
-        if (d < best2_init && ku < key) { key = ku; wqx = qx; wqy = qy; wqz = qz; }      // the tie rule: smallest (distance, position)
+        const bool take = (d < best2_init) & (ku < key);      // the tie rule: smallest (distance, position); selects, not branches
+        key = take ? ku : key;
+        wqx = take ? qx : wqx; wqy = take ? qy : wqy; wqz = take ? qz : wqz;
       };
       if (kIn > 0u) {
         consider(e0.x, e0.y, e0.z, __float_as_uint(e0.w));
@@ -1539,8 +1584,9 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
         if (kIn > 0u) lb0 = reinterpret_cast<const uint4*>(lp.b0)[i];
         const uint32_t idx[4] = {lb0.x, lb0.y, lb0.z, lb0.w};
         float3 q[4];
+        // only the entries the list holds are gathered (2.3 of 4 on average: the cache looks every lane's address up)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = ld_xyz(S.gold[0], idx[u]);
+        for (int u = 0; u < 4; ++u) q[u] = (kIn + (uint32_t)u < nlist) ? ld_xyz(S.gold[0], idx[u]) : make_float3(INFINITY, INFINITY, INFINITY);
 #pragma unroll
         for (int u = 0; u < 4; ++u) consider(q[u].x, q[u].y, q[u].z, idx[u]);
         if (nlist > kIn + 4u) {
@@ -1548,7 +1594,8 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
           const uint32_t idx1[4] = {lb1.x, lb1.y, kIn == 0u ? lb1.z : lb1.x, kIn == 0u ? lb1.w : lb1.y};     // (two in use beside inline entries)
           float3 r[4];
 #pragma unroll
-          for (int u = 0; u < (kIn == 0u ? 4 : 2); ++u) r[u] = ld_xyz(S.gold[0], idx1[u]);
+          for (int u = 0; u < (kIn == 0u ? 4 : 2); ++u)
+            r[u] = (kIn + 4u + (uint32_t)u < nlist) ? ld_xyz(S.gold[0], idx1[u]) : make_float3(INFINITY, INFINITY, INFINITY);
 #pragma unroll
           for (int u = 0; u < (kIn == 0u ? 4 : 2); ++u) consider(r[u].x, r[u].y, r[u].z, idx1[u]);
         }
@@ -2826,7 +2873,7 @@ int upload_state(ma_ctx* ctx, const double* T) {
 // `scheduled`: inside the ma_icp loop (costs recorded, longest-first order from iteration 1 on)
 template <int MODE>
 int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2, bool scheduled = false,
-              int list_kind = 0) {
+              int list_kind = 0, int warm_hint = -1) {
   uint32_t gshift = 0;
   const uint32_t G = grid_for(ctx->n, &gshift);
   ctx->last_G = (int)G;
@@ -2850,7 +2897,7 @@ int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float
                        ctx->levels, ctx->perm0.as<uint32_t>(), ctx->state.as<DevState>(), best2_init,
                        ctx->partials.as<double>(),
                        MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, nn_idx, nn_d2, sched,
-                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, lp);
+                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, lp, warm_hint);
   };
   if (MODE == 0 && with_lists && list_kind == 1) {
     if (count) args(k_nn_accum<true, MODE == 0 ? 0 : 1, MODE == 0 ? 1 : 0>);
@@ -4214,7 +4261,7 @@ static int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16],
     }
     const int kind = ctx->lists_on ? plan[k % kPlan] : 0;
     ctx->list_plan.push_back((uint8_t)kind);
-    if ((rc = launch_nn<0>(ctx, count, best2, nullptr, nullptr, MA_SCHED != 0, kind))) return rc;
+    if ((rc = launch_nn<0>(ctx, count, best2, nullptr, nullptr, MA_SCHED != 0, kind, k > 0 ? 1 : 0))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
     StateSlot* slot = slots_used ? &ctx->host_slots[k] : nullptr;
     if (sharded) {
