@@ -80,6 +80,7 @@ constexpr int kListLen = 8;
 #ifndef MA_LIST_INLINE
 #define MA_LIST_INLINE 0
 #endif
+
 constexpr int kListInline = MA_LIST_INLINE;     // 0 or 2 entries with inline coordinates (A/B: csrc/Makefile `variant`; 2 measured
                                                 // SLOWER, 25.7 against 22.8 us per list launch: 16 more streamed bytes per query cost more
                                                 // than the gathers they save, which hit the XCD's L2 — profiles/r04_variants_ab.txt)
@@ -1468,9 +1469,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     double* __restrict__ partials, uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx,
     float* __restrict__ nn_d2, const Sched sched, const ListCtl* __restrict__ lc, const ListPlanes lp,
     const int warm_hint) {
-  // a stopped loop: nothing to do.  A list launch tests this only after its loads are on their way (below): every
-  // dependent round trip in front of the first load is ~1 us of each of a launch's two generations of workgroups
-  if (MODE == 0 && LISTS != 2 && st->done) return;
+  if (MODE == 0 && st->done) return;      // a stopped loop: nothing to do
   constexpr int lmode = MODE == 0 ? LISTS : 0;
   const unsigned long long wg_start = wall_clock64();
   constexpr int kNW = kNNBlock / kWave;
@@ -1479,11 +1478,11 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   // enqueues and says so (warm_hint 0 / 1: one dependent scalar load less in front of the first data load); the stepping
   // entry points leave it to the state (-1)
   const bool warm = warm_hint >= 0 ? warm_hint != 0 : st->iter > 0;
-  // The chunk of this workgroup.  Search launches: XCD segments in longest-first order (the order is a dependent load).
-  // List launches: the same segments in cloud order — their work is uniform, so no order is needed, and the first loads
-  // depend on nothing but the kernel arguments; what must stay is the XCD's contiguous piece of the cloud (the gold lines
-  // its gathers touch live in its own L2: chunks in plain launch order cost 2.5 us of a 23-us launch).
-  const uint32_t chunk = xcd_chunk(blockIdx.x, sched, lmode != 2 && sched.order != nullptr && warm);
+  // The chunk of this workgroup: XCD segments in longest-first order.  List launches keep the mapping of the launch that
+  // wrote the lists (their work is uniform, the order itself buys them nothing, but chunks in plain launch order — every
+  // XCD touching gold lines from all over the map — cost 2.5 us of a 23-us launch, and segments in cloud order without
+  // the schedule read measured 0.4 us slower than with it: profiles/r04_variants_ab.txt).
+  const uint32_t chunk = xcd_chunk(blockIdx.x, sched, sched.order != nullptr && warm);
   const uint32_t i = chunk * kNNBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   // per-wavefront LDS: the work queues during the search, the group sums afterwards
@@ -1513,8 +1512,8 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   };
   float px = 0.f, py = 0.f, pz = 0.f, best2 = best2_init;
   uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
-  // list launch: the query's list (first plane, or the two inline entries) and its radius — issued here, beside the
-  // source point and in front of everything that depends on the state
+  // list launch: the query's list (first plane, or the two inline entries) and its radius, issued beside the source
+  // point (issuing them ahead of the `done` test as well changed nothing: profiles/r04_variants_ab.txt)
   float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;
   uint4 lb0 = make_uint4(0u, 0u, 0u, 0u);
   float Lq = 0.f;
@@ -1523,9 +1522,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       if (kListInline > 0) { e0 = lp.a0[i]; e1 = lp.a1[i]; }
       else lb0 = reinterpret_cast<const uint4*>(lp.b0)[i];           // without inline entries the first plane is read by every query
       Lq = lp.rad[i];
-      s = src[i];
     }
-    if (st->done) return;
   }
   if (has) {
     image(i);
@@ -1584,9 +1581,10 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
         if (kIn > 0u) lb0 = reinterpret_cast<const uint4*>(lp.b0)[i];
         const uint32_t idx[4] = {lb0.x, lb0.y, lb0.z, lb0.w};
         float3 q[4];
-        // only the entries the list holds are gathered (2.3 of 4 on average: the cache looks every lane's address up)
+        // (all four, whatever the list holds — free slots repeat the match, an L1 hit: gathering only the entries held
+        // is four exec-masked loads and measured 2 us slower per launch, profiles/r04_variants_ab.txt)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = (kIn + (uint32_t)u < nlist) ? ld_xyz(S.gold[0], idx[u]) : make_float3(INFINITY, INFINITY, INFINITY);
+        for (int u = 0; u < 4; ++u) q[u] = ld_xyz(S.gold[0], idx[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) consider(q[u].x, q[u].y, q[u].z, idx[u]);
         if (nlist > kIn + 4u) {
@@ -1594,8 +1592,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
           const uint32_t idx1[4] = {lb1.x, lb1.y, kIn == 0u ? lb1.z : lb1.x, kIn == 0u ? lb1.w : lb1.y};     // (two in use beside inline entries)
           float3 r[4];
 #pragma unroll
-          for (int u = 0; u < (kIn == 0u ? 4 : 2); ++u)
-            r[u] = (kIn + 4u + (uint32_t)u < nlist) ? ld_xyz(S.gold[0], idx1[u]) : make_float3(INFINITY, INFINITY, INFINITY);
+          for (int u = 0; u < (kIn == 0u ? 4 : 2); ++u) r[u] = ld_xyz(S.gold[0], idx1[u]);
 #pragma unroll
           for (int u = 0; u < (kIn == 0u ? 4 : 2); ++u) consider(r[u].x, r[u].y, r[u].z, idx1[u]);
         }
