@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_keys4(const float4* __restrict_
   const uint32_t c = cell_of(p.x, p.y, p.z, g);
   keys[i] = c;
   vals[i] = i;
-  atomicAdd(&counts[c], 1u);
+  if (counts) atomicAdd(&counts[c], 1u);
 }
 
 __global__ __launch_bounds__(kBlock) void k_gather4(const float4* __restrict__ gold0, const uint32_t* __restrict__ perm,
@@ -3076,22 +3076,29 @@ Pinhole make_pinhole(const float K[4], const double T[16], float depth_scale, co
 
 // Levels 1..3 (cell edges 2c, 4c, 8c over the same box) from the level-0 copy.  Stable sort by
 // cell id of level l: inside a cell the points keep their level-0 order.
+// Round 4: the same launches as level 0's build — cell keys without a histogram (no atomics), the own radix sort, the cell
+// table straight from the sorted keys (k_cell_starts + k_fill_gaps) — instead of a histogram with one atomic per point, a
+// memset and a library scan per level; and no synchronisation between the levels: everything is on one stream, the
+// scratch a level reuses is free by the time its launches run.  (An ungated run's first iteration, which is where these
+// levels are built, used to spend most of its 3.7 ms here.)
 int build_coarse_levels(ma_ctx* ctx) {
   const uint32_t n = ctx->m;
-  DevBuf& hist = ctx->misc;
+  HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
+  HIPCHK(ctx->keys_b.ensure((size_t)n * 4));
+  HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
+  HIPCHK(ctx->vals_b.ensure((size_t)n * 4));
+  const uint32_t nblk = (div_up(n + 1u, kBlock) + 7u) & ~7u;   // item n settles the cells behind the last occupied one; 8 | grid
+  HIPCHK(ctx->occ_b.ensure((size_t)nblk * 4));
+  if (!ctx->gap_list.p || ctx->gap_list_dirty) {
+    HIPCHK(ctx->gap_list.ensure(sizeof(GapList)));
+    HIPCHK(hipMemsetAsync(ctx->gap_list.p, 0, sizeof(GapList), ctx->stream));
+  }
   for (int l = 1; l < kLevels; ++l) {
     const GridP g = make_grid(ctx->grid_lo, ctx->grid_hi, ctx->origin, ctx->grid.c * (float)(1 << l));
     const uint64_t ncells = (uint64_t)g.nx * g.ny * g.nz;
     HIPCHK(ctx->cstart[l].ensure((ncells + 8) * 4));
-    HIPCHK(hist.ensure((ncells + 8) * 4 + 64));
-    uint32_t* d_hist = reinterpret_cast<uint32_t*>(static_cast<char*>(hist.p) + 64);
-    HIPCHK(hipMemsetAsync(hist.p, 0, (ncells + 8) * 4 + 64, ctx->stream));
-    HIPCHK(ctx->keys_a.ensure((size_t)n * 4));
-    HIPCHK(ctx->keys_b.ensure((size_t)n * 4));
-    HIPCHK(ctx->vals_a.ensure((size_t)n * 4));
-    HIPCHK(ctx->vals_b.ensure((size_t)n * 4));
     hipLaunchKernelGGL(k_cell_keys4, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->gold[0].as<float4>(), n, g,
-                       ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), d_hist);
+                       ctx->keys_a.as<uint32_t>(), ctx->vals_a.as<uint32_t>(), (uint32_t*)nullptr);
     HIPCHK(hipGetLastError());
     int bits = 1;
     while (bits < 32 && (1ull << bits) < ncells) ++bits;
@@ -3101,14 +3108,24 @@ int build_coarse_levels(ma_ctx* ctx) {
     HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
     HIPCHK(sort_pairs_u32(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), ctx->vals_a.as<uint32_t>(),
                           ctx->vals_b.as<uint32_t>(), n, bits, ctx->stream));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), (int)(ncells + 8), ctx->stream));
-    HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, d_hist, ctx->cstart[l].as<uint32_t>(), (int)(ncells + 8), ctx->stream));
+    ctx->gap_list_dirty = true;
+    hipLaunchKernelGGL(k_cell_starts, dim3(nblk), dim3(kBlock), 0, ctx->stream, ctx->keys_b.as<uint32_t>(), n,
+                       (uint32_t)(ncells + 8), ctx->cstart[l].as<uint32_t>(), ctx->occ_b.as<uint32_t>(),
+                       ctx->gap_list.as<GapList>());
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_fill_gaps, dim3(256), dim3(kBlock), 0, ctx->stream, ctx->gap_list.as<GapList>(),
+                       ctx->cstart[l].as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    // (the run-start counts are not wanted here: k_sum_u32 runs for its other duty, clearing the gap list's counter;
+    // its sum goes to a mailbox word nobody reads)
+    hipLaunchKernelGGL(k_sum_u32, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->occ_b.as<uint32_t>(), nblk,
+                       reinterpret_cast<unsigned long long*>(ctx->mailbox + kMailWord + 128), &ctx->gap_list.as<GapList>()->count);
+    HIPCHK(hipGetLastError());
+    ctx->gap_list_dirty = false;
     HIPCHK(ctx->gold[l].ensure(((size_t)n + 8) * sizeof(float4)));
     hipLaunchKernelGGL(k_gather4, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->gold[0].as<float4>(),
                        ctx->vals_b.as<uint32_t>(), n, ctx->gold[l].as<float4>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));   // hist / sort scratch is reused by the next level
     LevelSet& L = ctx->levels;
     L.gold[l] = ctx->gold[l].as<float4>();
     L.cs[l] = ctx->cstart[l].as<uint32_t>();
