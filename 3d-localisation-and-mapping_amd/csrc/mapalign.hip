@@ -887,6 +887,11 @@ __device__ __forceinline__ float dist2(const float px, const float py, const flo
 __device__ __forceinline__ void scan_run(const float px, const float py, const float pz,
                                          const float4* __restrict__ gold, const uint32_t a,
                                          const uint32_t b, float& best2, uint32_t& bestj) {
+  if (a >= b) return;
+  // The tie rule as ONE 64-bit comparison per candidate: keys (distance bits, position) — squared distances are
+  // non-negative, so their bit patterns order like the values.  "Nothing held, gate g" is the key (bits(g) - 1, none):
+  // a candidate strictly inside the gate is smaller, one AT the open gate is not.
+  unsigned long long key = ((unsigned long long)(__float_as_uint(best2) - (bestj == kNoMatch ? 1u : 0u)) << 32) | bestj;
   for (uint32_t j = a; j < b; j += 4u) {
     float4 q[4];
 #pragma unroll
@@ -894,12 +899,12 @@ __device__ __forceinline__ void scan_run(const float px, const float py, const f
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float d = dist2(px, py, pz, q[u].x, q[u].y, q[u].z);
-      const uint32_t pos = __float_as_uint(q[u].w);
-      const bool take = (d < best2) | ((d == best2) & (pos < bestj) & (bestj != kNoMatch));     // (no short circuit: selects, not branches)
-      best2 = take ? d : best2;
-      bestj = take ? pos : bestj;
+      const unsigned long long ku = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q[u].w);
+      key = ku < key ? ku : key;
     }
   }
+  bestj = (uint32_t)key;
+  best2 = __uint_as_float((uint32_t)(key >> 32) + (bestj == kNoMatch ? 1u : 0u));
 }
 
 // One pass at one level: the 3 x 3 rows around the query's row (rings 0 and 1), each over
