@@ -81,6 +81,7 @@ constexpr int kListLen = 8;
 #define MA_LIST_INLINE 0
 #endif
 
+
 constexpr int kListInline = MA_LIST_INLINE;     // 0 or 2 entries with inline coordinates (A/B: csrc/Makefile `variant`; 2 measured
                                                 // SLOWER, 25.7 against 22.8 us per list launch: 16 more streamed bytes per query cost more
                                                 // than the gathers they save, which hit the XCD's L2 — profiles/r04_variants_ab.txt)
@@ -1448,6 +1449,74 @@ __device__ __forceinline__ uint32_t xcd_chunk(const uint32_t b, const Sched& sc,
 // best (2 and 4 points per thread measured 25-70 % slower), and the 17 fp64 accumulator terms
 // are formed only after the search, so they hold no registers during it.
 
+// The fp64 image of a source point under the state's transform, in ONE association (every launch kind must arrive at
+// the same bits: a search launch forms it twice, a list launch once).
+__device__ __forceinline__ void point_image(const DevState* __restrict__ st, const float4 s, double& Px, double& Py, double& Pz) {
+  const double x = s.x, y = s.y, z = s.z;
+  Px = __fma_rn(st->R[2], z, __fma_rn(st->R[1], y, __fma_rn(st->R[0], x, st->t[0])));
+  Py = __fma_rn(st->R[5], z, __fma_rn(st->R[4], y, __fma_rn(st->R[3], x, st->t[1])));
+  Pz = __fma_rn(st->R[8], z, __fma_rn(st->R[7], y, __fma_rn(st->R[6], x, st->t[2])));
+}
+// a5: the 17 terms of one correspondence (w, w p', w q, w p' q^T row-major, w |p' - q|^2)
+__device__ __forceinline__ void pair_terms(double (&acc)[kNAcc], const double w, const double Px, const double Py, const double Pz,
+                                           const float3 q) {
+  const double qx = q.x, qy = q.y, qz = q.z;
+  const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
+  const double wPx = w * Px, wPy = w * Py, wPz = w * Pz;
+  acc[0] = w;
+  acc[1] = wPx; acc[2] = wPy; acc[3] = wPz;
+  acc[4] = w * qx; acc[5] = w * qy; acc[6] = w * qz;
+  acc[7] = wPx * qx;  acc[8] = wPx * qy;  acc[9] = wPx * qz;
+  acc[10] = wPy * qx; acc[11] = wPy * qy; acc[12] = wPy * qz;
+  acc[13] = wPz * qx; acc[14] = wPz * qy; acc[15] = wPz * qz;
+  acc[16] = w * __fma_rn(dz, dz, __fma_rn(dy, dy, dx * dx));
+}
+// Workgroup reduction of the live accumulators of one 256-point chunk, fixed order (deterministic), shared by every
+// launch kind so that their partials are the same bits:
+//   1. two DPP steps fold each group of 4 lanes (6 VALU ops per value; a full wavefront
+//      reduction in DPP costs 18 and was a quarter of the search kernel's VALU work);
+//   2. the 16 group sums per wavefront go to LDS; 8 threads per accumulator each add
+//      their share in index order;
+//   3. one thread per accumulator adds the 8 partial sums and writes the partial.
+// Without work counting only the 17 real accumulators take part (the counter slots stay 0).
+// WV: per-wavefront LDS area with a member v[kNAcc][16]; two barriers inside.
+constexpr int kRedParts = 8;
+template <bool COUNT, typename WV>
+__device__ __forceinline__ void reduce_chunk(const double (&acc)[kNAcc], WV* __restrict__ sh_w, double (*sh_part)[kRedParts],
+                                             double* __restrict__ partials, const uint32_t G, const uint32_t chunk,
+                                             const int lane, const int wv) {
+  constexpr int kNW = kNNBlock / kWave;
+  constexpr int kLive = COUNT ? kNAcc : ma::kAccLen;
+  constexpr int kVals = kNW * 16, kPer = kVals / kRedParts;
+#pragma unroll
+  for (int k = 0; k < kLive; ++k) {
+    double v = dpp_add<0x111>(acc[k]);
+    v = dpp_add<0x112>(v);
+    if ((lane & 3) == 3) sh_w[wv].v[k][lane >> 2] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kLive * kRedParts) {
+    const int k = threadIdx.x / kRedParts, part = threadIdx.x % kRedParts;
+    double v = 0.0;
+#pragma unroll
+    for (int t = 0; t < kPer; ++t) {
+      const int idx = part * kPer + t;
+      v += sh_w[idx / 16].v[k][idx % 16];
+    }
+    sh_part[k][part] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNAcc) {
+    const int k = threadIdx.x;
+    double v = 0.0;
+    if (k < kLive) {
+#pragma unroll
+      for (int t = 0; t < kRedParts; ++t) v += sh_part[k][t];
+    }
+    partials[(size_t)k * G + chunk] = v;
+  }
+}
+
 #if MA_WGTIMES   // debug variant only (tools/wgtimeline.py): start/end clock and placement of every workgroup
 __device__ unsigned long long g_wgt[64][4096][2];
 __device__ uint32_t g_wghw[64][4096][2];
@@ -1508,12 +1577,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   double Px = 0.0, Py = 0.0, Pz = 0.0;
   auto image = [&](const uint32_t at) {
     s = src[at];
-    // one association, spelled out: the search launches form the image twice (before and after the search), a list
-    // launch once, and all of them must arrive at the same bits whatever the compiler would contract
-    const double x = s.x, y = s.y, z = s.z;
-    Px = __fma_rn(st->R[2], z, __fma_rn(st->R[1], y, __fma_rn(st->R[0], x, st->t[0])));
-    Py = __fma_rn(st->R[5], z, __fma_rn(st->R[4], y, __fma_rn(st->R[3], x, st->t[1])));
-    Pz = __fma_rn(st->R[8], z, __fma_rn(st->R[7], y, __fma_rn(st->R[6], x, st->t[2])));
+    point_image(st, s, Px, Py, Pz);
   };
   float px = 0.f, py = 0.f, pz = 0.f, best2 = best2_init;
   uint32_t bestj = kNoMatch, nrows = 0, ncand = 0;
@@ -1657,17 +1721,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       float3 q;
       if constexpr (lmode == 2) q = make_float3(wqx, wqy, wqz);     // carried with the minimum: the very bits of the gold array
       else q = ld_xyz(S.gold[0], bestj);           // the winner's coordinates (level 0 holds every point)
-      const double w = (double)s.w;
-      const double qx = q.x, qy = q.y, qz = q.z;
-      const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
-      const double wPx = w * Px, wPy = w * Py, wPz = w * Pz;
-      acc[0] = w;
-      acc[1] = wPx; acc[2] = wPy; acc[3] = wPz;
-      acc[4] = w * qx; acc[5] = w * qy; acc[6] = w * qz;
-      acc[7] = wPx * qx;  acc[8] = wPx * qy;  acc[9] = wPx * qz;
-      acc[10] = wPy * qx; acc[11] = wPy * qy; acc[12] = wPy * qz;
-      acc[13] = wPz * qx; acc[14] = wPz * qy; acc[15] = wPz * qz;
-      acc[16] = w * __fma_rn(dz, dz, __fma_rn(dy, dy, dx * dx));
+      pair_terms(acc, (double)s.w, Px, Py, Pz, q);
     }
     if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
   }
@@ -1677,45 +1731,11 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   dbg_t4 = wall_clock64();
 #endif
 
-  // Workgroup reduction of the live accumulators, fixed order (deterministic):
-  //   1. two DPP steps fold each group of 4 lanes (6 VALU ops per value; a full wavefront
-  //      reduction in DPP costs 18 and was a quarter of this kernel's VALU work);
-  //   2. the 16 group sums per wavefront go to LDS; 8 threads per accumulator each add
-  //      their share in index order;
-  //   3. one thread per accumulator adds the 8 partial sums and writes the partial.
-  // Without work counting only the 17 real accumulators take part (the counter slots stay 0).
-  constexpr int kLive = COUNT ? kNAcc : ma::kAccLen;
-  constexpr int kVals = kNW * 16, kParts = 8, kPer = kVals / kParts;
-  __shared__ double sh_part[kNAcc][kParts];
+  // workgroup reduction of the live accumulators -> one partial per accumulator and chunk (reduce_chunk)
+  __shared__ double sh_part[kNAcc][kRedParts];
   __shared__ uint32_t sh_dismissed[kNW];
   if (lane == 0) sh_dismissed[wv] = ndismissed;
-#pragma unroll
-  for (int k = 0; k < kLive; ++k) {
-    double v = dpp_add<0x111>(acc[k]);
-    v = dpp_add<0x112>(v);
-    if ((lane & 3) == 3) sh_w[wv].v[k][lane >> 2] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kLive * kParts) {
-    const int k = threadIdx.x / kParts, part = threadIdx.x % kParts;
-    double v = 0.0;
-#pragma unroll
-    for (int t = 0; t < kPer; ++t) {
-      const int idx = part * kPer + t;
-      v += sh_w[idx / 16].v[k][idx % 16];
-    }
-    sh_part[k][part] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kNAcc) {
-    const int k = threadIdx.x;
-    double v = 0.0;
-    if (k < kLive) {
-#pragma unroll
-      for (int t = 0; t < kParts; ++t) v += sh_part[k][t];
-    }
-    partials[(size_t)k * G + chunk] = v;
-  }
+  reduce_chunk<COUNT>(acc, sh_w, sh_part, partials, G, chunk, lane, wv);
   // Cost for the next launch's schedule: this workgroup's duration, plus what its dismissed
   // points would have cost had they walked their rings (~0.5 us per point of one wavefront;
   // four wavefronts run side by side) — as the clouds approach each other such points come
