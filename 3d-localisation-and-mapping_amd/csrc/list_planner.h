@@ -25,6 +25,34 @@ constexpr int kPlan = 4;             // iterations per planning batch of ma_icp
 constexpr float kSkinDivDefault = 7.f;
 constexpr int kMinUsesDefault = 5;
 
+// ---- Where a stopped loop stops ENQUEUEING (icp_loop; the same rule on every rank of a sharded loop) ------------------
+// Every solve up to and including the one that stops the loop writes its pinned slot; the one that stops it also stores
+// `iterations_run` (its 1-based number; 0 while the loop runs) in the pinned `done` word.  Before batch b — first
+// iteration k, a multiple of kPlan, k >= 2 kPlan — the host waits for the slot of j = k - kPlan - 1.  What it may see,
+// in any order and at any time: the slot (complete or not yet), the done word (set or not yet).  The decision must be a
+// function of the STATES alone — "stop before batch b iff the loop stopped at an iteration <= j" — because the ranks of a
+// sharded loop look at different moments and must still issue the same number of collectives.
+enum class SlotWait { kKeepWaiting, kSlotHere, kStoppedBefore };
+inline SlotWait slot_wait_state(bool slot_complete, int iterations_run_at_stop, int j) {
+  if (slot_complete) return SlotWait::kSlotHere;
+  // stopped at iteration (iterations_run_at_stop - 1) < j: slot j will never be written.  Stopped AT j: it still comes,
+  // with `done` set in it — keep waiting for it (so that both orders of arrival give the same answer)
+  if (iterations_run_at_stop != 0 && iterations_run_at_stop - 1 < j) return SlotWait::kStoppedBefore;
+  return SlotWait::kKeepWaiting;
+}
+inline bool stops_before_batch(SlotWait w, bool slot_says_done) {
+  return w == SlotWait::kStoppedBefore || (w == SlotWait::kSlotHere && slot_says_done);
+}
+// the same decision with complete knowledge (after a drained stream): how many iterations a loop that stopped after
+// `iterations_run_at_stop` iterations (0: never) enqueues in all
+inline int iterations_enqueued(int max_iter, int iterations_run_at_stop, bool slots_in_use) {
+  if (iterations_run_at_stop == 0 || !slots_in_use) return max_iter;
+  const int s = iterations_run_at_stop - 1;                  // the iteration that stopped the loop
+  for (int k = 2 * kPlan; k < max_iter; k += kPlan)
+    if (s <= k - kPlan - 1) return k;
+  return max_iter;
+}
+
 struct ListPlanner {
   // set once per run
   double use_max = 0.0;      // a query passes its check while it has moved less than skin / 2: 0.49 skin

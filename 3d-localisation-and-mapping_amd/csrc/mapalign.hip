@@ -4253,9 +4253,11 @@ static int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16],
         int state = 0;                             // 1: slot j is here; 2: the loop stopped before j; 3: timeout
         bool yielding = false;
         for (uint32_t spins = 0;; ++spins) {
-          if (slot_ready(&sl, j + 1)) { state = 1; break; }
-          const int hd = *host_done;               // iterations run when the loop stopped; 0 while it runs
-          if (hd != 0 && hd - 1 < j) { state = 2; break; }      // (stopped AT j: its slot is still to come, with done set)
+          // (list_planner.h: slot_wait_state — the slot, or the loop stopped BEFORE j and the slot never comes; stopped
+          // AT j its slot is still to come, with `done` set in it)
+          const ma::SlotWait w = ma::slot_wait_state(slot_ready(&sl, j + 1), *host_done, j);
+          if (w == ma::SlotWait::kSlotHere) { state = 1; break; }
+          if (w == ma::SlotWait::kStoppedBefore) { state = 2; break; }
           if (yielding || (spins & 63u) == 63u) {
             const auto waited = std::chrono::steady_clock::now() - t_wait;
             if (waited > std::chrono::microseconds(ctx->cfg_planner_timeout_us)) { state = 3; break; }
@@ -4278,7 +4280,8 @@ static int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16],
           ctx->lists_on = false;
           slots_live = false;
           sync_mode = true;
-        } else if (state == 2 || const_cast<const DevState&>(sl.s).done) {
+        } else if (ma::stops_before_batch(state == 2 ? ma::SlotWait::kStoppedBefore : ma::SlotWait::kSlotHere,
+                                          const_cast<const DevState&>(sl.s).done != 0)) {
           stop_here = true;
         } else if (ctx->lists_on) {
           planner.plan_batch(k, T_of, plan);
@@ -4295,8 +4298,7 @@ static int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16],
       // after a planner timeout: the same rule as above — stop before this batch iff the loop stopped at an iteration
       // <= j — decided with the stream drained, so that a sharded rank still stops where its peers stop
       HIPCHK(hipStreamSynchronize(ctx->stream));
-      const int hd = *host_done;
-      if (hd != 0 && hd - 1 <= k - kPlan - 1 && !timek) break;
+      if (ma::iterations_enqueued(params->max_iter, *host_done, true) <= k && !timek) break;
     }
     const int kind = ctx->lists_on ? plan[k % kPlan] : 0;
     ctx->list_plan.push_back((uint8_t)kind);

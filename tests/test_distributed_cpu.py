@@ -15,6 +15,13 @@ import torch.multiprocessing as mp
 from conftest import PKG, ROOT
 
 
+@pytest.fixture(scope="module")
+def shim_built():
+    """tests/_build/list_planner_shim.so (csrc/list_planner.h behind a C interface), built by tests/test_list_planner.py's fixture code."""
+    import test_list_planner as tlp
+    return tlp.build_shim()
+
+
 class OracleShardEngine:
     """CPU stand-in with the HipShardEngine interface."""
 
@@ -121,6 +128,41 @@ def test_world2_rccl_bootstrap_id_travels_and_failures_reach_every_rank(tmp_path
         assert (int(z["w"]), int(z["r"]), int(z["n"]), int(z["k"])) == (2, rank, 2, rank)
         assert np.array_equal(z["uid"], np.arange(128, dtype=np.uint8))      # rank 0's id reached this rank
         assert "librccl could not be loaded" in str(z["raised"]) and not bool(z["bad_joined"])
+
+
+def _stop_worker(rank, world, port, out_dir):
+    """Two hosts of a sharded loop with a convergence test: each decides from ITS OWN looks at the pinned words where to
+    stop enqueueing, and issues one all-reduce per iteration it enqueues — as ma_icp_sharded does.  Unequal counts would
+    leave one rank waiting in a collective (the process group's timeout turns that into a failure here)."""
+    for p in (PKG, ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    import ctypes as C
+    import test_list_planner as tlp
+    lib = C.CDLL(os.path.join(ROOT, "tests", "_build", "list_planner_shim.so"))
+    for f in (lib.slot_wait_state, lib.stops_before_batch, lib.iterations_enqueued):
+        f.restype = C.c_int
+    rng = np.random.default_rng(100 + rank)              # every rank looks at different moments
+    counts = []
+    for max_iter, stop in ((40, 9), (40, 10), (40, 11), (40, 12), (40, 31), (40, None), (17, 3), (60, 58)):
+        n = tlp.simulate_host(lib, max_iter, stop, rng)
+        acc = torch.ones(17, dtype=torch.float64)
+        for _ in range(n):                               # the collective of every enqueued iteration
+            dist.all_reduce(acc)
+            acc /= world
+        counts.append(n)
+    np.savez(os.path.join(out_dir, f"stop{rank}.npz"), counts=np.array(counts))
+    dist.destroy_process_group()
+
+
+def test_world2_ranks_of_a_stopped_sharded_loop_issue_the_same_collectives(tmp_path, shim_built):
+    world = 2
+    mp.spawn(_stop_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    c0, c1 = (np.load(tmp_path / f"stop{r}.npz")["counts"] for r in range(world))
+    assert np.array_equal(c0, c1), (c0, c1)
+    assert list(c0) == [16, 16, 16, 20, 36, 40, 8, 60]
 
 
 def _free_port():
