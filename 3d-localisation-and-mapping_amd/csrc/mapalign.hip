@@ -26,7 +26,9 @@
 //                      [x0,x1] of row (y,z) are gold[cstart[row+x0] .. cstart[row+x1+1])
 //   occ_dist u8[ncells] level 0: Chebyshev distance (cells, capped) to the nearest occupied cell
 //   src    float4[N]   brick-major sorted in its own frame (256 consecutive points = a compact
-//                      patch), .w = per-point weight; prev u32[N] = last iteration's match
+//                      patch), .w = per-point weight; prev u32[N] = the match of the last SEARCH launch
+//   lists  ListPlanes  per source slot: 8 gold positions in two planes of 4 + the radius the list is complete for
+//                      (list launches: DESIGN.md 5)
 //   partials f64[19][G] one per 256-point chunk, state (R,t,flags), trace f64[iters][20],
 //   wg_cost u32[G] + seg_order u32[<=512]  workgroup durations and the longest-first schedule
 #include <hip/hip_runtime.h>
@@ -70,21 +72,20 @@ constexpr uint32_t kHoleBitsEarly = 0x7FC00000u;   // = kHoleBits (k_unproject):
 // Candidate lists (k_nn_accum, "list launches"): once the transform moves the cloud by less than a fraction of
 // a cell per iteration, a search launch also WRITES, per query, every gold point within (match distance + skin) of
 // the query's position; while a query has moved less than skin / 2 since then, its nearest neighbour is provably
-// in that list (triangle inequality, checked per query), and the launch reads 8 indices instead of searching.
+// in that list (triangle inequality, checked per query), and the launch reads up to 8 gold positions instead of searching.
 constexpr int kListLen = 8;
-// Storage (round 4), every plane indexed by source slot.  Entries 0 and 1 are kept INLINE — the gold point's
-// coordinates and its position, 16 bytes each, one plane per entry so that a wavefront's read of either is one
-// contiguous kilobyte — so that the common list (<= 2 entries) costs a list launch no gather at all; entries 2-5
-// (plane b0, four positions per slot) and 6-7 (plane b1, two per slot) are positions that the few longer lists gather
-// through.  An unused inline entry is (inf, inf, inf, none): its distance never passes the gate.
+// Storage, every plane indexed by source slot.  The build in force (MA_LIST_INLINE = 0) keeps POSITIONS only: plane b0
+// holds entries 0-3 (16 bytes per query, read by every list launch), plane b1 entries 4-7 (read by the few queries with
+// more than four), plane rad the radius the list is complete for (its low 4 bits: the number of entries).
+// MA_LIST_INLINE = 2 (A/B, csrc/Makefile `variant`) is the form VERDICT r03 asked for: entries 0 and 1 INLINE — the gold
+// point's coordinates and its position, 16 bytes each, planes a0 / a1 — so that the common list (<= 2 entries) costs no
+// gather; b0 then holds entries 2-5, b1 entries 6-7; an unused inline entry is (inf, inf, inf, none).  Measured SLOWER,
+// 25.7 against 22.8 us per list launch: 16 more streamed bytes per query cost more than the gathers they save, which hit
+// the XCD's L2 (profiles/r04_variants_ab.txt).
 #ifndef MA_LIST_INLINE
 #define MA_LIST_INLINE 0
 #endif
-
-
-constexpr int kListInline = MA_LIST_INLINE;     // 0 or 2 entries with inline coordinates (A/B: csrc/Makefile `variant`; 2 measured
-                                                // SLOWER, 25.7 against 22.8 us per list launch: 16 more streamed bytes per query cost more
-                                                // than the gathers they save, which hit the XCD's L2 — profiles/r04_variants_ab.txt)
+constexpr int kListInline = MA_LIST_INLINE;
 static_assert(kListInline == 0 || kListInline == 2, "inline entries");
 struct ListPlanes {
   float4* __restrict__ a0;
@@ -2428,6 +2429,7 @@ struct ma_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t evu0 = nullptr, evu1 = nullptr;   // around the last k_unproject launch (its count — and time — may be settled after other work has re-used ev0 / ev1)
   std::string err;
 
   // gold map
@@ -2984,7 +2986,7 @@ void fill_stats(const DevState& s, double gpu_ms, ma_stats* st) {
 }
 
 // Depth frame already in ctx->depth_in -> one slot per pixel at `out` (k_unproject: points and holes).
-// ev0/ev1 bracket the device work.  The kernel writes its per-workgroup counts of valid pixels straight into pinned
+// evu0/evu1 bracket the device work.  The kernel writes its per-workgroup counts of valid pixels straight into pinned
 // host memory (the third mailbox block), so the NUMBER of valid pixels costs no device-to-host copy — and no
 // synchronisation at all unless somebody asks for it: total != nullptr waits and adds the counts up; with nullptr the
 // call only enqueues, and finish_unproject() settles the count when it is first needed (round 3: a pageable copy
@@ -2994,7 +2996,7 @@ int finish_unproject(ma_ctx* ctx) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->unproj_pending = false;
   float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  HIPCHK(hipEventElapsedTime(&ms, ctx->evu0, ctx->evu1));
   ctx->last_op_ms = ms;
   const uint32_t* h = reinterpret_cast<const uint32_t*>(ctx->mailbox + 2 * kMailBytes);
   uint64_t t = 0;
@@ -3020,7 +3022,7 @@ int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinho
     HIPCHK(ctx->unproj_cnt.ensure((size_t)nb * 4));
     counts = ctx->unproj_cnt.as<uint32_t>();
   }
-  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->evu0, ctx->stream));
   if (dtype == 0)
     hipLaunchKernelGGL(k_unproject<float>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(), width, npx, cam,
                        counts, out);
@@ -3028,13 +3030,13 @@ int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinho
     hipLaunchKernelGGL(k_unproject<uint16_t>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<uint16_t>(), width, npx,
                        cam, counts, out);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->evu1, ctx->stream));
   if (!pinned) {
     std::vector<uint32_t> h(nb);
     HIPCHK(hipMemcpyAsync(h.data(), ctx->unproj_cnt.p, (size_t)nb * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    HIPCHK(hipEventElapsedTime(&ms, ctx->evu0, ctx->evu1));
     ctx->last_op_ms = ms;
     uint64_t t = 0;
     for (uint32_t c : h) t += c;
@@ -3244,6 +3246,8 @@ int ma_create(int device, ma_ctx** out) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->evu0) (void)hipEventDestroy(ctx->evu0);
+    if (ctx->evu1) (void)hipEventDestroy(ctx->evu1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->host_done) (void)hipHostFree(ctx->host_done);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
@@ -3256,6 +3260,8 @@ int ma_create(int device, ma_ctx** out) {
   if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->evu0)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->evu1)) != hipSuccess) return bail("hipEventCreate", e);
   static_assert(sizeof(DevState) <= 256, "pinned state slots are 256 bytes apart");
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_done), 1280 + kMaxSlots * sizeof(StateSlot), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
   std::memset(ctx->host_done, 0, 1024);
@@ -3288,6 +3294,8 @@ int ma_destroy(ma_ctx* ctx) {
   for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->evu0) (void)hipEventDestroy(ctx->evu0);
+  if (ctx->evu1) (void)hipEventDestroy(ctx->evu1);
   if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;

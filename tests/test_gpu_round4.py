@@ -418,6 +418,8 @@ def test_depth_source_without_the_count_only_enqueues_and_gives_the_same_cloud(e
     assert engine.set_source_from_depth(depth, K, T, 1000.0, count=False) is None
     res = engine.icp(30, 0.0, 0.10, with_trace=True)                # straight behind the unprojection, no count taken yet
     assert np.array_equal(res.T, ref.T) and np.array_equal(res.trace[:, :18], ref.trace[:, :18])
+    t_unproject = engine.last_device_ms()                           # the unprojection's own time, not the loop's that ran since
+    assert 0.0 < t_unproject < 0.5 * res.gpu_ms
     assert engine.n_source == n                                     # settled on demand
     assert np.array_equal(engine.get_source(), pts)
     engine.set_source_from_depth(depth, K, T, 1000.0, count=False)
