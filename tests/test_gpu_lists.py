@@ -143,3 +143,41 @@ def test_a_loop_that_stops_degenerate_does_not_leave_the_planner_waiting(engine,
         engine.icp(40, 0.0, 0.10)
     engine.set_source(comp)                                         # and the context works on
     assert engine.icp(40, 0.0, 0.10).iterations == 40
+
+
+def test_list_configuration_is_per_context_and_changes_no_bit(engine, monkeypatch):
+    """ma_list_config: lists on / off, the skin divisor and the reads a write must be followed by are settings of a
+    context (the environment only supplies the defaults at ma_create and is not read afterwards); whatever they are,
+    the transform and every iteration's sums are the searching loop's."""
+    from mapalign import _lib
+    gold, comp, _, _ = syn.make_pair(11, 120_000, 100_000, angle_deg=0.4, t0=(0.02, -0.015, 0.01))
+    engine.set_pair(gold, comp)
+    ref = engine.icp(60, 0.0, 0.10, with_trace=True, lists=False)
+    assert engine.list_stats() == {"builds": 0, "uses": 0}
+    plans = set()
+    for skin_div, min_uses in ((7, 5), (5, 3), (4, 1), (12, 8), (64, 64)):
+        engine.list_config(True, skin_div, min_uses)
+        r = engine.icp(60, 0.0, 0.10, with_trace=True)
+        assert np.array_equal(r.T, ref.T) and np.array_equal(r.trace[:, :18], ref.trace[:, :18]), (skin_div, min_uses)
+        plans.add("".join("SWL"[int(v)] for v in engine.list_plan()))
+    assert len(plans) >= 3                                          # the settings do change the plan ...
+    engine.list_config(False)
+    monkeypatch.setenv("MAPALIGN_LISTS", "1")                       # ... and the environment does not, once the context exists
+    r = engine.icp(60, 0.0, 0.10, with_trace=True)
+    assert engine.list_stats() == {"builds": 0, "uses": 0} and np.array_equal(r.T, ref.T)
+    engine.list_config(True)
+    monkeypatch.setenv("MAPALIGN_LISTS", "0")
+    engine.icp(60, 0.0, 0.10)
+    assert engine.list_stats()["uses"] >= 10
+    with mapalign.MapAligner(0) as off:                             # a context CREATED with MAPALIGN_LISTS=0 starts without lists
+        off.set_pair(gold, comp)
+        r = off.icp(60, 0.0, 0.10)
+        assert off.list_stats() == {"builds": 0, "uses": 0} and np.array_equal(r.T, ref.T)
+        off.list_config(True)
+        off.icp(60, 0.0, 0.10)
+        assert off.list_stats()["uses"] >= 10
+    for bad in ((True, 1.5, None), (True, 100.0, None), (True, None, 65), (True, None, -1)):
+        with pytest.raises(mapalign.MapAlignError) as e:
+            engine.list_config(*bad)
+        assert e.value.status == _lib.MA_ERR_INVALID
+    engine.list_config(True, 7, 5)
