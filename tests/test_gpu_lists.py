@@ -165,7 +165,7 @@ def test_list_configuration_is_per_context_and_changes_no_bit(engine, monkeypatc
     monkeypatch.setenv("MAPALIGN_LISTS", "1")                       # ... and the environment does not, once the context exists
     r = engine.icp(60, 0.0, 0.10, with_trace=True)
     assert engine.list_stats() == {"builds": 0, "uses": 0} and np.array_equal(r.T, ref.T)
-    engine.list_config(True)
+    engine.list_config(True, 7, 5)                                  # (None keeps a value: the sweep above ended on 64 / 64)
     monkeypatch.setenv("MAPALIGN_LISTS", "0")
     engine.icp(60, 0.0, 0.10)
     assert engine.list_stats()["uses"] >= 10
