@@ -45,7 +45,7 @@ def test_config5_2m_resampled_pair_vs_oracle(engine, seed):
     # this seed's share of what is left (seed 0 leaves half to seed 1; 60 s stay for the tests after these two)
     share = max(0.0, suite_seconds_left() - 60.0) / (2 - seed)
     t_start = time.perf_counter()
-    k, iters = 0, 30
+    k, iters = 0, 24
     while k < iters:
         acc, _, _, R, t, ok = orc.icp_step(index, comp, R, t, 0.10)
         assert ok
@@ -54,7 +54,7 @@ def test_config5_2m_resampled_pair_vs_oracle(engine, seed):
         k += 1
         if k == 3:
             per_it = (time.perf_counter() - t_start) / 3
-            iters = int(min(30, max(10, share / per_it)))
+            iters = int(min(24, max(10, share / per_it)))
     res = engine.icp(iters, 0.0, 0.10, with_trace=True)
     assert res.iterations == iters
     eR, et = orc.rt_error(res.R, res.t, R, t)
