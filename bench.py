@@ -481,7 +481,7 @@ def config_concurrent(gold, comp, device, R0):
     return out
 
 
-def config_c5(eng, seed=0, cpu_iters=12):
+def config_c5(eng, seed=0, cpu_iters=8):
     """The per-GPU workload of configs[4] (8 pairs x 2M points, one pair per GPU): one 2M pair here — timed over its
     50 iterations, checked against the ground truth, and compared with the CPU oracle after the SAME `cpu_iters`
     iterations of this independently resampled pair (a bounded sample: an oracle iteration costs 4-9 s at 2M points)."""
@@ -805,7 +805,7 @@ def main():
                 cpu, parity = cpu_baseline_and_parity(eng, gold, comp, args.cpu_iters)
             if not args.no_extra_configs and args.points == N_POINTS:
                 for name, fn in (("c3", lambda: config_c3(eng, gold)), ("c4", lambda: config_c4(eng, local_rank)),
-                                 ("c5_per_gpu", lambda: config_c5(eng, cpu_iters=0 if args.no_cpu_baseline else 12)),
+                                 ("c5_per_gpu", lambda: config_c5(eng, cpu_iters=0 if args.no_cpu_baseline else 8)),
                                  ("concurrent_pairs", lambda: config_concurrent(gold, comp, local_rank, R0))):
                     try:
                         extra[name] = fn()
