@@ -4201,7 +4201,11 @@ static int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16],
   // tol = 0 without lists (and MA_FLAG_TIME_KERNELS runs) take part in neither.
   constexpr int kBatch = 8;
   const bool early_exit = params->tol > 0.0 && !timek;
-  const bool lists_wanted = ctx->src_rs > 0.f && lists_allowed && long_run;
+  // (lists stop paying where the clouds outgrow the caches: at 16M points a list launch costs what a converged search
+  // launch costs — its gathers miss — and the two list-writing launches are pure loss: 55.0 against 53.2 ms per 50
+  // iterations; 8M gains 1 %, 1M-4M 3-4 %.  profiles/r04_variants_ab.txt, call 24)
+  constexpr uint32_t kListMaxPoints = 12u << 20;
+  const bool lists_wanted = ctx->src_rs > 0.f && lists_allowed && long_run && ctx->n <= kListMaxPoints && ctx->m <= kListMaxPoints;
   const bool slots_used = long_run && (lists_wanted || early_exit);    // the solves mirror their state into the slots, not into host_state_out
   const bool batch_exit = early_exit && !slots_used && !sharded;
   if (batch_exit) {
