@@ -21,7 +21,7 @@ T_TOL_M = 1e-3
 # host cores, depending on the box's load), so the tests that run the oracle for many iterations ask how much time is
 # left instead of guessing from a fixed per-iteration threshold (round 3: seeds 1-2 of the headline test dropped to 20
 # iterations on a box where the suite then finished with 495 s to spare).
-SUITE_BUDGET_S = float(os.environ.get("MAPALIGN_SUITE_BUDGET_S", "740"))
+SUITE_BUDGET_S = float(os.environ.get("MAPALIGN_SUITE_BUDGET_S", "720"))
 _suite_t0 = [None]
 
 

@@ -36,9 +36,9 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
     <= 1 mm on t for identical inputs" — the 1M-point pair, all 50 iterations, tol = 0, gate
     0.10 m.  The oracle runs its 50 KD-tree iterations on the host cores
     (1.2-4 s each on the 256-core GPU boxes, depending on their load).  Seed 0 always runs all 50.  Seeds 1 and 2 run
-    all 50 whenever the suite's wall-clock budget (conftest.suite_seconds_left) has room for them, and never fewer
-    than 34 — the list launches of this pair begin at iteration 29, so every seed compares them with the oracle
-    (still at equal iteration count)."""
+    all 50 whenever the suite's wall-clock budget (conftest.suite_seconds_left) has room for them; seed 1 never fewer
+    than 34 — the list launches of this pair begin at iteration 29, so they are compared with the oracle on two seeds at
+    least — and seed 2 never fewer than 20 (still at equal iteration count)."""
     from conftest import suite_seconds_left
     gold, comp, R0, t0 = syn.make_pair(seed, 1_000_000)
     engine.set_gold(gold)
@@ -57,9 +57,10 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
         k += 1
         if seed > 0 and k == 5:
             per_it = (time.perf_counter() - t_start) / 5
-            # what is left for this seed: the budget minus the reserve of the later tests, minus (for seed 1) seed 2's 34
-            room = suite_seconds_left() - RESERVE_AFTER_HEADLINE_S - (34 * per_it if seed == 1 else 0.0)
-            iters = int(min(50, max(34, k + room / per_it)))
+            # what is left for this seed: the budget minus the reserve of the later tests, minus (for seed 1) seed 2's floor
+            floor = 34 if seed == 1 else 20        # seed 1 always reaches the list launches; seed 2 gives way first on a slow host
+            room = suite_seconds_left() - RESERVE_AFTER_HEADLINE_S - (20 * per_it if seed == 1 else 0.0)
+            iters = int(min(50, max(floor, k + room / per_it)))
     res = engine.icp(iters, 0.0, 0.10, with_trace=True)
     assert res.iterations == iters
     eR, et = orc.rt_error(res.R, res.t, R, t)
