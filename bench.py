@@ -142,11 +142,11 @@ def algorithmic_bytes(trace, n_src, n_blocks, plan=None, kind=0):
     gold point examined (coordinates only, the remembered match included: SURVEY.md §8d's 12*C)
     + 12 B per matched point (re-read of the winner) + 19 fp64 partials per workgroup; what a
     list-writing launch (kind 1) stores is left out.
-    A list launch (kind 2: DESIGN.md 5 "List launches", round-4 layout) is a stream: 16 B source
-    point + 2 x 16 B inline list entries + 4 B radius = 52 B per point, every byte coalesced; no
-    remembered match is read or written and the winner is not re-read (its coordinates travel
-    with the minimum).  Only lists of more than two entries read 4-byte positions (the kernel's
-    word counter in these launches) and gather 12 B through each: 16 B per counted word.
+    A list launch (kind 2: DESIGN.md 5 "List launches", round-4 layout: positions only) reads 16 B source
+    point + 4 B radius = 20 B per point, and per counted list word (4 per point, 8 where the list holds
+    more than four entries: the kernel's word counter in these launches) the 4-byte position and the 12 B
+    of the gold point it names: 16 B per word.  No remembered match is read or written and the winner is
+    not re-read (its coordinates travel with the minimum).
     Averaged over the launches of ``kind`` (``plan`` = engine.list_plan(): what each iteration
     launched; None: every launch searched)."""
     if plan is not None:
@@ -157,7 +157,7 @@ def algorithmic_bytes(trace, n_src, n_blocks, plan=None, kind=0):
     words, cands, matched = trace[:, 18], trace[:, 19], trace[:, 0]
     per_launch = 24.0 * n_src + 4.0 * words + 12.0 * cands + 12.0 * matched + 19 * 8.0 * n_blocks
     if kind == 2:
-        per_launch = 52.0 * n_src + 16.0 * words + 19 * 8.0 * n_blocks
+        per_launch = 20.0 * n_src + 16.0 * words + 19 * 8.0 * n_blocks
     # SURVEY.md 8d's literal formula — 12 N (source xyz) + 4 per table word + 12 C — without the storage actually
     # used (float4 source points), the remembered-match words and the winner re-read: the strictest reading
     strict = 12.0 * n_src + 4.0 * words + 12.0 * cands
