@@ -1863,7 +1863,15 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
   s0.last_rmse = rmse;
   s0.last_W = W;
   double dR[9], dt[3];
-  if (ma::kabsch_from_acc(a, dR, dt)) {
+#if MA_WGTIMES
+  if (it < 64) g_rs[it][19][1] = wall_clock64();
+#endif
+  const int degenerate = ma::kabsch_from_acc(a, dR, dt);
+#if MA_WGTIMES
+  asm volatile("" :: "v"(dR[0]), "v"(dt[0]));
+  if (it < 64) g_rs[it][19][2] = wall_clock64();
+#endif
+  if (degenerate) {
     s0.degenerate = 1;
     s0.done = 1;
     *st = s0;
@@ -1905,6 +1913,9 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
     *const_cast<unsigned long long*>(&slot->chk) = slot_check(s0.R, s0.t, s0.iter);
     *const_cast<int*>(&slot->seq) = s0.iter;
   }
+#if MA_WGTIMES
+  if (it < 64) g_rs[it][19][3] = wall_clock64();
+#endif
 }
 
 // The solve alone (sharded-source stepping: the 17 sums come back from the all-reduce).

@@ -7,7 +7,7 @@ the last search workgroup of iteration k and the first one of iteration k+1 goes
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["MAPALIGN_LIB"] = os.path.join(ROOT, "3d-localisation-and-mapping_amd", "lib", "libmapalign_wgt.so")
+os.environ.setdefault("MAPALIGN_LIB", os.path.join(ROOT, "3d-localisation-and-mapping_amd", "lib", "libmapalign_wgt.so"))
 sys.path.insert(0, os.path.join(ROOT, "3d-localisation-and-mapping_amd"))
 import mapalign
 from mapalign import synthetic as syn, _lib
@@ -40,10 +40,11 @@ for it in range(2, 49):
     row = [(sums[:, 0].min() - end_search) * us, (sums[:, 0].max() - end_search) * us, (sums[:, 1].max() - end_search) * us,
            (sums[:, 2].max() - end_search) * us, (sums[last, 3] - end_search) * us, (sums[last, 4] - end_search) * us,
            (nxt[:, 0].min() - end_search) * us, (np.percentile(nxt[:, 0], 50) - end_search) * us,
-           (r[19, 4] - end_search) * us]
+           (r[19, 4] - end_search) * us, (r[19, 1] - end_search) * us, (r[19, 2] - end_search) * us, (r[19, 3] - end_search) * us]
     rows.append(row)
 rows = np.array(rows)
 names = ["first reduce wg enters", "last reduce wg enters", "last sum stored", "last ticket back", "19 sums read", "solve done (state stored)",
-         "first search wg of next iteration starts", "median search wg of next iteration starts", "rank workgroup done"]
+         "first search wg of next iteration starts", "median search wg of next iteration starts", "rank workgroup done",
+         "solve: trace row written, Kabsch step begins", "solve: Kabsch step done", "solve: state, mirror and slot stores issued"]
 for n, col in zip(names, rows.T):
     print(f"  {n:45s} median {np.median(col):6.2f}   p10 {np.percentile(col, 10):6.2f}   p90 {np.percentile(col, 90):6.2f}")
