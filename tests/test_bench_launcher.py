@@ -68,3 +68,29 @@ def test_guarded_leg_returns_its_result_or_gives_up_after_the_timeout():
     t0 = _time.perf_counter()
     res, timed_out = bench.run_guarded(lambda: _time.sleep(30), 0.3)
     assert timed_out and "no answer within" in res["error"] and _time.perf_counter() - t0 < 5.0
+
+
+def test_algorithmic_bytes_follow_the_layouts_the_kernels_read():
+    """bench.py::algorithmic_bytes, the numerator of roofline.achieved: per launch kind, the bytes DESIGN.md 5 counts —
+    and for list launches the POSITIONS-ONLY layout the library is built with (MA_LIST_INLINE 0): 16 B point + 4 B
+    radius per query, 4 B position + 12 B gold point per list word.  (Round 4 quoted 52 B per query for a while: the
+    inline layout that had been measured and dropped.)"""
+    import re
+
+    import numpy as np
+
+    src = open(os.path.join(ROOT, "3d-localisation-and-mapping_amd", "csrc", "mapalign.hip")).read()
+    assert re.search(r"#define MA_LIST_INLINE 0\b", src), "the list layout changed: revisit bench.algorithmic_bytes(kind=2)"
+    n, blocks = 1000, 4
+    trace = np.zeros((3, 20))
+    trace[:, 0] = [900, 950, 1000]          # matched
+    trace[:, 18] = [15000, 4000, 4200]      # table / list words
+    trace[:, 19] = [20000, 2300, 2400]      # candidates
+    plan = [0, 2, 2]
+    b_search, words_pp, cands_pp, b_strict = bench.algorithmic_bytes(trace, n, blocks, plan, 0)
+    assert b_search == 24 * n + 4 * 15000 + 12 * 20000 + 12 * 900 + 152 * blocks
+    assert b_strict == 12 * n + 4 * 15000 + 12 * 20000
+    assert (words_pp, cands_pp) == (15.0, 20.0)
+    b_list, words_pp, _, _ = bench.algorithmic_bytes(trace, n, blocks, plan, 2)
+    assert b_list == 20 * n + 16 * 4100 + 152 * blocks and words_pp == 4.1
+    assert bench.algorithmic_bytes(trace, n, blocks, plan, 1) == (0.0, 0.0, 0.0, 0.0)      # no launch of that kind
