@@ -1,12 +1,14 @@
 """One-off fuzz of the candidate lists (DESIGN.md 5 "List launches"): random shapes, sizes, gates (down to ones that leave most
-points unmatched, up to none), weights, cell edges and starts; 40-64 iterations with lists on and with MAPALIGN_LISTS=0 must give
-the same transform and the same 17 sums in every iteration, bit for bit.  (GPU box.)"""
+points unmatched, up to none), weights, cell edges and starts; 40-64 iterations with lists on and with every launch searching
+(MA_FLAG_NO_LISTS) must give the same transform and the same 17 sums in every iteration, bit for bit.  The 200 cases of seed 31
+are tests/test_gpu_round4.py::test_lists_on_and_off_bitwise_over_200_random_cases; this tool runs more of them.
+    python tools/fuzz_lists.py [cases] [seed]      (GPU box)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "3d-localisation-and-mapping_amd")); sys.path.insert(0, ROOT)
 import numpy as np, mapalign
 from mapalign import synthetic as syn
-rng = np.random.default_rng(31)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
 eng = mapalign.MapAligner(0)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 bad = used = done = degenerate = 0
@@ -39,8 +41,7 @@ for case in range(cases):
     try:
         eng.set_gold(gold, cell); eng.set_source(comp, w)
         for mode in ("1", "0"):
-            os.environ["MAPALIGN_LISTS"] = mode
-            r = eng.icp(iters, 0.0, gate, with_trace=True)
+            r = eng.icp(iters, 0.0, gate, with_trace=True, lists=mode == "1")
             out[mode] = (r.T.copy(), r.trace.copy(), eng.list_stats(), "".join("SWL"[int(v)] for v in eng.list_plan()))
     except mapalign.MapAlignError:
         degenerate += 1
