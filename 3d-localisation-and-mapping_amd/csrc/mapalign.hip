@@ -1846,18 +1846,27 @@ __global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ 
 // a6 + a7 for one thread: Kabsch step from the 19 reduced values, transform composition,
 // convergence test, trace row.  (Kept out of the search kernel: its fp64 Jacobi code needs
 // ~110 VGPRs and would halve the occupancy of the search.)
+// The solve is ONE lane, and a lone wavefront gets one vector instruction through every 7.5-9.5 cycles whatever it
+// depends on (profiles/r04_valu_issue_rate.txt, W = 1): the solve's time is its instruction count.  Hence the quaternion
+// form of the Kabsch step (kabsch.h: ~200 instructions for the SVD's ~500), the rmse from the hardware seeds (an IEEE
+// divide and square root are ~55 instructions, these 9, to an ulp or two), and in k_reduce_solve the 19 summing workgroups
+// writing their own sums into the trace row (SUMS_IN_ROW false) instead of this lane writing all of them.
+template <bool SUMS_IN_ROW = true>
 __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0, DevState* __restrict__ st,
                                            double* __restrict__ trace, const int trace_cap, const double tol,
                                            int* __restrict__ host_done, DevState* __restrict__ host_mirror = nullptr,
                                            StateSlot* __restrict__ slot = nullptr) {
   const int it = s0.iter;
   const double W = a[0];
-  const double rmse = W > 0.0 ? sqrt(a[16] / W) : NAN;
+  const double rmse = W > 0.0 ? (a[16] > 0.0 ? ma::sqrt_f64(a[16] * ma::inv_f64(W)) : 0.0) : NAN;
   if (it < trace_cap) {
     double* row = trace + (size_t)it * MA_TRACE_STRIDE;
+    if (SUMS_IN_ROW) {
 #pragma unroll
-    for (int k = 0; k < ma::kAccLen; ++k) row[k] = a[k];
-    row[17] = rmse; row[18] = a[17]; row[19] = a[18];
+      for (int k = 0; k < ma::kAccLen; ++k) row[k] = a[k];
+      row[18] = a[17]; row[19] = a[18];
+    }
+    row[17] = rmse;
   }
   s0.iter = it + 1;
   s0.last_rmse = rmse;
@@ -1966,6 +1975,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
     return;
   }
   const int k = blockIdx.x;
+  const int it_now = st->iter;
   DevState s0;
   if (threadIdx.x == 0) s0 = *st;   // whoever arrives last will need it: read it now, not after the hand-off
   const double* __restrict__ p = partials + (size_t)k * G;
@@ -1986,8 +1996,11 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   if ((threadIdx.x & (kWave - 1)) == kSumLane) red[threadIdx.x / kWave] = v;
   __syncthreads();
   if (threadIdx.x != 0) return;
-  __hip_atomic_store(&acc_out[k], ((red[0] + red[1]) + red[2]) + red[3], __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+  const double sum = ((red[0] + red[1]) + red[2]) + red[3];
+  __hip_atomic_store(&acc_out[k], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // this accumulator's entry of the iteration's trace row (columns 0-16 the sums, 17 the rmse — the solve's —, 18 and 19
+  // the two work counters)
+  if (it_now < trace_cap) trace[(size_t)it_now * MA_TRACE_STRIDE + (k < ma::kAccLen ? k : k + 1)] = sum;
 #if MA_WGTIMES
   if (dbg_it < 64) g_rs[dbg_it][k][1] = wall_clock64();
 #endif
@@ -2005,7 +2018,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   asm volatile("" :: "v"(a[0]), "v"(a[18]));
   if (dbg_it < 64) g_rs[dbg_it][k][3] = wall_clock64();
 #endif
-  solve_step(a, s0, st, trace, trace_cap, tol, host_done, host_mirror, slot);
+  solve_step<false>(a, s0, st, trace, trace_cap, tol, host_done, host_mirror, slot);
 #if MA_WGTIMES
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (dbg_it < 64) g_rs[dbg_it][k][4] = wall_clock64();

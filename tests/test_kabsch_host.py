@@ -14,6 +14,11 @@ from oracle import icp_oracle as orc
 SHIM = r"""
 #include "kabsch.h"
 extern "C" int host_kabsch(const double* acc, double* dR, double* dt) { return ma::kabsch_from_acc(acc, dR, dt); }
+extern "C" int host_qcp(const double* H, double l0, double* dR) {     // H row-major, H_ab = sum w p_a q_b
+  ma::Col3 g0{H[0], H[3], H[6]}, g1{H[1], H[4], H[7]}, g2{H[2], H[5], H[8]};
+  const double frob2 = ma::dot3(g0, g0) + ma::dot3(g1, g1) + ma::dot3(g2, g2);
+  return ma::rotation_qcp(g0, g1, g2, frob2, l0, dR) ? 1 : 0;
+}
 extern "C" void host_svd3(const double* A, double* US, double* V, double* sig) {
   for (int i = 0; i < 9; ++i) US[i] = A[i];
   ma::jacobi_svd3(US, V, sig);
@@ -36,6 +41,8 @@ def shim():
     lib.host_kabsch.argtypes = [dp, dp, dp]
     lib.host_kabsch.restype = C.c_int
     lib.host_svd3.argtypes = [dp, dp, dp, dp]
+    lib.host_qcp.argtypes = [dp, C.c_double, dp]
+    lib.host_qcp.restype = C.c_int
     return lib
 
 
@@ -61,6 +68,88 @@ def test_svd_matches_numpy(shim):
         assert np.allclose(US @ V.T, A, rtol=1e-12, atol=1e-12 * np.abs(A).max())
         assert np.allclose(V.T @ V, np.eye(3), atol=1e-13)
         assert np.allclose(np.sort(sig)[::-1], np.linalg.svd(A, compute_uv=False), rtol=1e-11, atol=1e-13 * sig.max())
+
+
+def _with_singular_values(rng, sig, det_sign=1.0):
+    U, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    V, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    A = U @ np.diag(sig) @ V.T
+    return A if np.sign(np.linalg.det(A)) == det_sign else -A
+
+
+def _kabsch_svd(H):
+    U, _, Vt = np.linalg.svd(H)
+    d = np.sign(np.linalg.det(Vt.T @ U.T))
+    return Vt.T @ np.diag([1.0, 1.0, d]) @ U.T
+
+
+def test_quaternion_path_equals_the_svd_where_it_accepts_and_declines_elsewhere(shim):
+    """kabsch.h::rotation_qcp — the solve's fast path — against V diag(1, 1, det) U^T from numpy's SVD over 20 000 random
+    problems: any scale, anisotropies up to 1e4 per axis, noise from 1e-5 to 0.1, rotations up to half a turn.  Where
+    it accepts, the rotation is the SVD's to 1e-10 (2e-14 at the median) and proper and orthogonal to rounding; it
+    accepts every well-conditioned small-angle problem (what an ICP iteration is); half turns, thin clouds, mirrored
+    H are declined — the caller then takes the SVD; a mirrored H is handled as it is."""
+    rng = np.random.default_rng(11)
+    errs, accepted_easy, easy = [], 0, 0
+    for k in range(20000):
+        n = int(rng.integers(4, 300))
+        p = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-3, 1, 3)
+        ang = rng.uniform(0, 0.3) if k % 2 else rng.uniform(0, np.pi)
+        R0 = syn.rotation_about_axis(rng.normal(size=3), ang)
+        q = p @ R0.T + rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-5, -1)
+        scale = 10.0 ** rng.uniform(-6, 6)
+        pc, qc = (p - p.mean(0)) * scale, (q - q.mean(0)) * scale
+        H = pc.T @ qc
+        l0 = 0.5 * ((pc - qc) ** 2).sum() + np.trace(H)
+        dR = np.full(9, np.nan)
+        ok = shim.host_qcp(_p(np.ascontiguousarray(H)), float(l0), _p(dR))
+        sv = np.linalg.svd(H, compute_uv=False)
+        # what an ICP iteration looks like: a small rotation, no extent much thinner than the others, a residual far
+        # below the clouds' size
+        is_easy = ang < 0.3 and sv[2] > 0.05 * sv[0] and np.linalg.det(H) > 0 and ((pc - qc @ R0) ** 2).sum() < 1e-3 * (pc ** 2).sum()
+        easy += is_easy
+        if not ok:
+            assert np.isnan(dR).all()                     # declined: nothing written
+            continue
+        accepted_easy += is_easy
+        dR = dR.reshape(3, 3)
+        errs.append(np.abs(dR - _kabsch_svd(H)).max())
+        assert np.abs(dR @ dR.T - np.eye(3)).max() < 1e-14 and np.linalg.det(dR) > 0.999999
+    errs = np.array(errs)
+    assert len(errs) > 10000 and errs.max() < 1e-10 and np.median(errs) < 1e-13, (len(errs), errs.max(), np.median(errs))
+    assert accepted_easy == easy and easy > 300, (accepted_easy, easy)
+    # collinear (rank 1: a double root), a half turn (the first adjugate column vanishes), a thin sheet: declined
+    for H in (np.outer([1.0, 2.0, 3.0], [0.5, -1.0, 2.0]), np.diag([-3.0, -2.0, 1.0]), np.diag([3.0, 1e-3, 1e-4])):
+        dR = np.full(9, np.nan)
+        l0 = float(np.abs(np.linalg.svd(H, compute_uv=False)).sum() * 1.01)
+        assert shim.host_qcp(_p(np.ascontiguousarray(H)), l0, _p(dR)) == 0, H
+    # a mirrored H (det < 0) needs no special case: the quaternion's rotation is proper by construction and is the
+    # one the SVD form reaches through its determinant correction
+    for H in (np.diag([3.0, 2.0, -1.0]), np.diag([5.0, 3.0, -2.0]) @ syn.rotation_about_axis(np.array([0.2, 0.9, -0.4]), 0.25).T):
+        dR = np.full(9, np.nan)
+        sv = np.linalg.svd(H, compute_uv=False)
+        l0 = float((sv[0] + sv[1] - sv[2]) * 1.001)      # Horn's largest eigenvalue for det H < 0, from just above
+        assert shim.host_qcp(_p(np.ascontiguousarray(H)), l0, _p(dR)) == 1
+        assert np.abs(dR.reshape(3, 3) - _kabsch_svd(H)).max() < 1e-13
+
+
+def test_kabsch_fast_and_general_path_agree_across_the_switch(shim):
+    """The solve takes the quaternion path where Horn's largest eigenvalue stands clear of the others and the Jacobi
+    SVD elsewhere; clouds whose third extent shrinks from thick to exactly planar cross the switch — the step must not
+    jump there."""
+    rng = np.random.default_rng(8)
+    R0 = syn.rotation_about_axis(np.array([0.3, -0.5, 0.8]), 0.4)
+    base = rng.normal(size=(500, 3))
+    for thick in [1.0, 0.3, 0.1, 3e-2, 1e-2, 1e-3, 1e-4, 1e-6, 1e-9, 0.0]:
+        p = base * np.array([4.0, 2.0, thick])
+        q = p @ R0.T + np.array([0.1, -0.2, 0.3])
+        w = np.ones(len(p))
+        acc = orc.accumulate(p, q, w, ((p - q) ** 2).sum(1))
+        dR, dt, rc = kabsch(shim, acc)
+        assert rc == 0
+        assert np.allclose(dR, R0, atol=1e-9), (thick, np.abs(dR - R0).max())
+        assert np.allclose(dt, [0.1, -0.2, 0.3], atol=1e-9)
+        assert np.isclose(np.linalg.det(dR), 1.0, atol=1e-12)
 
 
 def test_kabsch_matches_oracle_random(shim):
