@@ -158,9 +158,11 @@ MA_HD inline bool rotation_qcp(const Col3& g0, const Col3& g1, const Col3& g2, c
     if (!(dP > 0.0)) return false;
     step = P * inv_f64(dP);
     l -= step;
-    settled = fabs(step) <= 4e-16 * l;
+    // the error squares with every step (times at most ~150 / l where the acceptance test below holds): the step
+    // that is smaller than 1e-9 l lands within rounding of the root
+    settled = fabs(step) <= 1e-9 * l;
   }
-  if (!(fabs(step) <= 1e-12 * l)) return false;
+  if (!settled) return false;
   const double l3 = l * l * l;
   if (!(dP > 0.02 * l3)) return false;
   // first column of adj(N - l I): the cofactors of its first row

@@ -117,10 +117,16 @@ struct StateSlot {
 __host__ __device__ inline unsigned long long slot_check(const double* R, const double* t, int seq);
 // host: has the solve of iteration `want - 1` written this slot completely?  (every field read through volatile)
 inline bool slot_ready(const volatile StateSlot* sl, int want);
+// (The solving lane pays ~4 ns per instruction, 50 times per alignment: an exclusive-or per 32-bit half and word — every
+// second word with its halves swapped — instead of a 64-bit multiply and twelve 64-bit rotations.  What it has to catch is a
+// slot whose words come from two different solves, and the slots of a new run start out invalid.)
 __host__ __device__ inline unsigned long long slot_check(const double* R, const double* t, int seq) {
-  unsigned long long x = (unsigned long long)(unsigned)seq * 0x9E3779B97F4A7C15ull;
-  for (int i = 0; i < 9; ++i) { unsigned long long b; memcpy(&b, &R[i], 8); x = (x << 7 | x >> 57) ^ b; }
-  for (int i = 0; i < 3; ++i) { unsigned long long b; memcpy(&b, &t[i], 8); x = (x << 7 | x >> 57) ^ b; }
+  unsigned long long x = ((unsigned long long)(unsigned)seq << 32 | (unsigned)~seq) ^ 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < 12; ++i) {
+    unsigned long long b;
+    memcpy(&b, i < 9 ? &R[i] : &t[i - 9], 8);
+    x ^= (i & 1) ? (b << 32 | b >> 32) : b;
+  }
   return x;
 }
 inline bool slot_ready(const volatile StateSlot* sl, int want) {
