@@ -1544,12 +1544,14 @@ __device__ unsigned long long g_rs[64][20][5];   // k_reduce_solve, per iteratio
 // cost 6 VGPRs, a wavefront per SIMD and 10 % of every search launch): 0 search; 1 search and write the candidate lists;
 // 2 read the lists.  The host picks the kernel per iteration from the step sizes the solve reports (ma_icp).
 template <bool COUNT, int MODE, int LISTS>
+// (Argument order: the first 16 dwords are preloaded into scalar registers at dispatch — csrc/Makefile — so the state,
+// the source cloud, the remembered matches and the schedule, which the first instructions of a workgroup need, come
+// first; the level set, 200 bytes by value, is fetched while the first loads are in flight.)
 __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
-    const float4* __restrict__ src, const uint32_t n, const LevelSet S,
-    const uint32_t* __restrict__ perm0, const DevState* __restrict__ st, const float best2_init,
-    double* __restrict__ partials, uint32_t* __restrict__ prev, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, const Sched sched, const ListCtl* __restrict__ lc, const ListPlanes lp,
-    const int warm_hint) {
+    const DevState* __restrict__ st, const float4* __restrict__ src, const uint32_t n, const int warm_hint,
+    uint32_t* __restrict__ prev, const Sched sched, double* __restrict__ partials, const float best2_init,
+    const LevelSet S, const uint32_t* __restrict__ perm0, uint32_t* __restrict__ nn_idx,
+    float* __restrict__ nn_d2, const ListCtl* __restrict__ lc, const ListPlanes lp) {
   if (MODE == 0 && st->done) return;      // a stopped loop: nothing to do
   constexpr int lmode = MODE == 0 ? LISTS : 0;
   const unsigned long long wg_start = wall_clock64();
@@ -2947,11 +2949,10 @@ int launch_nn(ma_ctx* ctx, bool count, float best2_init, uint32_t* nn_idx, float
     lp.rad = reinterpret_cast<float*>(base + slots * 64);
   }
   auto args = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3(G), dim3(kNNBlock), 0, ctx->stream, ctx->src.as<float4>(), ctx->n,
-                       ctx->levels, ctx->perm0.as<uint32_t>(), ctx->state.as<DevState>(), best2_init,
-                       ctx->partials.as<double>(),
-                       MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, nn_idx, nn_d2, sched,
-                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, lp, warm_hint);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(kNNBlock), 0, ctx->stream, ctx->state.as<DevState>(), ctx->src.as<float4>(), ctx->n,
+                       warm_hint, MODE == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, sched,
+                       ctx->partials.as<double>(), best2_init, ctx->levels, ctx->perm0.as<uint32_t>(), nn_idx, nn_d2,
+                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, lp);
   };
   if (MODE == 0 && with_lists && list_kind == 1) {
     if (count) args(k_nn_accum<true, MODE == 0 ? 0 : 1, MODE == 0 ? 1 : 0>);
