@@ -2894,6 +2894,14 @@ int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
   return MA_OK;
 }
 
+// The state and the list control block a run starts from, handed over BY VALUE in the kernel's arguments: one tiny
+// launch instead of two small host-to-device copies in front of every loop (each copy is a DMA or blit of its own on
+// the stream, ~5 us of host time and as much on the device's).
+__global__ __launch_bounds__(kWave) void k_begin_run(const DevState s, const ListCtl c, DevState* __restrict__ st,
+                                                     ListCtl* __restrict__ lc) {
+  if (threadIdx.x == 0) { *st = s; *lc = c; }
+}
+
 int upload_state(ma_ctx* ctx, const double* T) {
   int rc = ensure_loop_buffers(ctx, std::max(ctx->trace_cap, 64));
   if (rc) return rc;
@@ -2904,7 +2912,6 @@ int upload_state(ma_ctx* ctx, const double* T) {
   // from the pinned slot (every earlier use of it has completed: each entry point that runs the loop ends with a sync)
   *ctx->host_state_in = s;
   *ctx->host_state_out = s;
-  HIPCHK(hipMemcpyAsync(ctx->state.p, ctx->host_state_in, sizeof(s), hipMemcpyHostToDevice, ctx->stream));
   // a new run starts without remembered matches: the search ignores prev[] while DevState::iter == 0 and has
   // written every entry by the end of that iteration — no 4 MB fill per run
   if (ctx->have_src) HIPCHK(ctx->prev.ensure((size_t)ctx->n * 4));
@@ -2917,7 +2924,8 @@ int upload_state(ma_ctx* ctx, const double* T) {
     for (int a = 0; a < 3; ++a) { c.blo[a] = ctx->src_lo[a]; c.bhi[a] = ctx->src_hi[a]; }
     c.slack = 1e-5f + 4e-7f * ctx->src_rs;
     *ctx->host_lc = c;
-    HIPCHK(hipMemcpyAsync(ctx->listctl.p, ctx->host_lc, sizeof(c), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_begin_run, dim3(1), dim3(kWave), 0, ctx->stream, s, c, ctx->state.as<DevState>(), ctx->listctl.as<ListCtl>());
+    HIPCHK(hipGetLastError());
   }
   *ctx->host_done = 0;   // every earlier launch has completed: each entry point that runs the loop ends with a sync
   ctx->state_valid = ctx->have_src;
