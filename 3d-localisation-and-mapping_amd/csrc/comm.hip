@@ -1,0 +1,176 @@
+// comm.hip — row e: the RCCL shim (librccl loaded with dlopen on first use), the communicator entry points and
+// ma_icp_sharded, the loop of host_loop.hip with the iteration's 17 sums all-reduced over the communicator's ranks.
+#include "ma_internal.h"
+#include <rccl/rccl.h>   // types and prototypes only: librccl is loaded with dlopen at ma_comm_init
+#include <dlfcn.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// RCCL (sharded-source mode): loaded on first use so that single-GPU users
+// need no librccl at load time, and so that a process that already holds an RCCL (PyTorch
+// bundles one under the same soname) shares it instead of getting a second copy.
+// ---------------------------------------------------------------------------------------
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;
+};
+
+RcclApi g_rccl;
+
+RcclApi* rccl_api() {
+  static const bool ok = [] {   // C++11 static initialisation is thread-safe
+    RcclApi& api = g_rccl;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (api.handle) break;
+    }
+    if (!api.handle) {
+      const char* e = dlerror();
+      api.error = std::string("cannot load librccl.so.1: ") + (e ? e : "unknown error");
+      return false;
+    }
+    auto sym = [&](const char* name) -> void* {
+      void* f = dlsym(api.handle, name);
+      if (!f && api.error.empty()) api.error = std::string("librccl lacks ") + name;
+      return f;
+    };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    return api.error.empty();
+  }();
+  return ok ? &g_rccl : nullptr;
+}
+
+#define NCCLCHK(expr)                                                                              \
+  do {                                                                                             \
+    ncclResult_t r_ = (expr);                                                                      \
+    if (r_ != ncclSuccess)                                                                         \
+      return ctx->fail(MA_ERR_COMM, std::string(#expr) + ": " + rccl_api()->GetErrorString(r_));   \
+  } while (0)
+
+}  // namespace
+
+namespace mai {
+
+void comm_destroy(ma_ctx* ctx) {
+  RcclApi* api = rccl_api();
+  if (api && ctx->comm) (void)api->CommDestroy(static_cast<ncclComm_t>(ctx->comm));
+  ctx->comm = nullptr;
+  ctx->comm_ranks = 0;
+  ctx->comm_rank = 0;
+}
+
+
+int comm_allreduce_sums(ma_ctx* ctx) {
+  NCCLCHK(rccl_api()->AllReduce(ctx->acc19.p, ctx->acc19.p, MA_ACC_LEN, ncclDouble, ncclSum, static_cast<ncclComm_t>(ctx->comm),
+                                ctx->stream));
+  return MA_OK;
+}
+
+}  // namespace mai
+
+extern "C" {
+
+// ---- RCCL: communicator bootstrap + the sharded-source loop --------------------------------
+int ma_comm_unique_id(void* id_out) {
+  return guarded(nullptr, [&]() -> int {
+  if (!id_out) return MA_ERR_INVALID;
+  RcclApi* api = rccl_api();
+  if (!api) { g_create_error = g_rccl.error; return MA_ERR_COMM; }
+  ncclUniqueId id;
+  const ncclResult_t r = api->GetUniqueId(&id);
+  if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + api->GetErrorString(r); return MA_ERR_COMM; }
+  static_assert(sizeof(ncclUniqueId) == MA_COMM_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id_out, &id, sizeof(id));
+  return MA_OK;
+  });
+}
+
+int ma_comm_init(ma_ctx* ctx, const void* id, int n_ranks, int rank) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return ctx->fail(MA_ERR_INVALID, "bad communicator arguments");
+  RcclApi* api = rccl_api();
+  if (!api) return ctx->fail(MA_ERR_COMM, g_rccl.error);
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->comm) comm_destroy(ctx);
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  ncclComm_t comm = nullptr;
+  NCCLCHK(api->CommInitRank(&comm, n_ranks, uid, rank));
+  ctx->comm = comm;
+  ctx->comm_ranks = n_ranks;
+  ctx->comm_rank = rank;
+  return MA_OK;
+  });
+}
+
+int ma_comm_destroy(ma_ctx* ctx) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  comm_destroy(ctx);
+  return MA_OK;
+  });
+}
+
+int ma_comm_allgather_f64(ma_ctx* ctx, const double* in, uint64_t count, double* out) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!ctx->comm) return ctx->fail(MA_ERR_STATE, "no communicator (ma_comm_init)");
+  if (!in || !out || count == 0 || count > (1ull << 24)) return ctx->fail(MA_ERR_INVALID, "bad gather arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t bytes = count * sizeof(double), total = bytes * (size_t)ctx->comm_ranks;
+  HIPCHK(ctx->nn_tmp.ensure(bytes + total));
+  char* base = static_cast<char*>(ctx->nn_tmp.p);
+  HIPCHK(hipMemcpyAsync(base, in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  NCCLCHK(rccl_api()->AllGather(base, base + bytes, count, ncclDouble, static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+  HIPCHK(hipMemcpyAsync(out, base + bytes, total, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+  });
+}
+
+int ma_comm_allreduce_f64(ma_ctx* ctx, double* inout, uint64_t count, int op) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!ctx->comm) return ctx->fail(MA_ERR_STATE, "no communicator (ma_comm_init)");
+  if (!inout || count == 0 || count > (1ull << 24) || op < 0 || op > 1) return ctx->fail(MA_ERR_INVALID, "bad reduce arguments");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t bytes = count * sizeof(double);
+  HIPCHK(ctx->nn_tmp.ensure(bytes));
+  HIPCHK(hipMemcpyAsync(ctx->nn_tmp.p, inout, bytes, hipMemcpyHostToDevice, ctx->stream));
+  NCCLCHK(rccl_api()->AllReduce(ctx->nn_tmp.p, ctx->nn_tmp.p, count, ncclDouble, op == 0 ? ncclSum : ncclMax,
+                                static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+  HIPCHK(hipMemcpyAsync(inout, ctx->nn_tmp.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MA_OK;
+  });
+}
+
+// One pair over the ranks of the communicator: gold map + grids replicated (every rank called
+// ma_set_gold with the same cloud), this rank's shard of the comparison cloud in ma_set_source.
+// The loop is icp_loop above — the same planner, list launches, pinned slots and early exit as ma_icp, with
+//   k_reduce19 (+ schedule ranking) -> ncclAllReduce(sum, 17 x f64, in place) -> k_solve
+// in the place of k_reduce_solve.
+int ma_icp_sharded(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16], ma_stats* stats) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  return icp_loop(ctx, params, init, T_out, stats, true);
+  });
+}
+
+}  // extern "C"

@@ -60,8 +60,9 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ITERS = 50
 GATE = 0.10
 N_POINTS = 1_000_000
-KERNEL_SOURCES = ("3d-localisation-and-mapping_amd/csrc/mapalign.hip", "3d-localisation-and-mapping_amd/csrc/host_math.h",
-                  "3d-localisation-and-mapping_amd/csrc/kabsch.h")
+# what the loop's kernels and the plan of its launches are compiled from (profiles/pmc_traffic.json is "fresh" for this hash)
+KERNEL_SOURCES = tuple("3d-localisation-and-mapping_amd/csrc/" + f for f in (
+    "ma_internal.h", "kernels_search.hip", "kernels_solve.hip", "host_loop.hip", "host_math.h", "kabsch.h", "list_planner.h"))
 
 
 def parse():

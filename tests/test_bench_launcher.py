@@ -79,7 +79,7 @@ def test_algorithmic_bytes_follow_the_layouts_the_kernels_read():
 
     import numpy as np
 
-    src = open(os.path.join(ROOT, "3d-localisation-and-mapping_amd", "csrc", "mapalign.hip")).read()
+    src = open(os.path.join(ROOT, "3d-localisation-and-mapping_amd", "csrc", "ma_internal.h")).read()
     assert re.search(r"#define MA_LIST_INLINE 0\b", src), "the list layout changed: revisit bench.algorithmic_bytes(kind=2)"
     n, blocks = 1000, 4
     trace = np.zeros((3, 20))

@@ -26,12 +26,10 @@ nreq = m.get("TCC_EA0_RDREQ_sum", 0.0)
 other = max(nreq - n32 - n64 - n128, 0.0)
 read_exact = 32 * n32 + 64 * n64 + 128 * n128 + 64 * other
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_h = hashlib.sha256()
-for rel in ("3d-localisation-and-mapping_amd/csrc/mapalign.hip", "3d-localisation-and-mapping_amd/csrc/host_math.h",
-            "3d-localisation-and-mapping_amd/csrc/kabsch.h"):       # the same files bench.py hashes
-    _h.update(open(os.path.join(ROOT, rel), "rb").read())
+sys.path.insert(0, ROOT)
+import bench as _bench      # noqa: E402  (the same hash over the same files as bench.py's line)
 res = {
-    "kernel": "k_nn_accum<false, 0, 0> (the search launches of the run)", "kernel_source_sha": _h.hexdigest()[:16], "launches_averaged": max((len(v) for v in agg.values()), default=0),
+    "kernel": "k_nn_accum<false, 0, 0> (the search launches of the run)", "kernel_source_sha": _bench.kernel_source_sha(), "launches_averaged": max((len(v) for v in agg.values()), default=0),
     "FETCH_SIZE_KB": m.get("FETCH_SIZE"), "WRITE_SIZE_KB": m.get("WRITE_SIZE"),
     "TCC_EA0_RDREQ": nreq, "RDREQ_32B": n32, "RDREQ_64B": n64, "RDREQ_128B": n128,
     "read_bytes_by_request_size": read_exact,
