@@ -73,9 +73,43 @@ void comm_destroy(ma_ctx* ctx) {
 }
 
 
+// The 17 sums are 64-bit fixed-point integers (host_math.h "Exact sums"): whatever order the collective adds them in —
+// ring, tree, any topology — the result is the same bits, and the same bits as one GPU summing the whole cloud.
 int comm_allreduce_sums(ma_ctx* ctx) {
-  NCCLCHK(rccl_api()->AllReduce(ctx->acc19.p, ctx->acc19.p, MA_ACC_LEN, ncclDouble, ncclSum, static_cast<ncclComm_t>(ctx->comm),
+  NCCLCHK(rccl_api()->AllReduce(ctx->acc19.p, ctx->acc19.p, MA_ACC_LEN, ncclInt64, ncclSum, static_cast<ncclComm_t>(ctx->comm),
                                 ctx->stream));
+  return MA_OK;
+}
+
+// What bounds a correspondence's terms must be the same on every rank, or their fixed-point scales (and with them their
+// integers) differ: the ranks gather each other's (n, wmax, rs) once per source cloud and every one installs
+// (sum n, max wmax, max rs) — the bounds of the whole cloud, which is also what a single GPU holding all of it derives.
+int comm_agree_sum_bounds(ma_ctx* ctx) {
+  if (ctx->sum_bounds_set) return MA_OK;
+  int rc;
+  if ((rc = ensure_source_box(ctx))) return rc;
+  const int g = ctx->comm_ranks;
+  double mine[3] = {(double)ctx->n, ctx->src_wmax, (double)ctx->src_rs};
+  std::vector<double> all(3 * (size_t)std::max(g, 1));
+  if (g > 1) {
+    const size_t bytes = sizeof(mine);
+    HIPCHK(ctx->nn_tmp.ensure(bytes * (size_t)(g + 1)));
+    char* base = static_cast<char*>(ctx->nn_tmp.p);
+    HIPCHK(hipMemcpyAsync(base, mine, bytes, hipMemcpyHostToDevice, ctx->stream));
+    NCCLCHK(rccl_api()->AllGather(base, base + bytes, 3, ncclDouble, static_cast<ncclComm_t>(ctx->comm), ctx->stream));
+    HIPCHK(hipMemcpyAsync(all.data(), base + bytes, bytes * (size_t)g, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  } else {
+    for (int i = 0; i < 3; ++i) all[i] = mine[i];
+  }
+  ma::SumBounds b{0.0, 0.0, 0.0};
+  for (int r = 0; r < std::max(g, 1); ++r) {
+    b.n_total += all[3 * r];
+    b.wmax = std::max(b.wmax, all[3 * r + 1]);
+    b.rs = std::max(b.rs, all[3 * r + 2]);
+  }
+  ctx->sum_bounds = b;
+  ctx->sum_bounds_set = true;
   return MA_OK;
 }
 
@@ -169,6 +203,11 @@ int ma_comm_allreduce_f64(ma_ctx* ctx, double* inout, uint64_t count, int op) {
 int ma_icp_sharded(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16], ma_stats* stats) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
+  if (ctx->comm && ctx->have_src) {
+    HIPCHK(hipSetDevice(ctx->device));
+    const int rc = comm_agree_sum_bounds(ctx);
+    if (rc) return rc;
+  }
   return icp_loop(ctx, params, init, T_out, stats, true);
   });
 }

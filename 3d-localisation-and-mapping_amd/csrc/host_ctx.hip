@@ -184,6 +184,7 @@ int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell) {
   ctx->have_src = false;
   ctx->unproj_pending = false;
   ctx->state_valid = false;
+  source_replaced(ctx);
   const uint32_t n = (uint32_t)m;
   HIPCHK(ctx->raw.ensure((size_t)n * 12));
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -214,6 +215,7 @@ int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t 
   ctx->have_src = false;
   ctx->unproj_pending = false;
   ctx->state_valid = false;
+  source_replaced(ctx);
   const uint32_t n = (uint32_t)n64;
   HIPCHK(ctx->raw.ensure((size_t)n * 12));
   HIPCHK(hipMemcpyAsync(ctx->raw.p, xyz, (size_t)n * 12, hipMemcpyDefault, ctx->stream));   // host OR device memory (include/mapalign.h)
@@ -239,6 +241,7 @@ static int set_pair_impl(ma_ctx* ctx, const void* gold_xyz, uint64_t m, float ce
   ctx->have_src = false;
   ctx->unproj_pending = false;
   ctx->state_valid = false;
+  source_replaced(ctx);
   const uint32_t mg = (uint32_t)m, n = (uint32_t)n64;
   const size_t in_bytes = f64 ? 24 : 12;
   if (!ctx->aux_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
@@ -382,6 +385,7 @@ int ma_set_gold_f64(ma_ctx* ctx, const double* xyz, uint64_t m, float cell, doub
   ctx->have_src = false;
   ctx->unproj_pending = false;
   ctx->state_valid = false;
+  source_replaced(ctx);
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   int rc = stage_f64(ctx, xyz, (uint32_t)m, true, shift_out);
   if (rc) return rc;
@@ -402,6 +406,7 @@ int ma_set_source_f64(ma_ctx* ctx, const double* xyz, const float* weights, uint
   ctx->have_src = false;
   ctx->unproj_pending = false;
   ctx->state_valid = false;
+  source_replaced(ctx);
   int rc = stage_f64(ctx, xyz, (uint32_t)n64, false, s);
   if (rc) return rc;
   return build_source_from_raw(ctx, (uint32_t)n64, weights);   // (non-finite coordinates are caught by its fp32 bounds pass)

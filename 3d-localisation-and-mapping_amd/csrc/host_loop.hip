@@ -19,10 +19,40 @@ int need_ready(ma_ctx* ctx) {
   if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set (ma_set_source)");
   return MA_OK;
 }
+int ensure_source_box(ma_ctx* ctx) {
+  if (!ctx->src_box_pending) return MA_OK;
+  // a source cloud from a depth frame: its box (stored, centred coordinates; holes skipped)
+  float lo[3], hi[3];
+  const int rc = cloud_bounds(ctx, ctx->src.as<float>(), ctx->n, lo, hi, 4, true);
+  if (rc) return rc;
+  double r2 = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    const double pad = 1e-4 + 1e-6 * (std::fabs((double)lo[a]) + std::fabs((double)hi[a]));
+    ctx->src_lo[a] = (float)((double)lo[a] - pad);
+    ctx->src_hi[a] = (float)((double)hi[a] + pad);
+    r2 += std::max((double)lo[a] * lo[a], (double)hi[a] * hi[a]);
+  }
+  ctx->src_rs = (float)(std::sqrt(r2) * 1.001 + 1e-4);
+  ctx->src_box_pending = false;
+  return MA_OK;
+}
+
+int run_sum_scale(ma_ctx* ctx, double gate, SumScale* out) {
+  ma::SumBounds b = ctx->sum_bounds;
+  if (!ctx->sum_bounds_set) {
+    if (!std::isfinite(gate)) { const int rc = ensure_source_box(ctx); if (rc) return rc; }     // only an ungated run's bounds look at rs
+    b.n_total = (double)ctx->n;
+    b.wmax = ctx->src_wmax;
+    b.rs = (double)ctx->src_rs;
+  }
+  *out = ma::sum_scale(b, ctx->gold_qb, gate, ctx->run_t0);
+  return MA_OK;
+}
+
 int ensure_loop_buffers(ma_ctx* ctx, int trace_rows) {
   HIPCHK(ctx->state.ensure(sizeof(DevState)));
   HIPCHK(ctx->partials.ensure((size_t)kNAcc * grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(double)));
-  HIPCHK(ctx->acc19.ensure(kNAcc * sizeof(double)));
+  HIPCHK(ctx->acc19.ensure(kNAcc * sizeof(long long)));
   HIPCHK(ctx->wg_cost.ensure((size_t)grid_for(std::max<uint32_t>(ctx->n, 1)) * sizeof(uint32_t)));
   HIPCHK(ctx->listctl.ensure(sizeof(ListCtl)));
   if (ctx->have_src && lists_enabled(ctx)) {      // candidate lists: sized with the other loop buffers, so that no later run allocates
@@ -50,6 +80,7 @@ int upload_state(ma_ctx* ctx, const double* T) {
   world_to_centred(T, ctx->origin, s);
   s.prev_rmse = NAN; s.last_rmse = NAN; s.last_W = 0;
   s.iter = 0; s.done = 0; s.converged = 0; s.degenerate = 0;
+  ctx->run_t0 = std::sqrt(s.t[0] * s.t[0] + s.t[1] * s.t[1] + s.t[2] * s.t[2]);      // (an ungated run's sum bounds)
   // from the pinned slot (every earlier use of it has completed: each entry point that runs the loop ends with a sync)
   *ctx->host_state_in = s;
   *ctx->host_state_out = s;
@@ -109,21 +140,10 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
   if ((rc = ensure_loop_buffers(ctx, params->max_iter))) return rc;
   const bool lists_allowed = lists_enabled(ctx) && !(params->flags & MA_FLAG_NO_LISTS);
   const bool long_run = params->max_iter > 3 * kPlan && params->max_iter <= kMaxSlots;
-  if (ctx->src_box_pending && lists_allowed && long_run) {
-    // a source cloud from a depth frame: its box (stored, centred coordinates; holes skipped) for the candidate lists
-    float lo[3], hi[3];
-    if ((rc = cloud_bounds(ctx, ctx->src.as<float>(), ctx->n, lo, hi, 4, true))) return rc;
-    double r2 = 0.0;
-    for (int a = 0; a < 3; ++a) {
-      const double pad = 1e-4 + 1e-6 * (std::fabs((double)lo[a]) + std::fabs((double)hi[a]));
-      ctx->src_lo[a] = (float)((double)lo[a] - pad);
-      ctx->src_hi[a] = (float)((double)hi[a] + pad);
-      r2 += std::max((double)lo[a] * lo[a], (double)hi[a] * hi[a]);
-    }
-    ctx->src_rs = (float)(std::sqrt(r2) * 1.001 + 1e-4);
-    ctx->src_box_pending = false;
-  }
+  if (lists_allowed && long_run && (rc = ensure_source_box(ctx))) return rc;      // (a depth frame's box: the candidate lists need it)
   if ((rc = upload_state(ctx, init))) return rc;
+  SumScale sc;
+  if ((rc = run_sum_scale(ctx, params->max_corr_dist, &sc))) return rc;
   const float best2 = open_gate2(params->max_corr_dist);
   const bool count = (params->flags & MA_FLAG_COUNT_WORK) != 0;
   const bool timek = (params->flags & MA_FLAG_TIME_KERNELS) != 0 && !sharded;
@@ -153,7 +173,11 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
   // iterations; 8M gains 1 %, 1M-4M 3-4 %.  profiles/r04_variants_ab.txt, call 24)
   constexpr uint32_t kListMaxPoints = 12u << 20;
   const bool lists_wanted = ctx->src_rs > 0.f && lists_allowed && long_run && ctx->n <= kListMaxPoints && ctx->m <= kListMaxPoints;
-  const bool slots_used = long_run && (lists_wanted || early_exit);    // the solves mirror their state into the slots, not into host_state_out
+  // the solves mirror their state into the slots, not into host_state_out.  A long SHARDED run always uses them: where a
+  // stopped loop (converged — or degenerate, which tol = 0 does not rule out) stops enqueueing must not depend on
+  // anything rank-local, and `lists_wanted` is (a shard's size, its box, its list settings): a rank that broke off at the
+  // next batch while a peer went on enqueueing all-reduces would hang the node
+  const bool slots_used = long_run && (lists_wanted || early_exit || sharded);
   const bool batch_exit = early_exit && !slots_used && !sharded;
   if (batch_exit) {
     const int need = (params->max_iter + kBatch - 1) / kBatch;
@@ -261,15 +285,15 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
     }
     const int kind = ctx->lists_on ? plan[k % kPlan] : 0;
     ctx->list_plan.push_back((uint8_t)kind);
-    if ((rc = launch_nn(ctx, 0, count, best2, nullptr, nullptr, MA_SCHED != 0, kind, k > 0 ? 1 : 0))) return rc;
+    if ((rc = launch_nn(ctx, 0, count, best2, nullptr, nullptr, sc, MA_SCHED != 0, kind, k > 0 ? 1 : 0))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
     StateSlot* slot = slots_used ? &ctx->host_slots[k] : nullptr;
     if (sharded) {
       if ((rc = launch_reduce(ctx, MA_SCHED != 0))) return rc;
       if ((rc = comm_allreduce_sums(ctx))) return rc;
-      if ((rc = launch_solve(ctx, params->tol, true, slot))) return rc;
+      if ((rc = launch_solve(ctx, params->tol, sc, true, slot))) return rc;
     } else {
-      if ((rc = launch_reduce_solve(ctx, params->tol, slot))) return rc;
+      if ((rc = launch_reduce_solve(ctx, params->tol, sc, slot))) return rc;
     }
     launched = k + 1;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 2], ctx->stream));
@@ -404,13 +428,17 @@ int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16], dou
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = ensure_levels_for(ctx, params->max_corr_dist))) return rc;
   if ((rc = upload_state(ctx, T_in))) return rc;
-  if ((rc = launch_nn(ctx, 0, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
+  SumScale sc;
+  if ((rc = run_sum_scale(ctx, params->max_corr_dist, &sc))) return rc;
+  if ((rc = launch_nn(ctx, 0, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr, sc))) return rc;
   if ((rc = launch_reduce(ctx))) return rc;
-  if ((rc = launch_solve(ctx, params->tol))) return rc;
-  double a[kNAcc];
-  HIPCHK(hipMemcpyAsync(a, ctx->acc19.p, sizeof(a), hipMemcpyDeviceToHost, ctx->stream));
+  if ((rc = launch_solve(ctx, params->tol, sc))) return rc;
+  long long ai[kNAcc];
+  HIPCHK(hipMemcpyAsync(ai, ctx->acc19.p, sizeof(ai), hipMemcpyDeviceToHost, ctx->stream));
   DevState s;
   if ((rc = fetch_state(ctx, &s))) return rc;
+  double a[kNAcc];
+  for (int k = 0; k < kNAcc; ++k) a[k] = k < MA_ACC_LEN ? ma::sum_to_double(ai[k], sc.e[ma::sum_group(k)]) : (double)ai[k];
   if (acc_out) acc_to_world(a, ctx->origin, acc_out);
   if (T_out) centred_to_world(s, ctx->origin, T_out);
   if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "no correspondence inside max_corr_dist, or rank-deficient covariance (fewer than 3 non-collinear pairs)");
@@ -432,7 +460,7 @@ int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_o
   HIPCHK(ctx->nn_idx.ensure(n * 4));
   HIPCHK(ctx->nn_d2.ensure(n * 4));
   HIPCHK(ctx->nn_tmp.ensure(n * 4));
-  if ((rc = launch_nn(ctx, 1, false, open_gate2(max_corr_dist), ctx->nn_idx.as<uint32_t>(), ctx->nn_d2.as<float>()))) return rc;
+  if ((rc = launch_nn(ctx, 1, false, open_gate2(max_corr_dist), ctx->nn_idx.as<uint32_t>(), ctx->nn_d2.as<float>(), SumScale{}))) return rc;
   const uint32_t* perm = nullptr;
   if ((rc = source_map(ctx, &perm))) return rc;
   if (idx_out) {
@@ -459,6 +487,48 @@ int ma_state_set(ma_ctx* ctx, const double T[16]) {
   });
 }
 
+int ma_sum_bounds_get(ma_ctx* ctx, double out[3]) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx || !out) return MA_ERR_INVALID;
+  if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure_source_box(ctx))) return rc;
+  out[0] = (double)ctx->n;
+  out[1] = ctx->src_wmax;
+  out[2] = (double)ctx->src_rs;
+  return MA_OK;
+  });
+}
+
+int ma_sum_bounds_set(ma_ctx* ctx, const double in[3]) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!in) { ctx->sum_bounds_set = false; return MA_OK; }
+  if (!ctx->have_src) return ctx->fail(MA_ERR_STATE, "source cloud not set (the bounds belong to a source cloud: a new one clears them)");
+  if (!(in[0] >= (double)ctx->n) || !(in[0] < 9.0e15) || !(in[1] >= ctx->src_wmax) || !std::isfinite(in[1]) ||
+      !(in[2] >= 0.0) || !std::isfinite(in[2]))
+    return ctx->fail(MA_ERR_INVALID, "sum bounds must cover this context's own (n_total >= n, wmax >= this cloud's, rs >= 0, all finite)");
+  ctx->sum_bounds = ma::SumBounds{in[0], in[1], in[2]};
+  ctx->sum_bounds_set = true;
+  return MA_OK;
+  });
+}
+
+int ma_sum_scale_get(ma_ctx* ctx, const ma_params* params, int32_t out[5]) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx || !out) return MA_ERR_INVALID;
+  int rc;
+  if ((rc = check_params(ctx, params))) return rc;
+  if ((rc = need_ready(ctx))) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  SumScale sc;
+  if ((rc = run_sum_scale(ctx, params->max_corr_dist, &sc))) return rc;
+  for (int g = 0; g < 5; ++g) out[g] = sc.e[g];
+  return MA_OK;
+  });
+}
+
 int ma_state_get(ma_ctx* ctx, double T_out[16], ma_stats* stats) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
@@ -481,11 +551,17 @@ int ma_step_accumulate(ma_ctx* ctx, const ma_params* params, void* acc_dev) {
   if ((rc = need_ready(ctx))) return rc;
   if (!ctx->state_valid) return ctx->fail(MA_ERR_STATE, "no valid stepping state: call ma_state_set after the clouds are set (a new gold map or source cloud invalidates it)");
   if (!acc_dev) return ctx->fail(MA_ERR_INVALID, "acc_dev is NULL");
+  if (!ctx->sum_bounds_set)
+    return ctx->fail(MA_ERR_STATE, "split stepping needs agreed sum bounds: ma_sum_bounds_set with the whole cloud's (n_total, wmax, rs) on every "
+                                   "shard's context (a lone context: its own ma_sum_bounds_get) — integers summed across contexts mean "
+                                   "something only if all contexts scale them alike");
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = ensure_levels_for(ctx, params->max_corr_dist))) return rc;
-  if ((rc = launch_nn(ctx, 0, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr))) return rc;
+  SumScale sc;
+  if ((rc = run_sum_scale(ctx, params->max_corr_dist, &sc))) return rc;
+  if ((rc = launch_nn(ctx, 0, (params->flags & MA_FLAG_COUNT_WORK) != 0, open_gate2(params->max_corr_dist), nullptr, nullptr, sc))) return rc;
   if ((rc = launch_reduce(ctx))) return rc;
-  HIPCHK(hipMemcpyAsync(acc_dev, ctx->acc19.p, MA_ACC_LEN * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(acc_dev, ctx->acc19.p, MA_ACC_LEN * sizeof(long long), hipMemcpyDeviceToDevice, ctx->stream));
   return MA_OK;
   });
 }
@@ -497,10 +573,16 @@ int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev) {
   if ((rc = check_params(ctx, params))) return rc;
   if (!ctx->state_valid) return ctx->fail(MA_ERR_STATE, "no valid stepping state: call ma_state_set after the clouds are set (a new gold map or source cloud invalidates it)");
   if (!acc_dev) return ctx->fail(MA_ERR_INVALID, "acc_dev is NULL");
+  if (!ctx->sum_bounds_set)
+    return ctx->fail(MA_ERR_STATE, "split stepping needs agreed sum bounds: ma_sum_bounds_set with the whole cloud's (n_total, wmax, rs) on every "
+                                   "shard's context (a lone context: its own ma_sum_bounds_get) — integers summed across contexts mean "
+                                   "something only if all contexts scale them alike");
   HIPCHK(hipSetDevice(ctx->device));
   // rows 17,18 (work counters) keep the local values of the accumulate step
-  HIPCHK(hipMemcpyAsync(ctx->acc19.p, acc_dev, MA_ACC_LEN * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  return launch_solve(ctx, params->tol);
+  SumScale sc;
+  if ((rc = run_sum_scale(ctx, params->max_corr_dist, &sc))) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->acc19.p, acc_dev, MA_ACC_LEN * sizeof(long long), hipMemcpyDeviceToDevice, ctx->stream));
+  return launch_solve(ctx, params->tol, sc);
   });
 }
 

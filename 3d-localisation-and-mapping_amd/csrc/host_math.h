@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 
 namespace ma {
@@ -86,6 +87,68 @@ inline void acc_to_world(const double* a, const double o[3], double* out) {
       out[7 + 3 * r + c] = a[7 + 3 * r + c] + a[1 + r] * o[c] + o[r] * a[4 + c] + W * o[r] * o[c];
   out[16] = a[16];
 }
+
+// ---- Exact (associative) sums: the 17 accumulators as 64-bit fixed-point integers -----------------------------------------
+// Row a5's sums are formed as INTEGERS: every correspondence's 17 terms are rounded once, each to a multiple of a
+// per-accumulator quantum 2^-e (round to nearest even: one fma against 1.5 * 2^52), and everything after that — the
+// workgroup's reduction, the 19-way sum, the all-reduce of a sharded loop — is integer addition, which is associative.
+// The sums therefore do not depend on how the source cloud is cut into chunks, workgroups, launches, shards or ranks,
+// nor on the order in which a collective adds them: ANY partition over ANY number of GPUs returns the single GPU's
+// bits (the term of a correspondence depends only on the point, its match and the transform).  62 bits hold the sum:
+// the exponents are chosen from bounds on what a term can be, so that n_total terms cannot overflow —
+//   |q_a| <= qb            the gold map's box (centred frame; the same on every rank: it derives from the gold map alone)
+//   |p'_a| <= pb           gated run: a matched p' lies within the gate of its gold point, pb = qb + gate;
+//                          ungated: p' = R p + t with |p| <= rs gives rs + |t0| for the first iteration, and every later
+//                          transform maps the matched points' centroid onto their gold points' centroid (inside the
+//                          box): |p'| <= sqrt(3) qb + 2 rs
+//   w <= wmax, d^2 <= gate^2 (gated) or 3 (pb + qb)^2
+// — and they are the same on every rank of a sharded run once n_total, wmax and rs are the whole cloud's
+// (ma_sum_bounds_get / _set; ma_icp_sharded agrees on them itself).  At 1M points, a 20 m map and a 0.10 m gate the
+// quantum of S is 2^-34 m^2 per correspondence: finer than the rounding of an fp64 accumulation of the same sum.
+constexpr int kSumW = 0, kSumP = 1, kSumQ = 2, kSumS = 3, kSumE = 4;
+struct SumScale { int e[5]; };        // term * 2^e[group] is rounded to an integer; groups: W, s_p, s_q, S, E
+struct SumBounds {
+  double n_total;   // correspondences that can contribute, all ranks together (source slots)
+  double wmax;      // largest weight (1 without weights)
+  double rs;        // largest |p| of a source point (centred frame); only ungated runs look at it
+};
+// accumulator index (0..16) -> group
+constexpr int sum_group(int k) { return k == 0 ? kSumW : (k < 4 ? kSumP : (k < 7 ? kSumQ : (k < 16 ? kSumS : kSumE))); }
+// smallest E with x <= 2^E (x > 0; powers of two get one more: harmless headroom)
+inline int ceil_log2(double x) {
+  int E = 0;
+  (void)std::frexp(x, &E);
+  return E;
+}
+inline SumScale sum_scale(const SumBounds& b, double qb, double gate, double t0_norm) {
+  const double n = std::max(b.n_total, 1.0), wmax = b.wmax > 0.0 && std::isfinite(b.wmax) ? b.wmax : 1.0;
+  qb = std::max(qb, 1e-30);
+  double pb, d2max;
+  if (std::isfinite(gate)) {
+    pb = qb + gate * 1.001 + 1e-6;
+    d2max = gate * gate * 1.001 + 1e-12;
+  } else {
+    const double rs = std::max(b.rs, 0.0);
+    pb = std::max(rs + t0_norm, 1.7320508075688772 * qb + 2.0 * rs) * 1.001 + 1e-6;
+    d2max = 3.0 * (pb + qb) * (pb + qb);
+  }
+  // a term may use min(50, 61 - L) bits: each term stays inside the fma's exact window (|k| < 2^51) and n terms inside 2^62
+  const int budget = std::min(50, 61 - ceil_log2(n));
+  const double term[5] = {wmax, wmax * pb, wmax * qb, wmax * pb * qb, wmax * d2max};
+  SumScale s;
+  for (int g = 0; g < 5; ++g) s.e[g] = std::max(-900, std::min(900, budget - ceil_log2(term[g])));
+  return s;
+}
+constexpr double kSumMagic = 6755399441055744.0;              // 1.5 * 2^52: fma(x, 2^e, magic) holds rne(x 2^e) in its low mantissa bits
+constexpr unsigned long long kSumMagicBits = 0x4338000000000000ull;
+// host model of what a correspondence term becomes, and back (tests; ma_icp_step's conversion)
+inline long long sum_quantize(double term, int e) {
+  const double r = std::fma(term, std::ldexp(1.0, e), kSumMagic);
+  unsigned long long bits;
+  std::memcpy(&bits, &r, 8);
+  return (long long)(bits - kSumMagicBits);
+}
+inline double sum_to_double(long long v, int e) { return std::ldexp((double)v, -e); }
 
 // strict '<' acceptance against this value implements the inclusive gate d^2 <= gate^2
 inline float open_gate2(double gate) {

@@ -497,6 +497,12 @@ __global__ __launch_bounds__(kBlock) void k_count_bad_weights(const float* __res
     for (int k = 0; k < kBlock / kWave; ++k) t += part[k];
     if (t) atomicAdd(out, (unsigned long long)t);
   }
+  // the largest weight (row a5's sum bounds, host_math.h): non-negative floats order like their bit patterns
+  float m = 0.f;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) m = fmaxf(m, w[i]);      // (fmaxf drops NaNs: those are counted above)
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, kWave));
+  if ((threadIdx.x & (kWave - 1)) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out + 1), __float_as_uint(m));
 }
 
 // sorted[pos] = centred(xyz[perm[pos]]).  w_mode 0: .w = weight (source cloud);
@@ -1002,6 +1008,11 @@ int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   }
   ctx->coarse_built = false;
   for (int a = 0; a < 3; ++a) { ctx->grid_lo[a] = lo[a]; ctx->grid_hi[a] = hi[a]; }
+  {   // largest |coordinate| a gold point can have in the centred frame (row a5's sum bounds)
+    double qb = 0.0;
+    for (int a = 0; a < 3; ++a) qb = std::max({qb, std::fabs((double)lo[a] - ctx->origin[a]), std::fabs((double)hi[a] - ctx->origin[a])});
+    ctx->gold_qb = qb * (1.0 + 1e-6) + 1e-6;
+  }
   // distance-to-occupied table of level 0: three separable passes, x (from the cell table), y, z
   {
     const uint32_t nc = (uint32_t)ncells0;
@@ -1046,14 +1057,20 @@ int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const f
     HIPCHK(hipMemcpyAsync(ctx->wts.p, weights, (size_t)n * 4, hipMemcpyDefault, L.stream));
     d_w = ctx->wts.as<float>();
     HIPCHK(L.misc->ensure(64));
-    HIPCHK(hipMemsetAsync(L.misc->p, 0, 8, L.stream));
+    HIPCHK(hipMemsetAsync(L.misc->p, 0, 16, L.stream));
     hipLaunchKernelGGL(k_count_bad_weights, dim3(std::min<uint32_t>(div_up(n, kBlock), 1024)), dim3(kBlock), 0,
                        L.stream, d_w, n, L.misc->as<unsigned long long>());
     HIPCHK(hipGetLastError());
     unsigned long long* bad = reinterpret_cast<unsigned long long*>(L.mail + kMailWord + 64);
-    HIPCHK(hipMemcpyAsync(bad, L.misc->p, 8, hipMemcpyDeviceToHost, L.stream));     // into pinned memory
+    HIPCHK(hipMemcpyAsync(bad, L.misc->p, 16, hipMemcpyDeviceToHost, L.stream));     // into pinned memory: {bad weights, bits of the largest}
     HIPCHK(hipStreamSynchronize(L.stream));
     if (*bad) return ctx->fail(MA_ERR_INVALID, "weights must be finite and >= 0");
+    {
+      float wmax;
+      const uint32_t bits = (uint32_t)bad[1];
+      std::memcpy(&wmax, &bits, 4);
+      ctx->src_wmax = wmax > 0.f ? (double)wmax : 1.0;
+    }
   }
   float lo[3], hi[3];
   int rc = cloud_bounds(ctx, d_raw, n, lo, hi, 3, false, &L);

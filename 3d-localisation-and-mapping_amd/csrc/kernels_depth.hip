@@ -389,6 +389,17 @@ int launch_unpermute4(ma_ctx* ctx, const void* in, const uint32_t* perm, uint32_
 // synchronisation at all unless somebody asks for it: total != nullptr waits and adds the counts up; with nullptr the
 // call only enqueues, and finish_unproject() settles the count when it is first needed (round 3: a pageable copy
 // of the count array and a stream sync in every call, 0.21 ms of host wall for 14 us of device work).
+// the frame is the source cloud: what its count of valid pixels decides
+static int settle_source_count(ma_ctx* ctx) {
+  ctx->n_pts = ctx->unproj_total;
+  ctx->src_holes = ctx->unproj_total != ctx->n;
+  if (ctx->unproj_total == 0) {
+    ctx->have_src = false;
+    return ctx->fail(MA_ERR_EMPTY, "depth image has no valid pixel");
+  }
+  return MA_OK;
+}
+
 int finish_unproject(ma_ctx* ctx) {
   if (!ctx->unproj_pending) return MA_OK;
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -400,15 +411,7 @@ int finish_unproject(ma_ctx* ctx) {
   uint64_t t = 0;
   for (uint32_t b = 0; b < ctx->unproj_blocks; ++b) t += h[b];
   ctx->unproj_total = (uint32_t)t;
-  if (ctx->unproj_is_source) {          // the frame is the source cloud: what the count decides
-    ctx->n_pts = ctx->unproj_total;
-    ctx->src_holes = ctx->unproj_total != ctx->n;
-    if (ctx->unproj_total == 0) {
-      ctx->have_src = false;
-      return ctx->fail(MA_ERR_EMPTY, "depth image has no valid pixel");
-    }
-  }
-  return MA_OK;
+  return ctx->unproj_is_source ? settle_source_count(ctx) : MA_OK;
 }
 
 static int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, const Pinhole& cam, float4* out, uint32_t* total,
@@ -440,7 +443,8 @@ static int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, cons
     for (uint32_t c : h) t += c;
     ctx->unproj_total = (uint32_t)t;
     ctx->unproj_pending = false;
-    if (total) *total = ctx->unproj_total;
+    if (total) *total = ctx->unproj_total;      // the caller looks at the total itself (map builder)
+    else if (is_source) return settle_source_count(ctx);
     return MA_OK;
   }
   ctx->unproj_pending = true;
@@ -517,6 +521,7 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   ctx->have_src = false;
   ctx->unproj_pending = false;
   ctx->state_valid = false;
+  source_replaced(ctx);
   const uint32_t npx = (uint32_t)((uint64_t)width * height);
   const size_t esz = dtype == 0 ? 4 : 2;
   HIPCHK(ctx->depth_in.ensure((size_t)npx * esz));
@@ -670,6 +675,7 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
     ctx->have_src = false;
     ctx->unproj_pending = false;
     ctx->state_valid = false;
+    source_replaced(ctx);
     return build_gold_from_raw(ctx, nvox, cell);   // ctx->raw already holds the voxel centroids
   }
   HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -649,19 +649,30 @@ __device__ __forceinline__ void point_image(const DevState* __restrict__ st, con
   Py = __fma_rn(st->R[5], z, __fma_rn(st->R[4], y, __fma_rn(st->R[3], x, st->t[1])));
   Pz = __fma_rn(st->R[8], z, __fma_rn(st->R[7], y, __fma_rn(st->R[6], x, st->t[2])));
 }
-// a5: the 17 terms of one correspondence (w, w p', w q, w p' q^T row-major, w |p' - q|^2)
-__device__ __forceinline__ void pair_terms(double (&acc)[kNAcc], const double w, const double Px, const double Py, const double Pz,
-                                           const float3 q) {
+// a5: the 17 terms of one correspondence (w, w p', w q, w p' q^T row-major, w |p' - q|^2), each rounded ONCE to a multiple
+// of its accumulator's quantum 2^-e (host_math.h "Exact sums"): fma(x, 2^e, 1.5 * 2^52) leaves rne(x 2^e) in the low
+// mantissa bits of the result, and the sums from here on add those bit patterns as 64-bit integers — 1.5 * 2^52 included,
+// once per lane, taken out again when the workgroup writes its partial.  Every path (search, list launch, any shard of any
+// partition) forms a correspondence's terms with exactly these operations, so the integer sums are the same whatever the
+// partition: this is what makes a sharded run return the single GPU's bits.
+__device__ __forceinline__ void pair_terms(unsigned long long (&acc)[kNAcc], const double w, const double Px, const double Py,
+                                           const double Pz, const float3 q, const SumScale& sc) {
   const double qx = q.x, qy = q.y, qz = q.z;
   const double dx = Px - qx, dy = Py - qy, dz = Pz - qz;
-  const double wPx = w * Px, wPy = w * Py, wPz = w * Pz;
-  acc[0] = w;
-  acc[1] = wPx; acc[2] = wPy; acc[3] = wPz;
-  acc[4] = w * qx; acc[5] = w * qy; acc[6] = w * qz;
-  acc[7] = wPx * qx;  acc[8] = wPx * qy;  acc[9] = wPx * qz;
-  acc[10] = wPy * qx; acc[11] = wPy * qy; acc[12] = wPy * qz;
-  acc[13] = wPz * qx; acc[14] = wPz * qy; acc[15] = wPz * qz;
-  acc[16] = w * __fma_rn(dz, dz, __fma_rn(dy, dy, dx * dx));
+  // w 2^e is exact (a power of two), so each term is one rounding of an exact product against the magic constant
+  const double wW = w * pow2_f64(sc.e[ma::kSumW]), wP = w * pow2_f64(sc.e[ma::kSumP]), wQ = w * pow2_f64(sc.e[ma::kSumQ]);
+  const double wS = w * pow2_f64(sc.e[ma::kSumS]), wE = w * pow2_f64(sc.e[ma::kSumE]);
+  const double wPx = wS * Px, wPy = wS * Py, wPz = wS * Pz;
+  auto q64 = [](const double a, const double b) -> unsigned long long {
+    return (unsigned long long)__double_as_longlong(__fma_rn(a, b, kSumMagic));
+  };
+  acc[0] = q64(wW, 1.0);
+  acc[1] = q64(wP, Px); acc[2] = q64(wP, Py); acc[3] = q64(wP, Pz);
+  acc[4] = q64(wQ, qx); acc[5] = q64(wQ, qy); acc[6] = q64(wQ, qz);
+  acc[7] = q64(wPx, qx);  acc[8] = q64(wPx, qy);  acc[9] = q64(wPx, qz);
+  acc[10] = q64(wPy, qx); acc[11] = q64(wPy, qy); acc[12] = q64(wPy, qz);
+  acc[13] = q64(wPz, qx); acc[14] = q64(wPz, qy); acc[15] = q64(wPz, qz);
+  acc[16] = q64(wE, __fma_rn(dz, dz, __fma_rn(dy, dy, dx * dx)));
 }
 // Workgroup reduction of the live accumulators of one 256-point chunk, fixed order (deterministic), shared by every
 // launch kind so that their partials are the same bits:
@@ -674,22 +685,22 @@ __device__ __forceinline__ void pair_terms(double (&acc)[kNAcc], const double w,
 // WV: per-wavefront LDS area with a member v[kNAcc][16]; two barriers inside.
 constexpr int kRedParts = 8;
 template <bool COUNT, typename WV>
-__device__ __forceinline__ void reduce_chunk(const double (&acc)[kNAcc], WV* __restrict__ sh_w, double (*sh_part)[kRedParts],
-                                             double* __restrict__ partials, const uint32_t G, const uint32_t chunk,
-                                             const int lane, const int wv) {
+__device__ __forceinline__ void reduce_chunk(const unsigned long long (&acc)[kNAcc], WV* __restrict__ sh_w,
+                                             unsigned long long (*sh_part)[kRedParts], long long* __restrict__ partials,
+                                             const uint32_t G, const uint32_t chunk, const int lane, const int wv) {
   constexpr int kNW = kNNBlock / kWave;
   constexpr int kLive = COUNT ? kNAcc : ma::kAccLen;
   constexpr int kVals = kNW * 16, kPer = kVals / kRedParts;
 #pragma unroll
   for (int k = 0; k < kLive; ++k) {
-    double v = dpp_add<0x111>(acc[k]);
-    v = dpp_add<0x112>(v);
+    unsigned long long v = dpp_add_u64<0x111>(acc[k]);
+    v = dpp_add_u64<0x112>(v);
     if ((lane & 3) == 3) sh_w[wv].v[k][lane >> 2] = v;
   }
   __syncthreads();
   if (threadIdx.x < kLive * kRedParts) {
     const int k = threadIdx.x / kRedParts, part = threadIdx.x % kRedParts;
-    double v = 0.0;
+    unsigned long long v = 0ull;
 #pragma unroll
     for (int t = 0; t < kPer; ++t) {
       const int idx = part * kPer + t;
@@ -700,12 +711,14 @@ __device__ __forceinline__ void reduce_chunk(const double (&acc)[kNAcc], WV* __r
   __syncthreads();
   if (threadIdx.x < kNAcc) {
     const int k = threadIdx.x;
-    double v = 0.0;
+    unsigned long long v = 0ull;
     if (k < kLive) {
 #pragma unroll
       for (int t = 0; t < kRedParts; ++t) v += sh_part[k][t];
+      // every lane of the workgroup carried the magic constant once (matched or not): out it goes, modulo 2^64
+      if (k < ma::kAccLen) v -= (unsigned long long)kNNBlock * kSumMagicBits;
     }
-    partials[(size_t)k * G + chunk] = v;
+    partials[(size_t)k * G + chunk] = (long long)v;
   }
 }
 
@@ -733,9 +746,9 @@ template <bool COUNT, int MODE, int LISTS>
 // first; the level set, 200 bytes by value, is fetched while the first loads are in flight.)
 __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     const DevState* __restrict__ st, const float4* __restrict__ src, const uint32_t n, const int warm_hint,
-    uint32_t* __restrict__ prev, const Sched sched, double* __restrict__ partials, const float best2_init,
+    uint32_t* __restrict__ prev, const Sched sched, long long* __restrict__ partials, const float best2_init,
     const LevelSet S, const uint32_t* __restrict__ perm0, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, const ListCtl* __restrict__ lc, const ListPlanes lp) {
+    float* __restrict__ nn_d2, const ListCtl* __restrict__ lc, const ListPlanes lp, const SumScale sc) {
   if (MODE == 0 && st->done) return;      // a stopped loop: nothing to do
   constexpr int lmode = MODE == 0 ? LISTS : 0;
   const unsigned long long wg_start = wall_clock64();
@@ -755,10 +768,10 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   // per-wavefront LDS: the work queues during the search, the group sums afterwards
   union WaveSearch {
     WaveLds q;
-    double v[kNAcc][16];
+    unsigned long long v[kNAcc][16];
   };
   struct WaveSums {            // a list launch has no work queues
-    double v[kNAcc][16];
+    unsigned long long v[kNAcc][16];
   };
   using WaveShared = typename std::conditional<lmode == 2, WaveSums, WaveSearch>::type;
   __shared__ WaveShared sh_w[kNW];
@@ -892,31 +905,34 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   unsigned long long dbg_t4 = 0;
 #endif
 
-  double acc[kNAcc];
+  // the 17 terms as integer bit patterns (pair_terms); a lane without a correspondence carries the bare magic constant
+  unsigned long long acc[kNAcc];
 #pragma unroll
-  for (int k = 0; k < kNAcc; ++k) acc[k] = 0.0;
+  for (int k = 0; k < kNAcc; ++k) acc[k] = k < ma::kAccLen ? kSumMagicBits : 0ull;
+  // The slot index once more, formed anew from the chunk (a scalar, made opaque) and the thread id: neither the index
+  // nor the point and its image have to live in vector registers through the search (64 VGPRs are all there are at 8
+  // waves per SIMD; with the index carried the allocator spilled it).
+  uint32_t chunk_again = chunk;
+  asm volatile("" : "+s"(chunk_again));
+  const uint32_t i2 = lmode == 2 ? i : chunk_again * kNNBlock + threadIdx.x;      // (a list launch has no search in between)
   if (has) {
 #if MA_DEBUG_FETCH      // debug build (tools/tie_debug.py): list launches leave their matches behind too
-    if (prev) prev[i] = bestj;
+    if (prev) prev[i2] = bestj;
 #else
-    if (prev && lmode != 2) prev[i] = bestj;
+    if (prev && lmode != 2) prev[i2] = bestj;
 #endif
-    if (MODE == 0 && lmode != 2) {       // (a list launch has no search in between: its point stays in registers)
-      uint32_t again = i;
-      asm volatile("" : "+v"(again));   // opaque copy of the index: the compiler must not keep s, P live instead
-      image(again);
-    }
+    if (MODE == 0 && lmode != 2) image(i2);       // (a list launch's point stays in registers)
     if (MODE == 1) {
-      nn_idx[i] = bestj != kNoMatch ? perm0[bestj] : kNoMatch;
-      nn_d2[i] = bestj != kNoMatch ? best2 : INFINITY;
+      nn_idx[i2] = bestj != kNoMatch ? perm0[bestj] : kNoMatch;
+      nn_d2[i2] = bestj != kNoMatch ? best2 : INFINITY;
     }
     if (MODE == 0 && bestj != kNoMatch) {
       float3 q;
       if constexpr (lmode == 2) q = make_float3(wqx, wqy, wqz);     // carried with the minimum: the very bits of the gold array
       else q = ld_xyz(S.gold[0], bestj);           // the winner's coordinates (level 0 holds every point)
-      pair_terms(acc, (double)s.w, Px, Py, Pz, q);
+      pair_terms(acc, (double)s.w, Px, Py, Pz, q, sc);
     }
-    if (COUNT) { acc[17] = (double)nrows; acc[18] = (double)ncand; }
+    if (COUNT) { acc[17] = nrows; acc[18] = ncand; }
   }
   if (MODE == 1) return;  // ma_nn: per-point outputs only
 #if MA_WGTIMES
@@ -925,7 +941,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
 #endif
 
   // workgroup reduction of the live accumulators -> one partial per accumulator and chunk (reduce_chunk)
-  __shared__ double sh_part[kNAcc][kRedParts];
+  __shared__ unsigned long long sh_part[kNAcc][kRedParts];
   __shared__ uint32_t sh_dismissed[kNW];
   if (lane == 0) sh_dismissed[wv] = ndismissed;
   reduce_chunk<COUNT>(acc, sh_w, sh_part, partials, G, chunk, lane, wv);
@@ -957,8 +973,8 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
 
 namespace mai {
 
-int launch_nn(ma_ctx* ctx, const int mode, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2, bool scheduled, int list_kind,
-              int warm_hint) {
+int launch_nn(ma_ctx* ctx, const int mode, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2, const SumScale& sc,
+              bool scheduled, int list_kind, int warm_hint) {
   uint32_t gshift = 0;
   const uint32_t G = grid_for(ctx->n, &gshift);
   ctx->last_G = (int)G;
@@ -980,8 +996,8 @@ int launch_nn(ma_ctx* ctx, const int mode, bool count, float best2_init, uint32_
   auto args = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(G), dim3(kNNBlock), 0, ctx->stream, ctx->state.as<DevState>(), ctx->src.as<float4>(), ctx->n,
                        warm_hint, mode == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, sched,
-                       ctx->partials.as<double>(), best2_init, ctx->levels, ctx->perm0.as<uint32_t>(), nn_idx, nn_d2,
-                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, lp);
+                       ctx->partials.as<long long>(), best2_init, ctx->levels, ctx->perm0.as<uint32_t>(), nn_idx, nn_d2,
+                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, lp, sc);
   };
   if (mode == 1) {                       // ma_nn: per-point outputs, always a search
     if (count) args(k_nn_accum<true, 1, 0>);

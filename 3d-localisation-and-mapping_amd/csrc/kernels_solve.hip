@@ -55,9 +55,17 @@ __device__ __forceinline__ void rank_groups(const int G, const uint32_t* __restr
 // CUs pull 31 KB each instead of one CU pulling 0.6 MB (one CU's load bandwidth, not the
 // arithmetic, is what a single-workgroup reduction waits for).  Fixed assignment partial ->
 // thread, fixed order within a thread, DPP + LDS tree: deterministic.
-__global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ partials, const int G,
+// The sums are 64-bit fixed-point INTEGERS (host_math.h "Exact sums"): integer addition is associative, so neither the
+// assignment of partials to threads nor the tree below matters for the result — only for the time.
+__device__ __forceinline__ double sum_value(const long long v, const int k, const SumScale& sc) {
+  // accumulator k as a number: v 2^-e (exact up to 53 bits); the two work counters (k >= 17) are plain counts
+  const double x = (double)v;
+  return k < ma::kAccLen ? x * pow2_f64(-sc.e[ma::sum_group(k)]) : x;
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce19(const long long* __restrict__ partials, const int G,
                                                      const DevState* __restrict__ st,
-                                                     double* __restrict__ acc_out,
+                                                     long long* __restrict__ acc_out,
                                                      const uint32_t* __restrict__ wg_cost,
                                                      uint32_t* __restrict__ order, const uint32_t gshift) {
   if (blockIdx.x == kNAcc) {   // launched only with a schedule (ma_icp_sharded): rank the groups for the next search
@@ -69,26 +77,26 @@ __global__ __launch_bounds__(kBlock) void k_reduce19(const double* __restrict__ 
     // a stopped loop: the search launch returned at once and left old partials behind.  The sharded loop keeps
     // issuing its all-reduces (every rank must issue the same number), so the sums are ZEROED rather than left
     // stale: in place, they would be multiplied by the number of ranks in every remaining iteration.
-    if (threadIdx.x == 0) acc_out[k] = 0.0;
+    if (threadIdx.x == 0) acc_out[k] = 0;
     return;
   }
-  const double* __restrict__ p = partials + (size_t)k * G;
-  double v = 0.0;
+  const long long* __restrict__ p = partials + (size_t)k * G;
+  unsigned long long v = 0ull;
   for (int b0 = threadIdx.x; b0 < G; b0 += 8 * kBlock) {
-    double u[8];
+    long long u[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {     // eight independent loads in flight per thread
       const int b = b0 + t * kBlock;
-      u[t] = b < G ? p[b] : 0.0;
+      u[t] = b < G ? p[b] : 0;
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v += u[t];
+    for (int t = 0; t < 8; ++t) v += (unsigned long long)u[t];
   }
-  __shared__ double red[kBlock / kWave];
-  v = wave_sum(v);
+  __shared__ unsigned long long red[kBlock / kWave];
+  v = wave_sum_u64(v);
   if ((threadIdx.x & (kWave - 1)) == kSumLane) red[threadIdx.x / kWave] = v;
   __syncthreads();
-  if (threadIdx.x == 0) acc_out[k] = ((red[0] + red[1]) + red[2]) + red[3];
+  if (threadIdx.x == 0) acc_out[k] = (long long)(red[0] + red[1] + red[2] + red[3]);
 }
 
 // a6 + a7 for one thread: Kabsch step from the 19 reduced values, transform composition,
@@ -135,7 +143,7 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
     if (host_mirror) *host_mirror = s0;
     if (host_done) *host_done = s0.iter;     // iterations run when the loop stopped (never 0)
     if (slot) {                              // every iteration up to and including the one that stops the loop writes its slot
-      *const_cast<unsigned long long*>(&slot->chk) = slot_check(s0.R, s0.t, s0.iter);
+      *const_cast<unsigned long long*>(&slot->chk) = slot_check(s0.R, s0.t, s0.iter, slot_flags(s0.done, s0.converged, s0.degenerate));
       *const_cast<int*>(&slot->seq) = s0.iter;
     }
     return;
@@ -166,8 +174,9 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
   if (host_mirror) *host_mirror = s0;
   if (slot) {      // candidate lists: host_mirror is this iteration's own pinned slot, and the host's planner reads it (ma_icp)
     // plain stores (the fields are volatile for the HOST's reads): a volatile store makes the wavefront wait for the
-    // posted write to be acknowledged, 0.7 us each; the checksum makes their order irrelevant
-    *const_cast<unsigned long long*>(&slot->chk) = slot_check(s0.R, s0.t, s0.iter);
+    // posted write to be acknowledged, 0.7 us each; the checksum — over the transform, the count AND the flags the host's stop
+    // rule reads — makes their order irrelevant
+    *const_cast<unsigned long long*>(&slot->chk) = slot_check(s0.R, s0.t, s0.iter, slot_flags(s0.done, s0.converged, s0.degenerate));
     *const_cast<int*>(&slot->seq) = s0.iter;
   }
 #if MA_WGTIMES
@@ -176,14 +185,15 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
 }
 
 // The solve alone (sharded-source stepping: the 17 sums come back from the all-reduce).
-__global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_in, DevState* __restrict__ st,
+__global__ __launch_bounds__(kWave) void k_solve(const long long* __restrict__ acc_in, DevState* __restrict__ st,
                                                  double* __restrict__ trace, const int trace_cap,
                                                  const double tol, int* __restrict__ host_done,
-                                                 DevState* __restrict__ host_mirror, StateSlot* __restrict__ slot) {
+                                                 DevState* __restrict__ host_mirror, StateSlot* __restrict__ slot,
+                                                 const SumScale sc) {
   if (st->done || threadIdx.x != 0) return;
   double a[kNAcc];
 #pragma unroll
-  for (int k = 0; k < kNAcc; ++k) a[k] = acc_in[k];
+  for (int k = 0; k < kNAcc; ++k) a[k] = sum_value(acc_in[k], k, sc);
   solve_step(a, *st, st, trace, trace_cap, tol, host_done, host_mirror, slot);
 }
 
@@ -199,14 +209,14 @@ __global__ __launch_bounds__(kWave) void k_solve(const double* __restrict__ acc_
 // One more workgroup (blockIdx kNAcc, beside the sums, not part of the hand-off) ranks the
 // scheduling groups by the cost the search kernel just recorded: order[r] = the group with
 // the r-th largest cost, ties by index (rank by counting, <= 512 groups).
-__global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restrict__ partials, const int G,
-                                                         DevState* __restrict__ st, double* __restrict__ acc_out,
+__global__ __launch_bounds__(kBlock) void k_reduce_solve(const long long* __restrict__ partials, const int G,
+                                                         DevState* __restrict__ st, long long* __restrict__ acc_out,
                                                          uint32_t* __restrict__ ticket, double* __restrict__ trace,
                                                          const int trace_cap, const double tol,
                                                          const uint32_t* __restrict__ wg_cost,
                                                          uint32_t* __restrict__ order, const uint32_t gshift,
                                                          int* __restrict__ host_done, DevState* __restrict__ host_mirror,
-                                                         StateSlot* __restrict__ slot) {
+                                                         StateSlot* __restrict__ slot, const SumScale sc) {
   // `done` is written only by the last arriver, after every workgroup has read it.  It is
   // tested AFTER the first loads have been issued: every dependent memory round trip of
   // this small kernel is ~1 us of the iteration.
@@ -226,29 +236,29 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   const int it_now = st->iter;
   DevState s0;
   if (threadIdx.x == 0) s0 = *st;   // whoever arrives last will need it: read it now, not after the hand-off
-  const double* __restrict__ p = partials + (size_t)k * G;
-  double v = 0.0;
+  const long long* __restrict__ p = partials + (size_t)k * G;
+  unsigned long long v = 0ull;
   for (int b0 = threadIdx.x; b0 < G; b0 += 16 * kBlock) {
-    double u[16];
+    long long u[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {    // sixteen independent loads in flight per thread
       const int b = b0 + t * kBlock;
-      u[t] = b < G ? p[b] : 0.0;
+      u[t] = b < G ? p[b] : 0;
     }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) v += u[t];
+    for (int t = 0; t < 16; ++t) v += (unsigned long long)u[t];
   }
   if (done) return;
-  __shared__ double red[kBlock / kWave];
-  v = wave_sum(v);
+  __shared__ unsigned long long red[kBlock / kWave];
+  v = wave_sum_u64(v);
   if ((threadIdx.x & (kWave - 1)) == kSumLane) red[threadIdx.x / kWave] = v;
   __syncthreads();
   if (threadIdx.x != 0) return;
-  const double sum = ((red[0] + red[1]) + red[2]) + red[3];
+  const long long sum = (long long)(red[0] + red[1] + red[2] + red[3]);
   __hip_atomic_store(&acc_out[k], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // this accumulator's entry of the iteration's trace row (columns 0-16 the sums, 17 the rmse — the solve's —, 18 and 19
   // the two work counters)
-  if (it_now < trace_cap) trace[(size_t)it_now * MA_TRACE_STRIDE + (k < ma::kAccLen ? k : k + 1)] = sum;
+  if (it_now < trace_cap) trace[(size_t)it_now * MA_TRACE_STRIDE + (k < ma::kAccLen ? k : k + 1)] = sum_value(sum, k, sc);
 #if MA_WGTIMES
   if (dbg_it < 64) g_rs[dbg_it][k][1] = wall_clock64();
 #endif
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const double* __restric
   __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   double a[kNAcc];
 #pragma unroll
-  for (int t = 0; t < kNAcc; ++t) a[t] = __hip_atomic_load(&acc_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int t = 0; t < kNAcc; ++t) a[t] = sum_value(__hip_atomic_load(&acc_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t, sc);
 #if MA_WGTIMES
   asm volatile("" :: "v"(a[0]), "v"(a[18]));
   if (dbg_it < 64) g_rs[dbg_it][k][3] = wall_clock64();
@@ -293,29 +303,29 @@ int launch_begin_run(ma_ctx* ctx, const DevState& s, const ListCtl& c) {
 // with_rank: one more workgroup orders the scheduling groups for the next search launch
 int launch_reduce(ma_ctx* ctx, bool with_rank) {
   hipLaunchKernelGGL(k_reduce19, dim3(kNAcc + (with_rank ? 1 : 0)), dim3(kBlock), 0, ctx->stream,
-                     ctx->partials.as<double>(), ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>(),
+                     ctx->partials.as<long long>(), ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<long long>(),
                      ctx->wg_cost.as<uint32_t>(), ctx->seg_order.as<uint32_t>(), ctx->last_gshift);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
 
 // the same sum plus the solve by the last-arriving workgroup, one launch
-int launch_reduce_solve(ma_ctx* ctx, double tol, StateSlot* slot) {
-  hipLaunchKernelGGL(k_reduce_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<double>(),
-                     ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<double>(), ctx->ticket.as<uint32_t>(),
+int launch_reduce_solve(ma_ctx* ctx, double tol, const SumScale& sc, StateSlot* slot) {
+  hipLaunchKernelGGL(k_reduce_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<long long>(),
+                     ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<long long>(), ctx->ticket.as<uint32_t>(),
                      ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(),
                      ctx->seg_order.as<uint32_t>(), ctx->last_gshift, ctx->host_done,
-                     slot ? &slot->s : ctx->host_state_out, slot);
+                     slot ? &slot->s : ctx->host_state_out, slot, sc);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
 
 // in_loop: inside the sharded loop (pinned `done` word, pinned mirror of the state, planner slot)
-int launch_solve(ma_ctx* ctx, double tol, bool in_loop, StateSlot* slot) {
-  hipLaunchKernelGGL(k_solve, dim3(1), dim3(kWave), 0, ctx->stream, ctx->acc19.as<double>(),
+int launch_solve(ma_ctx* ctx, double tol, const SumScale& sc, bool in_loop, StateSlot* slot) {
+  hipLaunchKernelGGL(k_solve, dim3(1), dim3(kWave), 0, ctx->stream, ctx->acc19.as<long long>(),
                      ctx->state.as<DevState>(), ctx->trace.as<double>(), ctx->trace_cap, tol,
                      in_loop ? ctx->host_done : (int*)nullptr,
-                     in_loop ? (slot ? &slot->s : ctx->host_state_out) : (DevState*)nullptr, slot);
+                     in_loop ? (slot ? &slot->s : ctx->host_state_out) : (DevState*)nullptr, slot, sc);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }

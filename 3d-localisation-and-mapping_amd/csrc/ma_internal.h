@@ -112,37 +112,10 @@ struct ListCtl {
   float slack;       // rounding allowance of the per-query displacement, metres
   double Rb[9], tb[3];
 };
-// What every solve of a loop that may use lists leaves in pinned host memory for the host's planner: the state it
-// produced, in a slot of its own (iteration k -> slot k), so that the host reads the transform of a fixed iteration
-// whatever the device has done since.  Posted writes: the solve does not wait for them.
-struct StateSlot {
-  ma::DevState s;
-  volatile unsigned long long chk;   // slot_check(R, t, seq): the host takes a slot only when it matches what it reads —
-  volatile int seq;                  // iterations solved (= s.iter) — so the solve needs no fence between the posted writes
-  int pad;                           // (a system-scope fence there cost 1.4 us of every iteration)
-};
-__host__ __device__ inline unsigned long long slot_check(const double* R, const double* t, int seq);
-// host: has the solve of iteration `want - 1` written this slot completely?  (every field read through volatile)
-inline bool slot_ready(const volatile StateSlot* sl, int want);
-// (The solving lane pays ~4 ns per instruction, 50 times per alignment: an exclusive-or per 32-bit half and word — every
-// second word with its halves swapped — instead of a 64-bit multiply and twelve 64-bit rotations.  What it has to catch is a
-// slot whose words come from two different solves, and the slots of a new run start out invalid.)
-__host__ __device__ inline unsigned long long slot_check(const double* R, const double* t, int seq) {
-  unsigned long long x = ((unsigned long long)(unsigned)seq << 32 | (unsigned)~seq) ^ 0x9E3779B97F4A7C15ull;
-  for (int i = 0; i < 12; ++i) {
-    unsigned long long b;
-    memcpy(&b, i < 9 ? &R[i] : &t[i - 9], 8);
-    x ^= (i & 1) ? (b << 32 | b >> 32) : b;
-  }
-  return x;
-}
-inline bool slot_ready(const volatile StateSlot* sl, int want) {
-  if (sl->seq != want) return false;
-  double R[9], t[3];
-  for (int i = 0; i < 9; ++i) R[i] = sl->s.R[i];
-  for (int i = 0; i < 3; ++i) t[i] = sl->s.t[i];
-  return sl->chk == slot_check(R, t, want);
-}
+using ma::StateSlot;                // list_planner.h: the pinned slot every solve of a planned loop reports into
+using ma::slot_check;
+using ma::slot_flags;
+using ma::slot_ready;
 
 // plain structs and host arithmetic shared with the CPU-side sanitizer test (host_math.h)
 using ma::DevState;
@@ -183,6 +156,30 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 constexpr int kSumLane = kWave - 1;
+
+// The same two for 64-bit INTEGERS (the exact sums of row a5, host_math.h "Exact sums"): an add of a DPP-shifted copy
+// and the wavefront total in lane 63.  Lanes without a source read 0 (bound_ctrl), the identity of the sum.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_add_u64(unsigned long long v) {
+  const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+  const uint32_t lo2 = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, true);
+  const uint32_t hi2 = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true);
+  return v + (((unsigned long long)hi2 << 32) | lo2);
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+  v = dpp_add_u64<0x111>(v);  // row_shr:1
+  v = dpp_add_u64<0x112>(v);  // row_shr:2
+  v = dpp_add_u64<0x114>(v);  // row_shr:4
+  v = dpp_add_u64<0x118>(v);  // row_shr:8
+  v = dpp_add_u64<0x142>(v);  // row_bcast:15
+  v = dpp_add_u64<0x143>(v);  // row_bcast:31 -> lane 63 = total
+  return v;
+}
+using ma::SumScale;
+using ma::kSumMagic;
+using ma::kSumMagicBits;
+// 2^e as a double from its exponent (|e| < 1000): two scalar operations, no table
+__device__ __forceinline__ double pow2_f64(const int e) { return __hiloint2double((1023 + e) << 20, 0); }
 
 
 // hardware square root (1 ulp, one instruction instead of the ~18 of the correctly rounded
@@ -333,6 +330,12 @@ struct ma_ctx {
   float src_rs = 0.f;                          // largest distance of a corner of the source cloud's box from the centring origin; 0: unknown, no lists
   float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // that box (centred frame)
   bool src_box_pending = false;                // source from a depth frame: the box is computed by the first run that can use it
+  // exact sums (host_math.h): what bounds a correspondence's terms
+  double src_wmax = 1.0;                       // largest weight of the source cloud (1 without weights)
+  double gold_qb = 0.0;                        // largest |coordinate| of the gold map's grid box, centred frame
+  double run_t0 = 0.0;                         // |t| of the transform the current run / stepping sequence started from (centred frame)
+  bool sum_bounds_set = false;                 // ma_sum_bounds_set: the bounds of the WHOLE cloud of a sharded run ...
+  ma::SumBounds sum_bounds{0.0, 1.0, 0.0};     // ... (n_total, wmax, rs); until then this context's own
   bool lists_on = false;                       // set by the loop (icp_loop) around its launches
   bool cfg_lists = true;                       // ma_list_config: lists allowed at all; skin = cell edge / cfg_skin_div; a write must
   float cfg_skin_div = ma::kSkinDivDefault;    //   be followed by >= cfg_min_uses predicted uses
@@ -456,14 +459,14 @@ hipError_t launch_f64_to_raw(const double* xyz, uint64_t n3, const double shift[
 // kernels_search.hip: one launch of k_nn_accum.  mode 0: accumulate (the loop), 1: per-point (idx, d2) only (ma_nn);
 // `scheduled`: inside the loop (costs recorded, longest-first order from iteration 1 on); list_kind 0 search, 1 search
 // and write the candidate lists, 2 read them
-int launch_nn(ma_ctx* ctx, int mode, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2, bool scheduled = false,
-              int list_kind = 0, int warm_hint = -1);
+int launch_nn(ma_ctx* ctx, int mode, bool count, float best2_init, uint32_t* nn_idx, float* nn_d2, const SumScale& sc,
+              bool scheduled = false, int list_kind = 0, int warm_hint = -1);
 
 // kernels_solve.hip
 int launch_begin_run(ma_ctx* ctx, const DevState& s, const ListCtl& c);
 int launch_reduce(ma_ctx* ctx, bool with_rank = false);
-int launch_reduce_solve(ma_ctx* ctx, double tol, StateSlot* slot = nullptr);
-int launch_solve(ma_ctx* ctx, double tol, bool in_loop = false, StateSlot* slot = nullptr);
+int launch_reduce_solve(ma_ctx* ctx, double tol, const SumScale& sc, StateSlot* slot = nullptr);
+int launch_solve(ma_ctx* ctx, double tol, const SumScale& sc, bool in_loop = false, StateSlot* slot = nullptr);
 
 // kernels_depth.hip
 int finish_unproject(ma_ctx* ctx);
@@ -473,6 +476,12 @@ int launch_unpermute4(ma_ctx* ctx, const void* in, const uint32_t* perm, uint32_
 
 // host_loop.hip
 int check_params(ma_ctx* ctx, const ma_params* p);
+// the box of a source cloud made from a depth frame, computed when first needed (candidate lists, ungated sum bounds)
+int ensure_source_box(ma_ctx* ctx);
+// the fixed-point scale of the 17 sums for a run gated at `gate` on the clouds and bounds in force (host_math.h)
+int run_sum_scale(ma_ctx* ctx, double gate, SumScale* out);
+// a new source cloud (or gold map): whatever was agreed for the old one no longer holds
+inline void source_replaced(ma_ctx* ctx) { ctx->sum_bounds_set = false; ctx->src_wmax = 1.0; }
 int need_ready(ma_ctx* ctx);
 int ensure_loop_buffers(ma_ctx* ctx, int trace_rows);
 int upload_state(ma_ctx* ctx, const double* T);
@@ -484,6 +493,8 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
 void comm_destroy(ma_ctx* ctx);
 // the loop's collective: all-reduce (sum) of the MA_ACC_LEN sums in ctx->acc19, in place, on the ctx stream
 int comm_allreduce_sums(ma_ctx* ctx);
+// every rank's (n, wmax, rs) -> the whole cloud's, installed as this context's sum bounds (one small collective per source cloud)
+int comm_agree_sum_bounds(ma_ctx* ctx);
 
 // host_ctx.hip
 void list_config_from_env(ma_ctx* ctx);

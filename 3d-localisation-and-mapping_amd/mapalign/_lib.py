@@ -112,6 +112,9 @@ ABI = {
     "ma_state_get": (C.c_int, [_ctx_p, _f64p, C.POINTER(ma_stats)]),
     "ma_step_accumulate": (C.c_int, [_ctx_p, C.POINTER(ma_params), C.c_void_p]),
     "ma_step_solve": (C.c_int, [_ctx_p, C.POINTER(ma_params), C.c_void_p]),
+    "ma_sum_bounds_get": (C.c_int, [_ctx_p, _f64p]),
+    "ma_sum_bounds_set": (C.c_int, [_ctx_p, _f64p]),
+    "ma_sum_scale_get": (C.c_int, [_ctx_p, C.POINTER(ma_params), C.POINTER(C.c_int32)]),
     "ma_mem_info_get": (C.c_int, [_ctx_p, C.POINTER(ma_mem_info)]),
     "ma_search_geometry": (C.c_int, [_ctx_p, _u32p, _u32p]),
     "ma_get_list_stats": (C.c_int, [_ctx_p, C.POINTER(C.c_int32)]),

@@ -8,8 +8,11 @@ Two modes, both without any per-point traffic between GPUs:
   mode and what ``bench.py --gpus N`` measures.
 * **sharded source** (:func:`sharded_align`) — one pair spread over the ranks of a group:
   the gold map and its grid are replicated, the comparison cloud is block-partitioned, and
-  per iteration the ONLY exchange is one all-reduce(sum) of the 17-double centroid /
-  cross-covariance accumulator (136 B, latency-bound).  The collective lives INSIDE
+  per iteration the ONLY exchange is one all-reduce(sum) of the 17 centroid /
+  cross-covariance sums (136 B, latency-bound) — 64-bit fixed-point INTEGERS, so the
+  result does not depend on the order of the additions, nor on the partition: any number
+  of ranks returns the single GPU's bits (``MapAligner.set_sum_bounds``: the ranks agree
+  once per cloud on what bounds a term).  The collective lives INSIDE
   ``libmapalign.so`` (``ma_icp_sharded``: search -> 19-way sum -> ``ncclAllReduce`` ->
   solve, enqueued from C on the context's stream, no Python between iterations); Python
   only bootstraps the ``ncclUniqueId`` (:func:`bootstrap_comm`) over whatever
@@ -93,8 +96,26 @@ class HipShardEngine:
         self.tol = float(tol)
 
     def new_acc(self):
+        """The exchange buffer: 17 fixed-point sums, int64 (summing them is exact in any order)."""
         import torch
-        return torch.zeros(ACC_LEN, dtype=torch.float64, device=f"cuda:{self.aligner.device}")
+        return torch.zeros(ACC_LEN, dtype=torch.int64, device=f"cuda:{self.aligner.device}")
+
+    def agree_sum_bounds(self, group=None):
+        """Collective: every rank's (n, wmax, rs) -> the whole cloud's, installed on this rank's context, so that all
+        ranks derive the same fixed-point scales (and the single GPU's).  Once per source cloud."""
+        import torch
+        import torch.distributed as dist
+
+        mine = np.asarray(self.aligner.sum_bounds(), dtype=np.float64)
+        world, _ = _world(group)
+        if world > 1:
+            on_gpu = dist.get_backend(group) == "nccl"
+            t = torch.as_tensor(mine, device=f"cuda:{self.aligner.device}" if on_gpu else "cpu")
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t, group=group)
+            mine = self.aligner.combine_sum_bounds(torch.stack(out).cpu().numpy())
+        self.aligner.set_sum_bounds(mine)
+        return mine
 
     def bind_current_stream(self):
         """Launch on torch's current stream so kernels and a torch collective are ordered without host syncs."""
@@ -116,7 +137,7 @@ class HipShardEngine:
 
 def sharded_icp(engine, acc, max_iter=50, init=None, group=None, all_reduce=None):
     """The sharded-source loop in Python over a duck-typed engine (tests / custom collectives).
-    ``acc`` is the 17-double exchange buffer; ``all_reduce(acc)`` defaults to
+    ``acc`` is the exchange buffer of 17 sums (int64 fixed point for the HIP engine); ``all_reduce(acc)`` defaults to
     ``torch.distributed.all_reduce(acc, SUM, group)``.  Returns ``(T 4x4, info dict)``;
     identical on every rank of the group."""
     if all_reduce is None:
@@ -126,10 +147,12 @@ def sharded_icp(engine, acc, max_iter=50, init=None, group=None, all_reduce=None
             if dist.is_initialized() and dist.get_world_size(group) > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
+    if hasattr(engine, "agree_sum_bounds"):
+        engine.agree_sum_bounds(group)
     engine.state_set(init)
     for _ in range(int(max_iter)):
         engine.accumulate_into(acc)   # a4 + a5 on the local shard
-        all_reduce(acc)               # the one collective: 17 doubles
+        all_reduce(acc)               # the one collective: 17 sums
         engine.solve_from(acc)        # a6 + a7, redundantly on every rank
     return engine.state_get()
 

@@ -168,6 +168,7 @@ class MapAligner:
         self._n_source = 0
         self._shift = np.zeros(3)
         self._map_shift = None
+        self._depth_keep = None         # a depth frame whose copy into the context is enqueued but not waited for yet
         self._comm_ranks = 0
         self.gold_token = None          # set by callers that want to know whether "their" gold map is still installed (api.align_many)
 
@@ -225,6 +226,7 @@ class MapAligner:
 
     def sync(self):
         self._chk(self._lib.ma_sync(self._ctx))
+        self._depth_keep = None
 
     # -- clouds ---------------------------------------------------------------------
     def set_gold(self, gold_cloud, cell=0.0):
@@ -376,6 +378,9 @@ class MapAligner:
             self._ctx, d_p, dtype, width, height,
             Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T), float(depth_scale), C.byref(nv) if count else None))
         self._n_source = int(nv.value) if count else None
+        # count=False only enqueued the copy of the frame (include/mapalign.h: the buffer must outlive it): what was made
+        # here for the call — an astype / contiguous copy, a tensor's owner — stays referenced until the next wait
+        self._depth_keep = None if count else (_keep, depth)
         return self._n_source
 
     # -- map builder (N4): depth frames + poses -> one voxel-deduplicated cloud on the device
@@ -544,7 +549,10 @@ class MapAligner:
         Tin = _conj_shift(_as_T(init), self._shift, inverse=True)
         Tout = np.empty((4, 4), dtype=np.float64)
         st = ma_stats()
-        self._chk(self._lib.ma_icp(self._ctx, C.byref(p), _f64p(Tin), _f64p(Tout), C.byref(st)))
+        try:
+            self._chk(self._lib.ma_icp(self._ctx, C.byref(p), _f64p(Tin), _f64p(Tout), C.byref(st)))
+        finally:
+            self._depth_keep = None          # ma_icp waits for the stream: an enqueued depth-frame copy is done
         Tout = _conj_shift(Tout, self._shift)
         tr = self.trace(st.iterations) if with_trace else None
         return AlignResult(Tout, int(st.iterations), float(st.rmse), float(st.inliers), bool(st.converged),
@@ -624,6 +632,39 @@ class MapAligner:
         self._chk(self._lib.ma_state_get(self._ctx, _f64p(Tout), C.byref(st)))
         return _conj_shift(Tout, self._shift), {"iterations": int(st.iterations), "converged": bool(st.converged),
                       "degenerate": bool(st.degenerate), "rmse": float(st.rmse), "inliers": float(st.inliers)}
+
+    # -- exact sums: the bounds every shard of one comparison cloud must agree on (include/mapalign.h "Exact sums")
+    def sum_bounds(self):
+        """This context's own ``(n, wmax, rs)``: points, largest weight, largest distance of a point from the origin."""
+        out = np.zeros(3, dtype=np.float64)
+        self._chk(self._lib.ma_sum_bounds_get(self._ctx, _f64p(out)))
+        return out
+
+    def set_sum_bounds(self, bounds):
+        """Install the WHOLE cloud's bounds (``combine_sum_bounds`` of every shard's); ``None`` clears them."""
+        if bounds is None:
+            self._chk(self._lib.ma_sum_bounds_set(self._ctx, None))
+        else:
+            self._chk(self._lib.ma_sum_bounds_set(self._ctx, _f64p(np.ascontiguousarray(bounds, dtype=np.float64).reshape(3))))
+
+    @staticmethod
+    def combine_sum_bounds(all_bounds):
+        """Bounds of the union of shards: ``[sum n, max wmax, max rs]``."""
+        b = np.asarray(all_bounds, dtype=np.float64).reshape(-1, 3)
+        return np.array([b[:, 0].sum(), b[:, 1].max(), b[:, 2].max()])
+
+    def sum_scale(self, max_corr_dist=0.10):
+        """Exponents ``e[5]`` (W, s_p, s_q, S, E) of the fixed-point sums for a run gated at ``max_corr_dist``."""
+        p = self._params(1, 0.0, max_corr_dist)
+        out = (C.c_int32 * 5)()
+        self._chk(self._lib.ma_sum_scale_get(self._ctx, C.byref(p), out))
+        return np.array(out[:], dtype=np.int64)
+
+    def sums_to_float(self, sums_i64, max_corr_dist=0.10):
+        """The 17 fixed-point sums (what ``step_accumulate`` writes: int64) as numbers, centred frame."""
+        e = self.sum_scale(max_corr_dist)
+        group = np.array([0, 1, 1, 1, 2, 2, 2] + [3] * 9 + [4])
+        return np.ldexp(np.asarray(sums_i64, dtype=np.int64).astype(np.float64), -e[group])
 
     def step_accumulate(self, acc_dev_ptr, max_corr_dist=0.10, count_work=False):
         p = self._params(1, 0.0, max_corr_dist, count_work)

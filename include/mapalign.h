@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MA_VERSION 400 /* 0.4.0: ma_list_config, ma_get_planner_diag, MA_FLAG_NO_LISTS; one tie rule (smallest position) on every path */
+#define MA_VERSION 500 /* 0.5.0: the 17 sums are exact 64-bit fixed-point integers (any sharding returns the single GPU's bits): ma_sum_bounds_get/_set, ma_sum_scale_get; ma_step_accumulate hands over int64 */
 #define MA_ACC_LEN 17  /* W, s_p[3], s_q[3], S[9] row-major (S_ab = sum w p'_a q_b), E */
 #define MA_TRACE_STRIDE 20 /* per-iteration trace row: acc[17], rmse, table_words_read, candidates */
 #define MA_NO_MATCH 0xFFFFFFFFu
@@ -205,8 +205,13 @@ int ma_cloud_moments(ma_ctx* ctx, int which, double out[13]);
  * the device — an alignment can follow on the same stream at once (ma_icp needs no count).  The
  * count is then settled by the first call that needs it (ma_get_source(ctx, NULL, &n) returns it),
  * and an image without a single valid pixel is reported there (MA_ERR_EMPTY) or by ma_icp
- * (MA_ERR_DEGENERATE: nothing to match).  The depth buffer is borrowed for the duration of the call
- * in both cases (it is copied before the call returns). */
+ * (MA_ERR_DEGENERATE: nothing to match).
+ * Lifetime of the depth buffer.  With n_valid != NULL the call waits for the device, so the buffer is free when it
+ * returns.  With n_valid == NULL the copy into the context is only ENQUEUED (hipMemcpyAsync on the ctx stream): a frame in
+ * DEVICE memory or in PINNED host memory must stay valid and unmodified until the next call on this context that waits
+ * for the stream (ma_sync, ma_icp, ma_get_source, ...), and a producer on another stream must not overwrite it before
+ * then; a frame in pageable host memory is staged by the runtime before hipMemcpyAsync returns, as for every pageable
+ * source (mapalign/engine.py keeps a temporary it made alive until that next wait either way). */
 int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height,
                              const float K[4], const double T_cam_to_world[16],
                              float depth_scale, uint64_t* n_valid);
@@ -313,14 +318,39 @@ int ma_icp_step(ma_ctx* ctx, const ma_params* params, const double T_in[16],
 int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_out,
           float* d2_out);
 
+/* Exact sums (row a5).  Every correspondence's 17 terms are rounded ONCE, each to a multiple of its accumulator's quantum
+ * 2^-e, and summed as 64-bit integers from there on (workgroup, 19-way sum, all-reduce): integer addition is associative,
+ * so the sums — and with them every transform — do not depend on how the source cloud is cut into workgroups, launches,
+ * shards or ranks, nor on the order in which a collective adds.  ANY partition of the comparison cloud over ANY number of
+ * contexts / GPUs returns the bits ma_icp returns for the whole cloud on one, PROVIDED the contexts derive the same
+ * exponents e, i.e. agree on what bounds a term: the gold map's box (the same everywhere by construction), the gate (a
+ * parameter), and three numbers of the comparison cloud —
+ *     {n_total: points of the WHOLE cloud, wmax: its largest weight (1 without weights),
+ *      rs: the largest distance of one of its points from the gold map's centring origin (only ungated runs use it)}.
+ * ma_sum_bounds_get returns this context's own three (for its shard); ma_sum_bounds_set installs the whole cloud's:
+ * {sum of the n, max of the wmax, max of the rs} over the shards — which is exactly what a single context holding the whole
+ * cloud derives for itself.  ma_icp_sharded does this exchange itself (one small all-gather per source cloud); callers of
+ * the split stepping below do it with their own collective.  The bounds belong to a source cloud: installing a new one
+ * (or a new gold map) clears them; NULL clears them explicitly.  Without agreed bounds results are still correct to
+ * rounding (1e-12 relative), just not bit-identical across different partitions.
+ * ma_sum_scale_get: the exponents e = {W, s_p, s_q, S, E} in force for a run with these parameters (MA_ACC_LEN int64 v_k
+ * mean v_k 2^-e[group(k)], groups: k = 0 | 1-3 | 4-6 | 7-15 | 16). */
+int ma_sum_bounds_get(ma_ctx* ctx, double out[3]);
+int ma_sum_bounds_set(ma_ctx* ctx, const double in[3] /* NULL: clear */);
+int ma_sum_scale_get(ma_ctx* ctx, const ma_params* params, int32_t out[5]);
+
 /* Split stepping for the sharded-source multi-GPU mode: every rank holds
  * the whole gold map and a shard of the source cloud; per iteration
- *   ma_step_accumulate -> all-reduce(sum) of MA_ACC_LEN doubles (RCCL) -> ma_step_solve.
- * acc_dev is a DEVICE pointer to MA_ACC_LEN doubles owned by the caller (e.g. a torch
- * tensor's data_ptr); accumulators are in the ctx's centred frame, which is identical
- * on all ranks because it derives from the gold map alone.  Nothing here synchronises
- * with the host.
- * Call order: ma_set_gold, ma_set_source (this rank's shard), ma_state_set, then the
+ *   ma_step_accumulate -> all-reduce(sum) of MA_ACC_LEN 64-bit INTEGERS -> ma_step_solve.
+ * acc_dev is a DEVICE pointer to MA_ACC_LEN int64 owned by the caller (e.g. a torch int64
+ * tensor's data_ptr): the fixed-point sums described above, in the ctx's centred frame, which is
+ * identical on all ranks because it derives from the gold map alone.  Sum them as integers
+ * (any order) and hand the totals to ma_step_solve of every rank.  Integers from different contexts may only be added
+ * if all of them were scaled alike, so both calls REQUIRE agreed bounds (ma_sum_bounds_set, above; MA_ERR_STATE without —
+ * a lone context installs its own ma_sum_bounds_get).  Nothing here synchronises
+ * with the host (an ungated run on a cloud made from a depth frame computes that cloud's box
+ * once, in ma_state_set).
+ * Call order: ma_set_gold, ma_set_source (this rank's shard), ma_sum_bounds_set, ma_state_set, then the
  * accumulate / solve pairs.  Installing another gold map or source cloud (ma_set_gold,
  * ma_set_source, ma_set_source_from_depth, ma_map_finish(as_gold)) invalidates the stepping
  * state — its buffers are sized for the clouds it was set for — and ma_step_accumulate /
@@ -333,7 +363,7 @@ int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev);
 /* The same sharded-source loop with the collective INSIDE the library (SURVEY.md §8e,
  * north_star "RCCL-over-xGMI all-reduce only of the per-pair accumulators"): librccl is
  * loaded with dlopen on first use and, per iteration, the library enqueues on the ctx stream
- *   search+accumulate (local shard) -> 19-way sum -> ncclAllReduce(sum, 17 doubles) -> solve
+ *   search+accumulate (local shard) -> 19-way sum -> ncclAllReduce(sum, 17 x int64: exact, order-free) -> solve
  * with the loop in C and no host synchronisation — the loop of ma_icp: the same candidate lists (each rank plans
  * its own shard's; which kernel a rank launches changes no bit of its sums), the same early exit with tol > 0 (decided
  * from the iteration at which the loop stopped, so that every rank issues the same number of collectives), the final

@@ -78,20 +78,46 @@ def accumulate(p_t, q, w, d2):
 
 
 class GoldIndex:
-    """KD-tree over the gold cloud (built once per alignment; row a4)."""
+    """KD-tree over the gold cloud (built once per alignment; row a4).
 
-    def __init__(self, gold, n_jobs=-1):
-        from sklearn.neighbors import NearestNeighbors
+    ``backend="sklearn"`` (default): ``sklearn.neighbors.NearestNeighbors(kd_tree)`` — the "NumPy/scikit-learn path"
+    north_star names, and what ``bench.py`` times as the CPU baseline.  ``backend="ckdtree"``:
+    ``scipy.spatial.cKDTree`` — the same exact nearest neighbour (tests/test_oracle.py holds the two to identical
+    indices), 4-7 times faster per query on the same cores, and able to stop at the gate: with ``radius`` set, a query
+    without a gold point inside it comes back as (index 0, d2 = inf), which the gate of ``icp_step`` gives weight 0
+    either way.  The long equal-iteration-count comparisons of the -m gpu suite (1M and 2M points, 50 iterations) use it
+    so that they fit the driver's time limit at FULL length; nothing about the arithmetic of rows a5-a7 changes."""
 
+    def __init__(self, gold, n_jobs=-1, backend="sklearn"):
         self.gold = np.ascontiguousarray(gold, dtype=np.float64)
         if self.gold.ndim != 2 or self.gold.shape[1] != 3 or self.gold.shape[0] == 0:
             raise ValueError("gold cloud must be a non-empty [M,3] array")
-        self.nn = NearestNeighbors(n_neighbors=1, algorithm="kd_tree", n_jobs=n_jobs)
-        self.nn.fit(self.gold)
+        self.backend = backend
+        self.n_jobs = n_jobs
+        if backend == "sklearn":
+            from sklearn.neighbors import NearestNeighbors
 
-    def query(self, pts):
-        d, j = self.nn.kneighbors(np.ascontiguousarray(pts, dtype=np.float64))
-        return j[:, 0].astype(np.int64), d[:, 0] ** 2
+            self.nn = NearestNeighbors(n_neighbors=1, algorithm="kd_tree", n_jobs=n_jobs)
+            self.nn.fit(self.gold)
+        elif backend == "ckdtree":
+            from scipy.spatial import cKDTree
+
+            self.tree = cKDTree(self.gold, leafsize=16)
+        else:
+            raise ValueError("backend must be 'sklearn' or 'ckdtree'")
+
+    def query(self, pts, radius=None):
+        """(index of the nearest gold point, squared distance) per query.  ``radius`` (ckdtree only; sklearn ignores it
+        and answers in full): nothing farther than this is looked for — such a query returns (0, inf)."""
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        if self.backend == "sklearn":
+            d, j = self.nn.kneighbors(pts)
+            return j[:, 0].astype(np.int64), d[:, 0] ** 2
+        bound = np.inf if radius is None or not np.isfinite(radius) else float(radius) * (1.0 + 1e-9) + 1e-300
+        d, j = self.tree.query(pts, k=1, workers=self.n_jobs if self.n_jobs else 1, distance_upper_bound=bound)
+        j = j.astype(np.int64)
+        j[j >= len(self.gold)] = 0          # "nothing inside the bound": d is inf there
+        return j, d ** 2
 
 
 def nn_bruteforce(gold, pts, chunk=2048):
@@ -125,12 +151,12 @@ def icp_step(index, comp, R, t, max_corr_dist=0.10, weights=None):
     """One iteration at state (R, t): returns (acc17, idx, d2, R_next, t_next, ok)."""
     comp = np.asarray(comp, dtype=np.float64)
     p_t = comp @ R.T + t
-    idx, d2 = index.query(p_t)
+    idx, d2 = index.query(p_t, radius=max_corr_dist)
     gate = d2 <= float(max_corr_dist) ** 2 if np.isfinite(max_corr_dist) else np.ones(len(d2), bool)
     w = gate.astype(np.float64)
     if weights is not None:
         w = w * np.asarray(weights, dtype=np.float64)
-    acc = accumulate(p_t, index.gold[idx], w, d2)
+    acc = accumulate(p_t, index.gold[idx], w, np.where(gate, d2, 0.0))      # (a query cut off at the gate carries d2 = inf and w = 0)
     dR, dt, ok = kabsch_from_acc(acc)
     if not ok:
         return acc, idx, d2, R, t, False
@@ -138,7 +164,7 @@ def icp_step(index, comp, R, t, max_corr_dist=0.10, weights=None):
 
 
 def icp_oracle(gold, comp, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None,
-               weights=None, n_jobs=-1, index=None, keep_nn=False):
+               weights=None, n_jobs=-1, index=None, keep_nn=False, backend="sklearn"):
     """Full loop.  Returns dict(R, t, iterations, rmse, inliers, converged, ok, trace).
 
     ``trace`` is a list of per-iteration dicts {acc, rmse, inliers[, idx, d2]} — the
@@ -147,7 +173,7 @@ def icp_oracle(gold, comp, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None,
     comp = np.asarray(comp, dtype=np.float64)
     if comp.ndim != 2 or comp.shape[1] != 3 or comp.shape[0] == 0:
         raise ValueError("comparison cloud must be a non-empty [N,3] array")
-    index = GoldIndex(gold, n_jobs=n_jobs) if index is None else index
+    index = GoldIndex(gold, n_jobs=n_jobs, backend=backend) if index is None else index
     R, t = as_matrix(init)
     trace = []
     converged = False

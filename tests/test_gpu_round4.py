@@ -33,19 +33,22 @@ NO_MATCH = 0xFFFFFFFF
 def test_config5_2m_resampled_pair_vs_oracle(engine, seed):
     """BASELINE configs[4]: "8 scan-pairs x 2M points each, one pair per GPU" — seeds 0-7, comparison cloud an independent
     resample of the gold surfaces.  One GPU's share of that, through ma_icp, against the oracle at EQUAL
-    iteration count with per-iteration inlier counts and squared-distance sums, as for the 1M headline pair.  An oracle
-    iteration costs 4-9 s at this size, so the iteration count follows the suite's wall-clock budget: at least 8 (the
-    expensive, far-apart iterations, where most of the kernel's code paths run), more when there is room."""
+    iteration count with per-iteration inlier counts and squared-distance sums, as for the 1M headline pair.  On the
+    oracle's cKDTree backend an iteration costs ~1 s at this size (scikit-learn: 4-9 s), so the comparison runs 50
+    iterations — past the first list launches of this pair — unless the suite's wall-clock budget says otherwise: then
+    never fewer than 8, with a warning, and the terminal summary says what ran."""
+    from conftest import record_comparison
     n = 2_000_000
     gold, comp, R0, t0 = syn.make_pair(seed, n)
     engine.set_pair(gold, comp)
-    index = orc.GoldIndex(gold, n_jobs=-1)
+    index = orc.GoldIndex(gold, n_jobs=-1, backend="ckdtree")
     R, t = np.eye(3), np.zeros(3)
     inliers, E = [], []
     # this seed's share of what is left (seed 0 leaves half to seed 1; 60 s stay for the tests after these two)
     share = max(0.0, suite_seconds_left() - 60.0) / (2 - seed)
     t_start = time.perf_counter()
-    k, iters = 0, 24
+    full = 50
+    k, iters = 0, full
     while k < iters:
         acc, _, _, R, t, ok = orc.icp_step(index, comp, R, t, 0.10)
         assert ok
@@ -54,9 +57,16 @@ def test_config5_2m_resampled_pair_vs_oracle(engine, seed):
         k += 1
         if k == 3:
             per_it = (time.perf_counter() - t_start) / 3
-            iters = int(min(24, max(8, share / per_it)))
+            iters = int(min(full, max(8, share / per_it)))
     res = engine.icp(iters, 0.0, 0.10, with_trace=True)
     assert res.iterations == iters
+    record_comparison(f"config5[{seed}]", iters, full, "ckdtree", (time.perf_counter() - t_start) / iters)
+    if iters != full:
+        import warnings
+        warnings.warn(f"config5 seed {seed}: compared after {iters} iterations — SHORTENED from {full}: the suite's wall-clock "
+                      "budget has no room for the full oracle run")
+    else:
+        assert engine.list_stats()["uses"] > 0       # the comparison reached this pair's list launches
     eR, et = orc.rt_error(res.R, res.t, R, t)
     print(f"config5 seed {seed}: 2M-point resampled pair compared after {iters} iterations "
           f"({(time.perf_counter() - t_start) / iters:.2f} s per oracle iteration): |dR|_F = {eR:.2e}, |dt| = {et:.2e} m")
@@ -73,14 +83,15 @@ def test_config5_2m_resampled_pair_vs_oracle(engine, seed):
 
 
 # ----------------------------------------------------------------------------- world sizes 2, 4, 8 on one GPU
-@pytest.mark.parametrize("shards", [2, 4, 8])
+@pytest.mark.parametrize("shards", [2, 4, 8, -3])
 def test_split_stepping_n_shards_of_the_1m_pair_equal_one_context(lib_built, shards):
-    """"world_size in {1,2,4,8} equality of accumulators vs 1-GPU".  The 1M-point benchmark pair, the
-    comparison cloud block-partitioned over `shards` contexts on this one GPU (the partition of mapalign.dist), every
-    context stepping its shard, the 17 sums ADDED IN RANK ORDER and handed back to every context's solve — the data path
-    of ma_icp_sharded with the all-reduce spelled out.  Every iteration's inlier count must be the single context's
-    exactly (the correspondences do not depend on the partition), the sums agree to rounding (another summation order),
-    every shard ends on the same bits as every other, and the transform is the single context's to 1e-11."""
+    """"world_size in {1,2,4,8} equality of accumulators vs 1-GPU" — as EQUALITY OF BITS (round 5: the 17
+    sums are exact fixed-point integers).  The 1M-point benchmark pair, the comparison cloud partitioned over contexts on
+    this one GPU — the block partition of mapalign.dist over 2, 4, 8 shards, and (-3) three shards of very different
+    sizes drawn at random from the cloud, nothing like a block partition — every context stepping its shard with the whole
+    cloud's sum bounds installed, the 17 sums added (in reverse rank order: the order must not matter) and handed back to
+    every context's solve: the data path of ma_icp_sharded with the all-reduce spelled out.  Every iteration's 17 sums,
+    the trace and the final transform must be the single context's BIT FOR BIT."""
     import torch
     from mapalign import dist as mdist
 
@@ -89,25 +100,36 @@ def test_split_stepping_n_shards_of_the_1m_pair_equal_one_context(lib_built, sha
     with mapalign.MapAligner(0) as full:
         full.set_pair(gold, comp)
         ref = full.icp(iters, 0.0, 0.10, with_trace=True, lists=False)
+        ref_lists = full.icp(iters, 0.0, 0.10, with_trace=True)
+        assert np.array_equal(ref_lists.T, ref.T)
+        own = full.sum_bounds()
+    if shards > 0:
+        parts = [np.arange(*mdist.shard_bounds(len(comp), shards, r)) for r in range(shards)]
+    else:
+        owner = np.random.default_rng(5).choice(3, size=len(comp), p=[0.6, 0.3, 0.1])
+        parts = [np.flatnonzero(owner == r) for r in range(3)]
     engs, accs = [], []
-    for r in range(shards):
-        lo, hi = mdist.shard_bounds(len(comp), shards, r)
+    for idx in parts:
         a = mapalign.MapAligner(0)
         a.set_gold(gold)
-        a.set_source(comp[lo:hi])
+        a.set_source(comp[idx])
         he = mdist.HipShardEngine(a, 0.10, 0.0)
         he.bind_current_stream()
-        he.state_set(None)
         engs.append(he)
         accs.append(he.new_acc())
+    whole = mapalign.MapAligner.combine_sum_bounds([he.aligner.sum_bounds() for he in engs])
+    assert whole[0] == own[0] and whole[1] == own[1]             # n_total and wmax: the single context's own
+    for he in engs:
+        he.aligner.set_sum_bounds(whole)
+        he.state_set(None)
     sums = []
     for _ in range(iters):
         for he, acc in zip(engs, accs):
             he.accumulate_into(acc)
-        total = accs[0].clone()
-        for acc in accs[1:]:
-            total += acc                                         # rank order
-        sums.append(total.cpu().numpy().copy())
+        total = accs[-1].clone()
+        for acc in accs[-2::-1]:
+            total += acc                                         # any order: integer sums
+        sums.append(engs[0].aligner.sums_to_float(total.cpu().numpy(), 0.10))
         for he, acc in zip(engs, accs):
             acc.copy_(total)
             he.solve_from(acc)
@@ -118,14 +140,12 @@ def test_split_stepping_n_shards_of_the_1m_pair_equal_one_context(lib_built, sha
     for T, info in states[1:]:
         assert np.array_equal(T, states[0][0]) and info == states[0][1]
     T, info = states[0]
-    assert info["iterations"] == iters and info["inliers"] == ref.inliers
-    assert np.allclose(T, ref.T, atol=1e-11, rtol=0)
-    eR, et = orc.rt_error(T[:3, :3], T[:3, 3], ref.R, ref.t)
-    assert eR <= 1e-11 and et <= 1e-11, (eR, et)
+    assert info["iterations"] == iters and info["inliers"] == ref.inliers and info["rmse"] == ref.rmse
+    assert np.array_equal(T, ref.T)                               # the single GPU's bits
     # the sums are in the contexts' centred frame; W and E do not depend on the frame
     sums = np.array(sums)
-    assert np.array_equal(sums[:, 0], ref.trace[:, 0])            # inlier counts, every iteration, exactly
-    assert np.allclose(sums[:, 16], ref.trace[:, 16], rtol=1e-11, atol=0)
+    assert np.array_equal(sums[:, 0], ref.trace[:, 0])            # inlier counts, every iteration
+    assert np.array_equal(sums[:, 16], ref.trace[:, 16])          # sums of squared distances: the same integers
 
 
 # ----------------------------------------------------------------------------- one tie rule: the promoted fuzz

@@ -147,6 +147,67 @@ int main() {
     const bool refuse_count = !ma::voxel_box(wide_lo, wide_hi, 1.0f, b2, bits2);   // 8e6^3 = 5.1e20 voxels
     std::printf("voxedge %d %llu %d %d %d\n", ok1 ? 1 : 0, b1.d[0] * b1.d[1] * b1.d[2], bits1, refuse_index ? 1 : 0, refuse_count ? 1 : 0);
   }
+  // ---- exact sums: scales chosen from the bounds never overflow; any partition / order gives the same integers;
+  //      the integer sums are at least as close to the exact sums as an fp64 accumulation
+  {
+    int bad = 0;
+    double worst_rel = 0, worst_fp64 = 0;
+    for (int it = 0; it < 300; ++it) {
+      const bool gated = it % 3 != 0;
+      const double qb = std::pow(10.0, 3.0 * U(rng)), gate = gated ? qb * std::pow(10.0, -2.0 + U(rng)) : INFINITY;
+      const double wmax = it % 5 == 0 ? std::pow(10.0, 2.0 * U(rng)) : 1.0, rs = qb * (0.5 + 0.5 * std::fabs(U(rng))), t0 = 3.0 * qb * std::fabs(U(rng));
+      const uint32_t n = 1u + (uint32_t)(rng() % 4000ull);
+      const ma::SumBounds B{(double)n * (double)(1ull << (rng() % 20ull)), wmax, rs};
+      const ma::SumScale sc = ma::sum_scale(B, qb, gate, t0);
+      const double pb = gated ? qb + gate : std::max(rs + t0, 1.7320508075688772 * qb + 2.0 * rs);
+      const double d2max = gated ? gate * gate : 3.0 * (pb + qb) * (pb + qb);
+      // every term AT its bound stays inside the fma's exact window, and n_total of them inside 2^62
+      const double lim[5] = {wmax, wmax * pb, wmax * qb, wmax * pb * qb, wmax * d2max};
+      for (int g = 0; g < 5; ++g) {
+        const double k = std::ldexp(lim[g], sc.e[g]);
+        bad += !(k <= std::ldexp(1.0, 50)) || !(k * B.n_total <= std::ldexp(1.0, 61) * 1.0000001);
+        bad += ma::sum_quantize(lim[g], sc.e[g]) != (long long)std::nearbyint(k);
+        bad += ma::sum_quantize(-lim[g], sc.e[g]) != -(long long)std::nearbyint(k);
+      }
+      // n random correspondences inside the bounds: terms -> integers; three partitions, three orders
+      std::vector<long long> k17((size_t)n * 17);
+      long double exact[17] = {0};
+      double fp64[17] = {0};
+      for (uint32_t i = 0; i < n; ++i) {
+        const double w = wmax * std::fabs(U(rng)), q[3] = {qb * U(rng), qb * U(rng), qb * U(rng)};
+        double p[3];
+        for (int a = 0; a < 3; ++a) p[a] = gated ? q[a] + gate * 0.57 * U(rng) : pb * U(rng);
+        double term[17];
+        term[0] = w;
+        for (int a = 0; a < 3; ++a) { term[1 + a] = w * p[a]; term[4 + a] = w * q[a]; for (int b = 0; b < 3; ++b) term[7 + 3 * a + b] = w * p[a] * q[b]; }
+        term[16] = w * ((p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]));
+        for (int k = 0; k < 17; ++k) {
+          k17[(size_t)i * 17 + k] = ma::sum_quantize(term[k], sc.e[ma::sum_group(k)]);
+          exact[k] += (long double)term[k];
+          fp64[k] += term[k];
+        }
+      }
+      long long fwd[17] = {0}, rev[17] = {0}, parts[17] = {0};
+      for (uint32_t i = 0; i < n; ++i) for (int k = 0; k < 17; ++k) fwd[k] += k17[(size_t)i * 17 + k];
+      for (uint32_t i = n; i-- > 0;) for (int k = 0; k < 17; ++k) rev[k] += k17[(size_t)i * 17 + k];
+      {   // three "ranks" of uneven size, each summed on its own with wrap-around arithmetic, then added in another order
+        unsigned long long r[3][17] = {{0}};
+        for (uint32_t i = 0; i < n; ++i) for (int k = 0; k < 17; ++k) r[(i * 2654435761u >> 7) % 3u][k] += (unsigned long long)k17[(size_t)i * 17 + k];
+        for (int k = 0; k < 17; ++k) parts[k] = (long long)(r[2][k] + r[0][k] + r[1][k]);
+      }
+      for (int k = 0; k < 17; ++k) {
+        bad += fwd[k] != rev[k] || fwd[k] != parts[k];
+        const double back = ma::sum_to_double(fwd[k], sc.e[ma::sum_group(k)]);
+        const double scale = std::ldexp(1.0, -sc.e[ma::sum_group(k)]) * std::sqrt((double)n);     // quanta x sqrt(n): a random walk of n roundings
+        worst_rel = std::max(worst_rel, std::fabs((double)((long double)back - exact[k])) / scale);
+        worst_fp64 = std::max(worst_fp64, std::fabs((double)((long double)fp64[k] - exact[k])) / scale);
+      }
+    }
+    std::printf("sums %d %.3e %.3e\n", bad, worst_rel, worst_fp64);
+    // the benchmark's scale: 1M points, 20 m map, 0.10 m gate
+    const ma::SumScale s1m = ma::sum_scale(ma::SumBounds{1e6, 1.0, 12.0}, 10.3, 0.10, 0.0);
+    std::printf("sums1m %d %d %d %d %d\n", s1m.e[0], s1m.e[1], s1m.e[2], s1m.e[3], s1m.e[4]);
+  }
   // ---- large-coordinate shift of fp64 clouds: none below the threshold, box centre rounded half-to-even above it
   {
     const double lo_s[3] = {-10.0, 2.0, 0.0}, hi_s[3] = {999.0, 3.0, 1.0};
@@ -231,3 +292,17 @@ def test_voxel_box_and_large_coordinate_shift(report):
     s = [float(v) for v in report["shift"][0]]
     assert s[:3] == [0.0, 0.0, 0.0]
     assert s[3:] == [float(np.round(0.5 * (412340.0 + 412351.0))), float(np.round(0.5 * (5234560.5 + 5234574.5))), float(np.round(120.5))]
+
+
+def test_exact_sums_never_overflow_and_do_not_depend_on_partition_or_order(report):
+    """csrc/host_math.h "Exact sums": for 300 random bound sets (gated and ungated, weighted, n_total up to 2^32) every
+    term at its bound stays inside the fma's exact window and n_total of them inside 62 bits; the integer sums of random
+    correspondences are the same forwards, backwards and over three uneven "ranks" added in another order; and read back
+    as numbers they differ from the exact sums (long double) by a random walk of n roundings of at most half a quantum
+    each: below 2 quanta x sqrt(n) in every one of the 5100 sums."""
+    bad, worst_quanta, _ = report["sums"][0]
+    assert int(bad) == 0
+    assert float(worst_quanta) < 2.0, worst_quanta
+    e = [int(v) for v in report["sums1m"][0]]
+    # 1M points, |q| <= 10.3 m, gate 0.10 m: budget 41 bits per term; S's quantum is 2^-34 m^2, E's 2^-47 m^2
+    assert e == [41 - 1, 41 - 4, 41 - 4, 41 - 7, 41 + 6]

@@ -61,6 +61,24 @@ extern "C" int stops_before_batch(int wait_state, int slot_says_done) {
 extern "C" int iterations_enqueued(int max_iter, int iterations_run_at_stop, int slots_in_use) {
   return ma::iterations_enqueued(max_iter, iterations_run_at_stop, slots_in_use != 0);
 }
+// The pinned slot as a host may find it: `landed` says which of its words the posted writes have delivered so far
+// (bit 0: R and t, 1: chk, 2: seq, 3: the flags done / converged / degenerate, 4: iter); the others still hold what the
+// loop put there before the run (icp_loop's invalidation).  Returns slot_ready(slot, want) | done-as-read << 1.
+extern "C" int slot_as_found(const double* R, const double* t, int iter, int done, int converged, int degenerate, int landed, int want) {
+  ma::StateSlot now{}, sl{};
+  for (int i = 0; i < 9; ++i) now.s.R[i] = R[i];
+  for (int i = 0; i < 3; ++i) now.s.t[i] = t[i];
+  now.s.iter = iter; now.s.done = done; now.s.converged = converged; now.s.degenerate = degenerate;
+  now.chk = ma::slot_check(R, t, iter, ma::slot_flags(done, converged, degenerate));
+  now.seq = iter;
+  sl.seq = -1; sl.s.iter = -1; sl.chk = ~0ull; sl.s.R[0] = NAN;      // icp_loop: nothing of an earlier run may pass for this run's slot
+  if (landed & 1) { for (int i = 0; i < 9; ++i) sl.s.R[i] = now.s.R[i]; for (int i = 0; i < 3; ++i) sl.s.t[i] = now.s.t[i]; }
+  if (landed & 2) sl.chk = now.chk;
+  if (landed & 4) sl.seq = now.seq;
+  if (landed & 8) { sl.s.done = now.s.done; sl.s.converged = now.s.converged; sl.s.degenerate = now.s.degenerate; }
+  if (landed & 16) sl.s.iter = now.s.iter;
+  return (ma::slot_ready(&sl, want) ? 1 : 0) | (sl.s.done ? 2 : 0);
+}
 extern "C" void limits(double skin, double* out) {
   const float z[3] = {0, 0, 0};
   ma::ListPlanner P;
@@ -380,6 +398,36 @@ def simulate_host(shim, max_iter, stop_iter, rng, k_plan=K_PLAN):
         enqueued = k + 1
         host_t += rng.uniform(0.0, 0.3)
     return enqueued
+
+
+def test_a_slot_is_taken_only_when_every_word_the_stop_rule_reads_has_landed(shim):
+    """the host's stop rule reads `done` from the slot, so `done` must be under the slot's validity
+    check — a slot whose R, t, chk and seq have landed but whose `done` has not must read as "not here yet" (a rank that
+    took it would enqueue one batch of collectives more than a peer that saw `done`).  Every subset of landed words of the
+    slot of a STOPPING solve (done = 1): ready only when all five groups are there; and the slot of a solve that goes on
+    (done = 0) never reads as stopping."""
+    shim.slot_as_found.restype = C.c_int
+    shim.slot_as_found.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)] + [C.c_int] * 6
+    rng = np.random.default_rng(11)
+    for case in range(50):
+        R = np.linalg.qr(rng.normal(size=(3, 3)))[0].ravel().copy()
+        t = rng.normal(size=3)
+        it = int(rng.integers(1, 4000))
+        Rp, tp = R.ctypes.data_as(C.POINTER(C.c_double)), t.ctypes.data_as(C.POINTER(C.c_double))
+        for done, conv, deg in ((1, 1, 0), (1, 0, 1), (0, 0, 0)):
+            for landed in range(32):
+                r = shim.slot_as_found(Rp, tp, it, done, conv, deg, landed, it)
+                ready, says_done = r & 1, (r >> 1) & 1
+                if landed == 31:
+                    assert ready == 1 and says_done == done
+                elif done:
+                    # anything short of everything: not ready (in particular landed = 0b10111: all but the flags)
+                    assert ready == 0, (case, done, conv, deg, bin(landed))
+                else:
+                    # flags all zero equal the cleared slot's: the remaining words decide; never "done"
+                    assert says_done == 0 and (ready == 0 or landed & 23 == 23)
+            # a slot complete for ANOTHER iteration is not this iteration's
+            assert shim.slot_as_found(Rp, tp, it, done, conv, deg, 31, it + 1) & 1 == 0
 
 
 def test_a_stopped_loop_enqueues_the_same_iterations_whenever_the_host_looks(shim):

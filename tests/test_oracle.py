@@ -237,3 +237,27 @@ def test_lift_boxes_oracle_median_rule_known_answers():
     assert not v.any() and np.isnan(c).all()
     c0, v0 = orc.lift_boxes_oracle([[2.2, 1.9, 3.9, 3.1]], depth, K, T, 1000.0)      # rule 0 beside it: corner pixels
     assert np.allclose(c0[0, :, 2][v0[0]], [1.0, 2.0, 5.0, 4.0][:int(v0[0].sum())]) or v0[0].sum() == 4
+
+
+@pytest.mark.parametrize("seed,n,gate", [(0, 10_000, 0.10), (2, 60_000, 0.10), (4, 20_000, 0.35), (6, 5000, np.inf)])
+def test_ckdtree_backend_is_the_sklearn_oracle(seed, n, gate):
+    """oracle.GoldIndex(backend="ckdtree") — what the long -m gpu comparisons run on — against the default
+    scikit-learn backend: the same nearest neighbour for every query inside the gate (indices identical, squared distances
+    to rounding) in a one-step query, and the same loop — identical inlier counts in every iteration, transforms equal to
+    rounding — over 20 iterations.  (A query the gate cuts off comes back as (0, inf) and weighs nothing.)"""
+    gold, comp, R0, t0 = syn.make_pair(seed, n)
+    a = orc.GoldIndex(gold, n_jobs=1)
+    b = orc.GoldIndex(gold, n_jobs=2, backend="ckdtree")
+    ja, da = a.query(comp)
+    jb, db = b.query(comp, radius=gate)
+    inside = da <= gate ** 2 if np.isfinite(gate) else np.ones(len(da), bool)
+    assert np.array_equal(ja[inside], jb[inside]) and np.allclose(da[inside], db[inside], rtol=1e-14, atol=0)
+    assert np.isinf(db[~inside]).all()
+    jc, dc = b.query(comp)                                    # without a bound: the full answer
+    assert np.array_equal(ja, jc) and np.allclose(da, dc, rtol=1e-14, atol=0)
+    ra = orc.icp_oracle(gold, comp, max_iter=20, max_corr_dist=gate, index=a)
+    rb = orc.icp_oracle(gold, comp, max_iter=20, max_corr_dist=gate, index=b)
+    assert [r["inliers"] for r in ra["trace"]] == [r["inliers"] for r in rb["trace"]]
+    assert np.allclose([r["acc"] for r in ra["trace"]], [r["acc"] for r in rb["trace"]], rtol=1e-12, atol=1e-12)
+    eR, et = orc.rt_error(ra["R"], ra["t"], rb["R"], rb["t"])
+    assert eR < 1e-12 and et < 1e-12, (eR, et)
