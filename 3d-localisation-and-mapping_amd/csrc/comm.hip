@@ -3,6 +3,7 @@
 #include "ma_internal.h"
 #include <rccl/rccl.h>   // types and prototypes only: librccl is loaded with dlopen at ma_comm_init
 #include <dlfcn.h>
+#include <unistd.h>
 
 namespace {
 
@@ -84,14 +85,50 @@ int comm_allreduce_sums(ma_ctx* ctx) {
 // What bounds a correspondence's terms must be the same on every rank, or their fixed-point scales (and with them their
 // integers) differ: the ranks gather each other's (n, wmax, rs) once per source cloud and every one installs
 // (sum n, max wmax, max rs) — the bounds of the whole cloud, which is also what a single GPU holding all of it derives.
+// The same agreement over the peer-to-peer exchange (no RCCL in the process): every rank copies its three numbers, then a
+// tag, into its entry of the bounds area behind the rows of every rank's array, and reads its own array until all g
+// entries carry this agreement's tag.  Host-driven (bootstrap time: once per source cloud), bounded by the exchange's
+// timeout x 5.
+static int p2p_agree_sum_bounds(ma_ctx* ctx, const double mine[3], std::vector<double>& all) {
+  const int g = ctx->xchg_ranks;
+  const unsigned long long gen = ++ctx->xchg_agree_gen;
+  unsigned long long entry[4];
+  std::memcpy(entry, mine, 24);
+  entry[3] = gen;
+  const size_t at = ma::kXBoundsOffset + (size_t)ctx->xchg_rank * 4;
+  for (int r = 0; r < g; ++r) HIPCHK(hipMemcpyAsync(ctx->xchg_peer[r] + at, entry, 24, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));      // the numbers are in place everywhere before any tag is
+  for (int r = 0; r < g; ++r) HIPCHK(hipMemcpyAsync(ctx->xchg_peer[r] + at + 3, entry + 3, 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<unsigned long long> got((size_t)g * 4);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    HIPCHK(hipMemcpyAsync(got.data(), ctx->xchg + ma::kXBoundsOffset, got.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    bool ok = true;
+    for (int r = 0; r < g; ++r) ok = ok && got[(size_t)r * 4 + 3] == gen;
+    if (ok) break;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5 * (long long)ctx->xchg_timeout_ms)) {
+      ctx->xchg_broken = true;
+      return ctx->fail(MA_ERR_COMM, "peer-to-peer exchange: a rank's sum bounds did not arrive (are all ranks in ma_icp_sharded on the same source generation?)");
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  for (int r = 0; r < g; ++r) std::memcpy(&all[(size_t)r * 3], &got[(size_t)r * 4], 24);
+  return MA_OK;
+}
+
 int comm_agree_sum_bounds(ma_ctx* ctx) {
   if (ctx->sum_bounds_set) return MA_OK;
   int rc;
   if ((rc = ensure_source_box(ctx))) return rc;
-  const int g = ctx->comm_ranks;
+  const bool p2p = use_p2p(ctx);
+  const int g = p2p ? ctx->xchg_ranks : ctx->comm_ranks;
   double mine[3] = {(double)ctx->n, ctx->src_wmax, (double)ctx->src_rs};
   std::vector<double> all(3 * (size_t)std::max(g, 1));
-  if (g > 1) {
+  if (g > 1 && p2p) {
+    if ((rc = p2p_agree_sum_bounds(ctx, mine, all))) return rc;
+  } else if (g > 1) {
     const size_t bytes = sizeof(mine);
     HIPCHK(ctx->nn_tmp.ensure(bytes * (size_t)(g + 1)));
     char* base = static_cast<char*>(ctx->nn_tmp.p);
@@ -111,6 +148,28 @@ int comm_agree_sum_bounds(ma_ctx* ctx) {
   ctx->sum_bounds = b;
   ctx->sum_bounds_set = true;
   return MA_OK;
+}
+
+
+// the blob of ma_p2p_export (include/mapalign.h: MA_P2P_BLOB_BYTES opaque bytes)
+struct P2PBlob {
+  unsigned long long magic;
+  long long pid;
+  int device, finegrained;
+  unsigned long long ptr;
+  hipIpcMemHandle_t handle;
+};
+static_assert(sizeof(P2PBlob) <= MA_P2P_BLOB_BYTES, "blob size");
+constexpr unsigned long long kP2PMagic = 0x4D41503250763031ull;      // "MAP2Pv01"
+
+void p2p_release(ma_ctx* ctx) {
+  for (int r = 0; r < ma::kXMaxRanks; ++r) {
+    if (ctx->xchg_peer[r] && ctx->xchg_peer_ipc[r]) (void)hipIpcCloseMemHandle(ctx->xchg_peer[r]);
+    ctx->xchg_peer[r] = nullptr;
+    ctx->xchg_peer_ipc[r] = false;
+  }
+  ctx->xchg_ranks = 0;
+  ctx->xchg_rank = 0;
 }
 
 }  // namespace mai
@@ -195,6 +254,121 @@ int ma_comm_allreduce_f64(ma_ctx* ctx, double* inout, uint64_t count, int op) {
   });
 }
 
+// ---- peer-to-peer exchange: bootstrap ----------------------------------------------------------------------------------------
+// ma_p2p_export: allocate (once) and zero this context's array of rows and describe it in a blob any channel can carry;
+// ma_p2p_init: map every rank's array — a pointer of this very process is used as it is (contexts of one process, on one
+// device or on peers with access enabled), another process's through hipIpcOpenMemHandle.
+int ma_p2p_export(ma_ctx* ctx, void* blob_out) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx || !blob_out) return MA_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  p2p_release(ctx);                     // (a new bootstrap: whatever was mapped before is let go)
+  if (!ctx->xchg) {
+    // fine-grained device memory where the runtime has it (coherent for peers' writes without cache maintenance);
+    // otherwise ordinary device memory — every access to the rows is a system-scope atomic either way
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, ma::kXWords * 8, hipDeviceMallocFinegrained) == hipSuccess && p) {
+      ctx->xchg_finegrained = true;
+    } else {
+      (void)hipGetLastError();
+      p = nullptr;
+      HIPCHK(hipMalloc(&p, ma::kXWords * 8));
+      ctx->xchg_finegrained = false;
+    }
+    ctx->xchg = static_cast<unsigned long long*>(p);
+  }
+  HIPCHK(hipMemsetAsync(ctx->xchg, 0, ma::kXWords * 8, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->xchg_seq = 0;
+  ctx->xchg_agree_gen = 0;
+  ctx->xchg_broken = false;
+  P2PBlob b{};
+  b.magic = kP2PMagic;
+  b.pid = (long long)getpid();
+  b.device = ctx->device;
+  b.finegrained = ctx->xchg_finegrained ? 1 : 0;
+  b.ptr = (unsigned long long)reinterpret_cast<uintptr_t>(ctx->xchg);
+  const hipError_t e = hipIpcGetMemHandle(&b.handle, ctx->xchg);
+  if (e != hipSuccess) {                // same-process ranks need no handle: leave it zeroed and say so only when it is asked for
+    (void)hipGetLastError();
+    std::memset(&b.handle, 0, sizeof(b.handle));
+    b.finegrained |= 2;                 // bit 1: no IPC handle
+  }
+  std::memset(blob_out, 0, MA_P2P_BLOB_BYTES);
+  std::memcpy(blob_out, &b, sizeof(b));
+  return MA_OK;
+  });
+}
+
+int ma_p2p_init(ma_ctx* ctx, const void* blobs, int n_ranks, int rank) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (!blobs || n_ranks < 1 || n_ranks > ma::kXMaxRanks || rank < 0 || rank >= n_ranks)
+    return ctx->fail(MA_ERR_INVALID, "bad arguments (1 <= n_ranks <= 16, 0 <= rank < n_ranks)");
+  if (!ctx->xchg) return ctx->fail(MA_ERR_STATE, "ma_p2p_export first");
+  HIPCHK(hipSetDevice(ctx->device));
+  p2p_release(ctx);
+  const char* base = static_cast<const char*>(blobs);
+  for (int r = 0; r < n_ranks; ++r) {
+    P2PBlob b;
+    std::memcpy(&b, base + (size_t)r * MA_P2P_BLOB_BYTES, sizeof(b));
+    if (b.magic != kP2PMagic) { p2p_release(ctx); return ctx->fail(MA_ERR_INVALID, "blob " + std::to_string(r) + " is not a ma_p2p_export blob"); }
+    if (r == rank) {
+      if (b.pid != (long long)getpid() || b.ptr != (unsigned long long)reinterpret_cast<uintptr_t>(ctx->xchg)) {
+        p2p_release(ctx);
+        return ctx->fail(MA_ERR_INVALID, "blob [rank] is not this context's own export");
+      }
+      ctx->xchg_peer[r] = ctx->xchg;
+    } else if (b.pid == (long long)getpid()) {
+      if (b.device != ctx->device) {     // another device of this process: direct access over xGMI
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, ctx->device, b.device);
+        if (!can) { p2p_release(ctx); return ctx->fail(MA_ERR_COMM, "no peer access between devices " + std::to_string(ctx->device) + " and " + std::to_string(b.device)); }
+        const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { p2p_release(ctx); return ctx->fail(MA_ERR_COMM, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e)); }
+        (void)hipGetLastError();
+      }
+      ctx->xchg_peer[r] = reinterpret_cast<unsigned long long*>(static_cast<uintptr_t>(b.ptr));
+    } else {
+      if (b.finegrained & 2) { p2p_release(ctx); return ctx->fail(MA_ERR_COMM, "rank " + std::to_string(r) + " could not export an IPC handle for its rows (hipIpcGetMemHandle failed there)"); }
+      void* p = nullptr;
+      const hipError_t e = hipIpcOpenMemHandle(&p, b.handle, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess || !p) { (void)hipGetLastError(); p2p_release(ctx); return ctx->fail(MA_ERR_COMM, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(e)); }
+      ctx->xchg_peer[r] = static_cast<unsigned long long*>(p);
+      ctx->xchg_peer_ipc[r] = true;
+    }
+  }
+  ctx->xchg_ranks = n_ranks;
+  ctx->xchg_rank = rank;
+  ctx->xchg_seq = 0;
+  ctx->xchg_agree_gen = 0;
+  ctx->xchg_broken = false;
+  ctx->sum_bounds_set = false;          // (bounds agreed over another group of ranks do not carry over)
+  return MA_OK;
+  });
+}
+
+int ma_p2p_destroy(ma_ctx* ctx) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  p2p_release(ctx);
+  return MA_OK;
+  });
+}
+
+int ma_comm_config(ma_ctx* ctx, int transport) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (transport != MA_TRANSPORT_RCCL && transport != MA_TRANSPORT_P2P) return ctx->fail(MA_ERR_INVALID, "transport: MA_TRANSPORT_RCCL or MA_TRANSPORT_P2P");
+  if (transport != ctx->comm_transport) ctx->sum_bounds_set = ctx->sum_bounds_set && (ctx->comm_ranks == ctx->xchg_ranks);
+  ctx->comm_transport = transport;
+  return MA_OK;
+  });
+}
+
 // One pair over the ranks of the communicator: gold map + grids replicated (every rank called
 // ma_set_gold with the same cloud), this rank's shard of the comparison cloud in ma_set_source.
 // The loop is icp_loop above — the same planner, list launches, pinned slots and early exit as ma_icp, with
@@ -203,7 +377,9 @@ int ma_comm_allreduce_f64(ma_ctx* ctx, double* inout, uint64_t count, int op) {
 int ma_icp_sharded(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16], ma_stats* stats) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;
-  if (ctx->comm && ctx->have_src) {
+  if ((ctx->comm || ctx->xchg_ranks > 0) && ctx->have_src) {
+    if (use_p2p(ctx) && ctx->xchg_broken)
+      return ctx->fail(MA_ERR_COMM, "the peer-to-peer exchange ended a run in a communication failure: set it up again (ma_p2p_export / ma_p2p_init on every rank)");
     HIPCHK(hipSetDevice(ctx->device));
     const int rc = comm_agree_sum_bounds(ctx);
     if (rc) return rc;

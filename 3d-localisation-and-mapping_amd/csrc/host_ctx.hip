@@ -46,6 +46,9 @@ void list_config_from_env(ma_ctx* ctx) {
   e = std::getenv("MAPALIGN_PLANNER_TIMEOUT_US");       // fault injection for the tests: make the planner's wait give up early
   const long t = e ? std::atol(e) : 0;
   if (t >= 1 && t <= 60L * 1000 * 1000) ctx->cfg_planner_timeout_us = (int)t;
+  e = std::getenv("MAPALIGN_P2P_TIMEOUT_MS");           // how long a solving wave waits for its peers' sums (tests shorten it)
+  const long tp = e ? std::atol(e) : 0;
+  if (tp >= 1 && tp <= 30000) ctx->xchg_timeout_ms = (int)tp;
 }
 
 }  // namespace mai
@@ -135,12 +138,15 @@ int ma_destroy(ma_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm) comm_destroy(ctx);
+  p2p_release(ctx);
+  if (ctx->xchg) { (void)hipFree(ctx->xchg); ctx->xchg = nullptr; }
   try {
     for (DevBuf* b : ctx->all_bufs()) b->release();
   } catch (...) {   // (the buffer list is a std::vector: never let its allocation failure cross the ABI)
   }
   if (ctx->host_done) (void)hipHostFree(ctx->host_done);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+  if (ctx->batch_stage) (void)hipHostFree(ctx->batch_stage);
   for (hipEvent_t e : ctx->batch_ev) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->kev) (void)hipEventDestroy(e);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -132,7 +132,8 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
   int rc;
   if ((rc = check_params(ctx, params))) return rc;
   if ((rc = need_ready(ctx))) return rc;
-  if (sharded && !ctx->comm) return ctx->fail(MA_ERR_STATE, "no communicator (ma_comm_init)");
+  if (sharded && !ctx->comm && ctx->xchg_ranks == 0) return ctx->fail(MA_ERR_STATE, "no communicator (ma_comm_init, or ma_p2p_export + ma_p2p_init)");
+  const bool p2p = sharded && use_p2p(ctx);
   if (!T_out) return ctx->fail(MA_ERR_INVALID, "T_out is NULL");
   if (init) for (int i = 0; i < 16; ++i) if (!std::isfinite(init[i])) return ctx->fail(MA_ERR_INVALID, "non-finite init");
   HIPCHK(hipSetDevice(ctx->device));
@@ -288,7 +289,9 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
     if ((rc = launch_nn(ctx, 0, count, best2, nullptr, nullptr, sc, MA_SCHED != 0, kind, k > 0 ? 1 : 0))) return rc;
     if (timek) HIPCHK(hipEventRecord(ctx->kev[2 * k + 1], ctx->stream));
     StateSlot* slot = slots_used ? &ctx->host_slots[k] : nullptr;
-    if (sharded) {
+    if (p2p) {
+      if ((rc = launch_reduce_exchange_solve(ctx, params->tol, sc, slot))) return rc;
+    } else if (sharded) {
       if ((rc = launch_reduce(ctx, MA_SCHED != 0))) return rc;
       if ((rc = comm_allreduce_sums(ctx))) return rc;
       if ((rc = launch_solve(ctx, params->tol, sc, true, slot))) return rc;
@@ -331,6 +334,16 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
   }
   centred_to_world(s, ctx->origin, T_out);
   fill_stats(s, ms, stats);
+  if (p2p) {
+    // iterations the ranks have solved together: the next run's rows go on from here (the same number on every rank —
+    // identical sums, identical states, identical stops)
+    ctx->xchg_seq += (unsigned long long)std::max(s.iter, 0);
+    if (s.degenerate == 2) {
+      ctx->xchg_broken = true;
+      return ctx->fail(MA_ERR_COMM, "peer-to-peer exchange: a peer's sums did not arrive within " + std::to_string(ctx->xchg_timeout_ms) +
+                                    " ms (iteration " + std::to_string(s.iter) + "); the loop was stopped");
+    }
+  }
   if (s.degenerate) return ctx->fail(MA_ERR_DEGENERATE, "no correspondence inside max_corr_dist, or rank-deficient covariance (fewer than 3 non-collinear pairs)");
   return MA_OK;
 }

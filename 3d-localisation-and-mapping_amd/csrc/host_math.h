@@ -150,6 +150,23 @@ inline long long sum_quantize(double term, int e) {
 }
 inline double sum_to_double(long long v, int e) { return std::ldexp((double)v, -e); }
 
+// ---- Peer-to-peer exchange of the sums (row e, comm.hip / kernels_solve.hip k_reduce_exchange_solve) ----------------------
+// Every rank owns an array of rows [kXSlots][kXMaxRanks][kXRowWords] of 8-byte words in its own device memory, mapped into
+// every peer.  Iteration number `seq` (counted over the life of the communicator, the same on every rank) uses slot
+// seq % kXSlots; rank r WRITES its 17 sums into row [slot][r] of every rank's array (its own included), and reads the g rows
+// of that slot in ITS OWN array.  A word is self-validating: the sums are 62-bit integers (host_math.h "Exact sums"), and
+// the two bits above carry a tag that changes with every reuse of the slot — a naturally aligned 8-byte store is atomic,
+// so a word is either the one this iteration wrote or the one of kXSlots iterations ago (different tag), never a mixture.
+// No fence, no checksum, no ordering between words: the writer's stores are all in flight together, the reader polls.
+constexpr int kXSlots = 4, kXMaxRanks = 16, kXRowWords = 32;      // a row: 17 words in use, 256 bytes apart
+constexpr size_t kXBoundsOffset = (size_t)kXSlots * kXMaxRanks * kXRowWords;       // behind the rows: [kXMaxRanks][4] words for the bounds agreement
+constexpr size_t kXWords = kXBoundsOffset + (size_t)kXMaxRanks * 4;
+constexpr unsigned xword_tag(unsigned long long seq) { return (unsigned)((seq / (unsigned)kXSlots) + 1ull) & 3u; }      // (a zeroed buffer reads as tag 0: never the first generation's)
+constexpr unsigned long long xword_encode(long long v, unsigned long long seq) {
+  return ((unsigned long long)v & ((1ull << 62) - 1ull)) | ((unsigned long long)xword_tag(seq) << 62);
+}
+constexpr long long xword_value(unsigned long long w) { return (long long)(w << 2) >> 2; }      // sign-extend bit 61
+
 // strict '<' acceptance against this value implements the inclusive gate d^2 <= gate^2
 inline float open_gate2(double gate) {
   if (!std::isfinite(gate)) return std::numeric_limits<float>::infinity();

@@ -3,7 +3,6 @@
 // sort, fp64 staging, cloud moments (row N1).  Kernels first (anonymous namespace), then the host functions that
 // launch them (namespace mai: ma_internal.h declares the ones other units call).
 #include "ma_internal.h"
-#include <rocprim/rocprim.hpp>    // Onesweep radix sort for clouds above kSortMaxN points (sort_pairs_u32)
 
 namespace {
 
@@ -211,7 +210,9 @@ constexpr int kSortTile = kBlock * kSortItems;        // keys per workgroup
 constexpr int kSortBins = 256;
 static_assert(kSortBins == kBlock, "one thread per digit in the base computation");
 
-__global__ __launch_bounds__(kBlock) void k_sort_hist(const uint32_t* __restrict__ keys, const uint32_t n, const int shift,
+// (KEY: uint32_t — cell keys of the grid builds — or unsigned long long — the voxel keys of the map builder, row N4.)
+template <typename KEY>
+__global__ __launch_bounds__(kBlock) void k_sort_hist(const KEY* __restrict__ keys, const uint32_t n, const int shift,
                                                       const uint32_t nblocks, uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[kSortBins];
   h[threadIdx.x] = 0u;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_sort_hist(const uint32_t* __restrict
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const uint32_t i = base + (uint32_t)j * kBlock + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (kSortBins - 1)], 1u);
+    if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (kSortBins - 1)], 1u);
   }
   __syncthreads();
   hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -247,10 +248,11 @@ __global__ __launch_bounds__(kBlock) void k_sort_rows(uint32_t* __restrict__ his
   if (lane == 0) totals[bin] = run;
 }
 
-__global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+template <typename KEY>
+__global__ __launch_bounds__(kBlock) void k_sort_scatter(const KEY* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                          const uint32_t n, const int shift, const uint32_t nblocks,
                                                          const uint32_t* __restrict__ row_prefix, const uint32_t* __restrict__ totals,
-                                                         uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+                                                         KEY* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
   constexpr int kNW = kBlock / kWave;
   __shared__ uint32_t cnt[kNW][kSortBins];      // per-wavefront digit counts, then per-wavefront output bases
   __shared__ uint32_t wave_tot[kNW];
@@ -273,13 +275,14 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
   // stable ranks inside the wavefront's segment of the tile
   const uint32_t seg = blockIdx.x * (uint32_t)kSortTile + (uint32_t)w * (uint32_t)(kWave * kSortItems);
   const unsigned long long lt = (1ull << lane) - 1ull;
-  uint32_t key[kSortItems], rank[kSortItems];
+  KEY key[kSortItems];
+  uint32_t rank[kSortItems];
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const uint32_t i = seg + (uint32_t)j * kWave + (uint32_t)lane;
     const bool valid = i < n;
-    key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
-    const uint32_t d = (key[j] >> shift) & (kSortBins - 1);
+    key[j] = valid ? keys_in[i] : (KEY)~(KEY)0;
+    const uint32_t d = (uint32_t)(key[j] >> shift) & (kSortBins - 1);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -309,10 +312,81 @@ __global__ __launch_bounds__(kBlock) void k_sort_scatter(const uint32_t* __restr
   for (int j = 0; j < kSortItems; ++j) {
     const uint32_t i = seg + (uint32_t)j * kWave + (uint32_t)lane;
     if (i < n) {
-      const uint32_t pos = cnt[w][(key[j] >> shift) & (kSortBins - 1)] + rank[j];
+      const uint32_t pos = cnt[w][(uint32_t)(key[j] >> shift) & (kSortBins - 1)] + rank[j];
       keys_out[pos] = key[j];
       vals_out[pos] = vals_in[i];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Exclusive prefix sum of 32-bit words (scan_exclusive_u32): tile sums, tile offsets, tiles
+// ---------------------------------------------------------------------------------------
+// A thread owns kSortItems CONSECUTIVE words of its workgroup's tile (two 16-byte loads), so its local prefix is a short
+// serial chain; the threads' totals are scanned by wavefront (shuffles) and across the four wavefronts through LDS.
+__device__ __forceinline__ uint32_t block_exclusive_scan(const uint32_t mine, uint32_t* sh_wave /*[kBlock / kWave]*/, uint32_t& block_total) {
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const uint32_t u = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += u;
+  }
+  if (lane == kWave - 1) sh_wave[w] = incl;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < kBlock / kWave; ++k) {
+    const uint32_t t = sh_wave[k];
+    before += k < w ? t : 0u;
+    total += t;
+  }
+  block_total = total;
+  return before + incl - mine;
+}
+__global__ __launch_bounds__(kBlock) void k_scan_tile_sums(const uint32_t* __restrict__ in, const uint32_t n, uint32_t* __restrict__ tile) {
+  const uint32_t first = blockIdx.x * (uint32_t)kSortTile + threadIdx.x * (uint32_t)kSortItems;
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) s += first + j < n ? in[first + j] : 0u;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
+  __shared__ uint32_t part[kBlock / kWave];
+  if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) t += part[w];
+    tile[blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_scan_offsets(uint32_t* __restrict__ tile, const uint32_t ntiles) {
+  __shared__ uint32_t sh_wave[kBlock / kWave];
+  uint32_t run = 0;
+  for (uint32_t t0 = 0; t0 < ntiles; t0 += kBlock) {
+    const uint32_t i = t0 + threadIdx.x;
+    const uint32_t v = i < ntiles ? tile[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, sh_wave, total);
+    if (i < ntiles) tile[i] = run + ex;
+    run += total;
+    __syncthreads();                    // sh_wave is reused by the next trip
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(const uint32_t* __restrict__ in, const uint32_t n, const uint32_t* __restrict__ tile,
+                                                       uint32_t* __restrict__ out) {
+  __shared__ uint32_t sh_wave[kBlock / kWave];
+  const uint32_t first = blockIdx.x * (uint32_t)kSortTile + threadIdx.x * (uint32_t)kSortItems;
+  uint32_t v[kSortItems], s = 0;
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) { v[j] = first + j < n ? in[first + j] : 0u; s += v[j]; }
+  uint32_t total;
+  uint32_t run = tile[blockIdx.x] + block_exclusive_scan(s, sh_wave, total);
+#pragma unroll
+  for (int j = 0; j < kSortItems; ++j) {
+    if (first + j < n) out[first + j] = run;
+    run += v[j];
   }
 }
 
@@ -653,42 +727,62 @@ int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float
   if (bad > 0) return ctx->fail(MA_ERR_INVALID, "cloud has non-finite coordinates (filter them first, as the reference's read_point_cloud(remove_nan_points=True, remove_infinite_points=True) does)");
   return MA_OK;
 }
-// Stable radix sort of (cell key, index) pairs: the three-kernel passes above for clouds of up to kSortMaxN points,
-// rocPRIM's Onesweep (one look-back-chained launch per 8 key bits; the library's choice above 2^20 items anyway)
-// beyond.  Two-call pattern of the library: tmp == nullptr asks for the temporary bytes.  The inputs are left intact.
-constexpr uint32_t kSortMaxN = 4u << 20;
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config,
-                                              (size_t)65536>;
+// Stable radix sort of (key, index) pairs, 32- or 64-bit keys: the three-kernel passes above.  Two-call pattern:
+// tmp == nullptr asks for the temporary bytes.  The inputs are left intact.
+// (Round 4 handed clouds above 4M points to rocPRIM's Onesweep: with the scans below that was the last use of a library
+// primitive in the product; round 5 measures the own passes there too — profiles/r05_variants_ab.txt — and drops it.)
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
-hipError_t sort_pairs_u32(void* tmp, size_t& tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                          uint32_t* vals_out, uint32_t n, int bits, hipStream_t stream) {
-  if (n > kSortMaxN)
-    return rocprim::radix_sort_pairs<SortConfig>(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                                 (unsigned)bits, stream);
+template <typename KEY>
+static hipError_t sort_pairs_impl(void* tmp, size_t& tmp_bytes, const KEY* keys_in, KEY* keys_out, const uint32_t* vals_in,
+                                  uint32_t* vals_out, uint32_t n, int bits, hipStream_t stream) {
   const uint32_t nblocks = div_up(n, (uint32_t)kSortTile);
-  const size_t pair_bytes = align256((size_t)n * 4), hist_bytes = align256((size_t)kSortBins * nblocks * 4);
-  const size_t need = 2 * pair_bytes + hist_bytes + align256(kSortBins * 4);
+  const size_t key_bytes = align256((size_t)n * sizeof(KEY)), val_bytes = align256((size_t)n * 4),
+               hist_bytes = align256((size_t)kSortBins * nblocks * 4);
+  const size_t need = key_bytes + val_bytes + hist_bytes + align256(kSortBins * 4);
   if (!tmp) { tmp_bytes = need; return hipSuccess; }
   if (tmp_bytes < need) return hipErrorInvalidValue;
   char* base = static_cast<char*>(tmp);
-  uint32_t* t_keys = reinterpret_cast<uint32_t*>(base);
-  uint32_t* t_vals = reinterpret_cast<uint32_t*>(base + pair_bytes);
-  uint32_t* hist = reinterpret_cast<uint32_t*>(base + 2 * pair_bytes);
-  uint32_t* totals = reinterpret_cast<uint32_t*>(base + 2 * pair_bytes + hist_bytes);
+  KEY* t_keys = reinterpret_cast<KEY*>(base);
+  uint32_t* t_vals = reinterpret_cast<uint32_t*>(base + key_bytes);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(base + key_bytes + val_bytes);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(base + key_bytes + val_bytes + hist_bytes);
   const int passes = std::max(1, (bits + 7) / 8);
-  const uint32_t* src_k = keys_in;
+  const KEY* src_k = keys_in;
   const uint32_t* src_v = vals_in;
   for (int p = 0; p < passes; ++p) {
     const bool to_out = ((passes - 1 - p) & 1) == 0;       // the last pass writes the caller's output; alternate backwards from there
-    uint32_t* dst_k = to_out ? keys_out : t_keys;
+    KEY* dst_k = to_out ? keys_out : t_keys;
     uint32_t* dst_v = to_out ? vals_out : t_vals;
-    hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(kBlock), 0, stream, src_k, n, 8 * p, nblocks, hist);
+    hipLaunchKernelGGL(k_sort_hist<KEY>, dim3(nblocks), dim3(kBlock), 0, stream, src_k, n, 8 * p, nblocks, hist);
     hipLaunchKernelGGL(k_sort_rows, dim3(kSortBins / (kBlock / kWave)), dim3(kBlock), 0, stream, hist, nblocks, totals);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(kBlock), 0, stream, src_k, src_v, n, 8 * p, nblocks,
+    hipLaunchKernelGGL(k_sort_scatter<KEY>, dim3(nblocks), dim3(kBlock), 0, stream, src_k, src_v, n, 8 * p, nblocks,
                        (const uint32_t*)hist, (const uint32_t*)totals, dst_k, dst_v);
     src_k = dst_k;
     src_v = dst_v;
   }
+  return hipGetLastError();
+}
+hipError_t sort_pairs_u32(void* tmp, size_t& tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                          uint32_t* vals_out, uint32_t n, int bits, hipStream_t stream) {
+  return sort_pairs_impl<uint32_t>(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, bits, stream);
+}
+hipError_t sort_pairs_u64(void* tmp, size_t& tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
+                          const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, int bits, hipStream_t stream) {
+  return sort_pairs_impl<unsigned long long>(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, bits, stream);
+}
+
+// Exclusive prefix sum of n 32-bit words (out[i] = in[0] + ... + in[i-1]; out may be in), three launches: every workgroup
+// sums its tile of 2048 words, ONE workgroup turns the tile sums into tile offsets (a running total carried through its
+// loop), every workgroup scans its tile from its offset.  tmp: one word per tile (scan_tmp_bytes).  What the rank map of a
+// cloud with holes and the voxel numbering of the map builder need (both once per cloud, outside the loop).
+size_t scan_tmp_bytes(uint32_t n) { return align256((size_t)div_up(std::max<uint32_t>(n, 1), (uint32_t)kSortTile) * 4); }
+hipError_t scan_exclusive_u32(void* tmp, const uint32_t* in, uint32_t* out, uint32_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const uint32_t ntiles = div_up(n, (uint32_t)kSortTile);
+  uint32_t* tile = static_cast<uint32_t*>(tmp);
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(kBlock), 0, stream, in, n, tile);
+  hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(kBlock), 0, stream, tile, ntiles);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kBlock), 0, stream, in, n, (const uint32_t*)tile, out);
   return hipGetLastError();
 }
 

@@ -2,7 +2,6 @@
 // map builder: voxel keys, sort, per-voxel centroids) and the kernels that hand stored points back to the caller; then
 // the host functions and C entry points that launch them.
 #include "ma_internal.h"
-#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -38,10 +37,25 @@ __device__ __forceinline__ double depth_z(const T* __restrict__ depth, uint32_t 
 // them) to keep 99.9999 % valid pixels where they already were.
 // Algorithmic bytes: w h sizeof(depth) read + 16 w h written (24.6 MB for configs[2]).
 
-template <typename T>
+// BATCH (row N4, ma_map_add_depth_batch): blockIdx.y is the frame — frames stored back to back, outputs back to back,
+// one camera->world pose per frame read from `poses` (12 doubles each, the translation already minus the map origin) —
+// so that the n frames of a map cost one launch.  The point of a pixel is formed by the same spelled-out operations
+// either way, so a batch of n frames writes the bits of n single calls.
+template <typename T, bool BATCH>
 __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ depth, const int width,
-                                                      const uint32_t npx, const Pinhole cam,
+                                                      const uint32_t npx, const Pinhole cam, const double* __restrict__ poses,
                                                       uint32_t* __restrict__ counts, float4* __restrict__ out) {
+  double T12[12];
+  if (BATCH) {
+    depth += (size_t)blockIdx.y * npx;
+    out += (size_t)blockIdx.y * npx;
+    counts += (size_t)blockIdx.y * gridDim.x;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T12[k] = poses[12 * (size_t)blockIdx.y + k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T12[k] = cam.T[k];
+  }
   const uint32_t first = blockIdx.x * kPxPerBlock + threadIdx.x * kPxPerThread;
   double z[kPxPerThread];
   if (first + kPxPerThread <= npx && (reinterpret_cast<uintptr_t>(depth + first) & (sizeof(T) * kPxPerThread - 1)) == 0) {
@@ -66,9 +80,9 @@ __global__ __launch_bounds__(kBlock) void k_unproject(const T* __restrict__ dept
       if (ok) {
         const double X = ((double)u - cam.cx) * z[k] * cam.fx_inv;
         const double Y = ((double)v - cam.cy) * z[k] * cam.fy_inv;
-        p.x = (float)(cam.T[0] * X + cam.T[1] * Y + cam.T[2] * z[k] + cam.T[3]);
-        p.y = (float)(cam.T[4] * X + cam.T[5] * Y + cam.T[6] * z[k] + cam.T[7]);
-        p.z = (float)(cam.T[8] * X + cam.T[9] * Y + cam.T[10] * z[k] + cam.T[11]);
+        p.x = (float)__fma_rn(T12[0], X, __fma_rn(T12[1], Y, __fma_rn(T12[2], z[k], T12[3])));
+        p.y = (float)__fma_rn(T12[4], X, __fma_rn(T12[5], Y, __fma_rn(T12[6], z[k], T12[7])));
+        p.z = (float)__fma_rn(T12[8], X, __fma_rn(T12[9], Y, __fma_rn(T12[10], z[k], T12[11])));
         p.w = 1.0f;
         ++cnt;
       } else {
@@ -425,11 +439,11 @@ static int unproject_frame(ma_ctx* ctx, int dtype, int width, uint32_t npx, cons
   }
   HIPCHK(hipEventRecord(ctx->evu0, ctx->stream));
   if (dtype == 0)
-    hipLaunchKernelGGL(k_unproject<float>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(), width, npx, cam,
-                       counts, out);
+    hipLaunchKernelGGL((k_unproject<float, false>), dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<float>(), width, npx, cam,
+                       (const double*)nullptr, counts, out);
   else
-    hipLaunchKernelGGL(k_unproject<uint16_t>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<uint16_t>(), width, npx,
-                       cam, counts, out);
+    hipLaunchKernelGGL((k_unproject<uint16_t, false>), dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->depth_in.as<uint16_t>(), width, npx,
+                       cam, (const double*)nullptr, counts, out);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->evu1, ctx->stream));
   if (!pinned) {
@@ -476,10 +490,8 @@ int source_map(ma_ctx* ctx, const uint32_t** map) {
     hipLaunchKernelGGL(k_hole_flags, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->src.as<float4>(), n,
                        ctx->keys_a.as<uint32_t>());
     HIPCHK(hipGetLastError());
-    size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), (int)n, ctx->stream));
-    HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), (int)n, ctx->stream));
+    HIPCHK(ctx->cub_tmp.ensure(scan_tmp_bytes(n)));
+    HIPCHK(scan_exclusive_u32(ctx->cub_tmp.p, ctx->keys_a.as<uint32_t>(), ctx->keys_b.as<uint32_t>(), n, ctx->stream));
     hipLaunchKernelGGL(k_rank_map, dim3(div_up(n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->keys_a.as<uint32_t>(),
                        ctx->keys_b.as<uint32_t>(), n, ctx->src_perm.as<uint32_t>());
     HIPCHK(hipGetLastError());
@@ -600,6 +612,84 @@ int ma_map_add_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int h
   });
 }
 
+// Row N4 for a whole run of frames (pose_processor.py:88-122 is the reference's per-frame loop): ONE upload of n_frames
+// frames stored back to back, one upload of their poses, ONE k_unproject launch (blockIdx.y = frame), one copy of the
+// per-workgroup counts, one synchronisation — a single frame is launch-bound (24.6 MB in 11 us: 0.28 of the HBM roofline),
+// a batch of them is not.  The map holds exactly what n_frames ma_map_add_depth calls would have put there.
+int ma_map_add_depth_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int width, int height, uint32_t n_frames,
+                           const float K[4], const double* T_cam_to_world, float depth_scale, uint64_t* n_added) {
+  return guarded(ctx, [&]() -> int {
+  if (!ctx) return MA_ERR_INVALID;
+  if (ctx->map_cap == 0) return ctx->fail(MA_ERR_STATE, "ma_map_begin first");
+  if (!depth_frames || !K || !T_cam_to_world) return ctx->fail(MA_ERR_INVALID, "NULL argument");
+  if (dtype != 0 && dtype != 1) return ctx->fail(MA_ERR_INVALID, "dtype must be 0 (float32) or 1 (uint16)");
+  if (width <= 0 || height <= 0 || (uint64_t)width * height >= 0xFFFFFFFEull || n_frames == 0 || n_frames > 65535u)
+    return ctx->fail(MA_ERR_INVALID, "bad image size / frame count (1..65535 frames)");
+  if (!(K[0] != 0.f) || !(K[1] != 0.f) || !(depth_scale > 0.f) || !std::isfinite(depth_scale)) return ctx->fail(MA_ERR_INVALID, "bad intrinsics / depth_scale");
+  for (uint64_t i = 0; i < 16ull * n_frames; ++i) if (!std::isfinite(T_cam_to_world[i])) return ctx->fail(MA_ERR_INVALID, "non-finite camera pose");
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t npx = (uint32_t)((uint64_t)width * height);
+  const uint64_t total_px = (uint64_t)npx * n_frames;
+  if (ctx->map_n + total_px > ctx->map_cap) return ctx->fail(MA_ERR_TOO_LARGE, "map capacity exceeded (ma_map_begin capacity_points)");
+  if (!ctx->map_has_origin) {   // points are stored relative to the first camera position (fp32 precision)
+    for (int r = 0; r < 3; ++r) ctx->map_origin[r] = std::round(T_cam_to_world[4 * r + 3]);
+    ctx->map_has_origin = true;
+  }
+  { const int rc0 = finish_unproject(ctx); if (rc0) return rc0; }      // an earlier frame's count still pending in the pinned block
+  const size_t esz = dtype == 0 ? 4 : 2, frame_bytes = (size_t)npx * esz;
+  const uint32_t nb = div_up(npx, kPxPerBlock);
+  const size_t n_counts = (size_t)nb * n_frames;
+  // the poses as the kernel reads them (make_pinhole's rows, translation minus the map origin), and the counts coming
+  // back, through one pinned staging block
+  const size_t pose_bytes = (size_t)n_frames * 12 * sizeof(double), stage_bytes = pose_bytes + n_counts * 4;
+  if (ctx->batch_stage_cap < stage_bytes) {
+    if (ctx->batch_stage) (void)hipHostFree(ctx->batch_stage);
+    ctx->batch_stage = nullptr;
+    ctx->batch_stage_cap = 0;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->batch_stage), stage_bytes + stage_bytes / 4, hipHostMallocDefault));
+    ctx->batch_stage_cap = stage_bytes + stage_bytes / 4;
+  }
+  double* h_poses = reinterpret_cast<double*>(ctx->batch_stage);
+  uint32_t* h_counts = reinterpret_cast<uint32_t*>(ctx->batch_stage + pose_bytes);
+  Pinhole cam0{};
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const Pinhole cam = make_pinhole(K, T_cam_to_world + 16 * (size_t)f, depth_scale, ctx->map_origin);
+    if (f == 0) cam0 = cam;
+    for (int k = 0; k < 12; ++k) h_poses[(size_t)f * 12 + k] = cam.T[k];
+  }
+  HIPCHK(ctx->lift_frames.ensure(frame_bytes * n_frames));
+  HIPCHK(ctx->lift_poses.ensure(pose_bytes));
+  HIPCHK(ctx->unproj_cnt.ensure(n_counts * 4));
+  HIPCHK(hipMemcpyAsync(ctx->lift_frames.p, depth_frames, frame_bytes * n_frames, hipMemcpyDefault, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->lift_poses.p, h_poses, pose_bytes, hipMemcpyHostToDevice, ctx->stream));
+  float4* out = ctx->map_pts.as<float4>() + ctx->map_n;
+  HIPCHK(hipEventRecord(ctx->evu0, ctx->stream));
+  if (dtype == 0)
+    hipLaunchKernelGGL((k_unproject<float, true>), dim3(nb, n_frames), dim3(kBlock), 0, ctx->stream, ctx->lift_frames.as<float>(), width, npx,
+                       cam0, ctx->lift_poses.as<double>(), ctx->unproj_cnt.as<uint32_t>(), out);
+  else
+    hipLaunchKernelGGL((k_unproject<uint16_t, true>), dim3(nb, n_frames), dim3(kBlock), 0, ctx->stream, ctx->lift_frames.as<uint16_t>(), width,
+                       npx, cam0, ctx->lift_poses.as<double>(), ctx->unproj_cnt.as<uint32_t>(), out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->evu1, ctx->stream));
+  HIPCHK(hipMemcpyAsync(h_counts, ctx->unproj_cnt.p, n_counts * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->evu0, ctx->evu1));
+  ctx->last_op_ms = ms;                  // the one launch (ma_last_device_ms)
+  uint64_t all = 0;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    uint64_t t = 0;
+    for (uint32_t b = 0; b < nb; ++b) t += h_counts[(size_t)f * nb + b];
+    if (n_added) n_added[f] = t;
+    all += t;
+  }
+  ctx->map_n += total_px;
+  ctx->map_valid += all;
+  return MA_OK;
+  });
+}
+
 int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t* n_io) {
   return guarded(ctx, [&]() -> int {
   if (!ctx || !n_io) return MA_ERR_INVALID;
@@ -632,21 +722,15 @@ int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t
                      inv_voxel, box, hole_key, ctx->map_keys_a.as<unsigned long long>(), ctx->vals_a.as<uint32_t>());
   HIPCHK(hipGetLastError());
   size_t tmp_bytes = 0;
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, ctx->map_keys_a.as<unsigned long long>(),
-                                            ctx->map_keys_b.as<unsigned long long>(), ctx->vals_a.as<uint32_t>(),
-                                            ctx->vals_b.as<uint32_t>(), (int)nslots, 0, sort_bits, ctx->stream));
-  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-  HIPCHK(hipcub::DeviceRadixSort::SortPairs(ctx->cub_tmp.p, tmp_bytes, ctx->map_keys_a.as<unsigned long long>(),
-                                            ctx->map_keys_b.as<unsigned long long>(), ctx->vals_a.as<uint32_t>(),
-                                            ctx->vals_b.as<uint32_t>(), (int)nslots, 0, sort_bits, ctx->stream));
+  HIPCHK(sort_pairs_u64(nullptr, tmp_bytes, ctx->map_keys_a.as<unsigned long long>(), ctx->map_keys_b.as<unsigned long long>(),
+                        ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), nslots, sort_bits, ctx->stream));
+  HIPCHK(ctx->cub_tmp.ensure(std::max(tmp_bytes, scan_tmp_bytes(n + 1))));
+  HIPCHK(sort_pairs_u64(ctx->cub_tmp.p, tmp_bytes, ctx->map_keys_a.as<unsigned long long>(), ctx->map_keys_b.as<unsigned long long>(),
+                        ctx->vals_a.as<uint32_t>(), ctx->vals_b.as<uint32_t>(), nslots, sort_bits, ctx->stream));
   hipLaunchKernelGGL(k_voxel_heads, dim3(div_up((uint64_t)n + 1, kBlock)), dim3(kBlock), 0, ctx->stream,
                      ctx->map_keys_b.as<unsigned long long>(), n, ctx->map_flags.as<uint32_t>());
   HIPCHK(hipGetLastError());
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ctx->map_flags.as<uint32_t>(), ctx->map_seg.as<uint32_t>(),
-                                          (int)(n + 1), ctx->stream));
-  HIPCHK(ctx->cub_tmp.ensure(tmp_bytes));
-  HIPCHK(hipcub::DeviceScan::ExclusiveSum(ctx->cub_tmp.p, tmp_bytes, ctx->map_flags.as<uint32_t>(),
-                                          ctx->map_seg.as<uint32_t>(), (int)(n + 1), ctx->stream));
+  HIPCHK(scan_exclusive_u32(ctx->cub_tmp.p, ctx->map_flags.as<uint32_t>(), ctx->map_seg.as<uint32_t>(), n + 1, ctx->stream));
   uint32_t nvox = 0;
   HIPCHK(hipMemcpyAsync(&nvox, ctx->map_seg.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -289,9 +289,131 @@ __global__ __launch_bounds__(kWave) void k_begin_run(const DevState s, const Lis
                                                      ListCtl* __restrict__ lc) {
   if (threadIdx.x == 0) { *st = s; *lc = c; }
 }
+// Row e without a library collective: a5 (final sum) + the EXCHANGE + a6 + a7 in one launch — a sharded iteration is two
+// launches, as an unsharded one is.  The 19 summing workgroups are k_reduce_solve's; the first wavefront of the one
+// that arrives last then
+//   1. writes this rank's 17 sums, one 8-byte word per lane, into its row of the iteration's slot in EVERY rank's array
+//      (host_math.h "Peer-to-peer exchange": tagged, self-validating words; system-scope stores, all in flight together);
+//   2. polls the g rows of that slot in its OWN array until every word carries this iteration's tag — bounded: after
+//      `timeout_ticks` of the 100 MHz clock the loop stops with degenerate = 2 (the host reports MA_ERR_COMM), so every
+//      wave leaves the kernel whatever the peers do;
+//   3. adds the g rows (integers: any order gives the same bits), converts, and lane 0 solves.
+// Every rank computes the same sums, hence the same state: nothing else is exchanged.
+struct XPeers {
+  unsigned long long* rows[ma::kXMaxRanks];
+  int n_ranks, rank;
+};
+__global__ __launch_bounds__(kBlock) void k_reduce_exchange_solve(
+    const long long* __restrict__ partials, const int G, DevState* __restrict__ st, long long* __restrict__ acc_out,
+    uint32_t* __restrict__ ticket, double* __restrict__ trace, const int trace_cap, const double tol,
+    const uint32_t* __restrict__ wg_cost, uint32_t* __restrict__ order, const uint32_t gshift, int* __restrict__ host_done,
+    DevState* __restrict__ host_mirror, StateSlot* __restrict__ slot, const SumScale sc, const XPeers xp,
+    const unsigned long long seq_base, const unsigned long long timeout_ticks) {
+  const int done = st->done;
+  if (blockIdx.x == kNAcc) {
+    rank_groups(G, wg_cost, order, gshift, done);
+    return;
+  }
+  const int k = blockIdx.x;
+  const int it_now = st->iter;
+  DevState s0;
+  if (threadIdx.x == 0) s0 = *st;
+  const long long* __restrict__ p = partials + (size_t)k * G;
+  unsigned long long v = 0ull;
+  for (int b0 = threadIdx.x; b0 < G; b0 += 16 * kBlock) {
+    long long u[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int b = b0 + t * kBlock;
+      u[t] = b < G ? p[b] : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v += (unsigned long long)u[t];
+  }
+  if (done) return;
+  __shared__ unsigned long long red[kBlock / kWave];
+  __shared__ uint32_t sh_last;
+  v = wave_sum_u64(v);
+  if ((threadIdx.x & (kWave - 1)) == kSumLane) red[threadIdx.x / kWave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long sum = (long long)(red[0] + red[1] + red[2] + red[3]);
+    __hip_atomic_store(&acc_out[k], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t arrived = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    sh_last = arrived == (uint32_t)(kNAcc - 1) ? 1u : 0u;
+    if (sh_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  }
+  __syncthreads();
+  if (!sh_last || threadIdx.x >= kWave) return;
+  // ---- the first wavefront of the last arriver: exchange and solve
+  const int lane = threadIdx.x;
+  const unsigned long long seq = seq_base + (unsigned long long)it_now;
+  const uint32_t xslot = (uint32_t)(seq % (unsigned long long)ma::kXSlots);
+  const uint32_t tag = ma::xword_tag(seq);
+  const long long mine = lane < kNAcc ? __hip_atomic_load(&acc_out[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  if (lane < ma::kAccLen) {
+    const unsigned long long w = ma::xword_encode(mine, seq);
+    const size_t at = ((size_t)xslot * ma::kXMaxRanks + (size_t)xp.rank) * ma::kXRowWords + (size_t)lane;
+    for (int r = 0; r < xp.n_ranks; ++r) __hip_atomic_store(xp.rows[r] + at, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const unsigned long long* my = xp.rows[xp.rank] + (size_t)xslot * ma::kXMaxRanks * ma::kXRowWords;
+  unsigned long long total = 0ull;
+  bool arrived_all = false;
+  const unsigned long long t_wait = wall_clock64();
+  for (;;) {
+    bool all = true;
+    total = 0ull;
+    if (lane < ma::kAccLen) {
+      for (int r = 0; r < xp.n_ranks; ++r) {
+        const unsigned long long w = __hip_atomic_load(my + (size_t)r * ma::kXRowWords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        all = all && (uint32_t)(w >> 62) == tag;
+        total += (unsigned long long)ma::xword_value(w);
+      }
+    }
+    if (__ballot(!all) == 0ull) { arrived_all = true; break; }
+    if (wall_clock64() - t_wait > timeout_ticks) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  const double mine_value = lane < ma::kAccLen ? sum_value((long long)total, lane, sc) : (double)mine;     // lanes 17, 18: this rank's work counters
+  double a[kNAcc];
+#pragma unroll
+  for (int t = 0; t < kNAcc; ++t) a[t] = __shfl(mine_value, t, kWave);
+  if (lane != 0) return;
+  if (!arrived_all) {
+    // a peer's rows did not come: stop the loop where it stands (every rank whose peers are silent does the same after
+    // its own wait) and say why — degenerate = 2 is MA_ERR_COMM on the host
+    s0.iter = it_now + 1;
+    s0.degenerate = 2;
+    s0.done = 1;
+    *st = s0;
+    if (host_mirror) *host_mirror = s0;
+    if (host_done) *host_done = s0.iter;
+    if (slot) {
+      *const_cast<unsigned long long*>(&slot->chk) = slot_check(s0.R, s0.t, s0.iter, slot_flags(s0.done, s0.converged, s0.degenerate));
+      *const_cast<int*>(&slot->seq) = s0.iter;
+    }
+    return;
+  }
+  solve_step<true>(a, s0, st, trace, trace_cap, tol, host_done, host_mirror, slot);
+}
+
 }  // namespace
 
 namespace mai {
+
+int launch_reduce_exchange_solve(ma_ctx* ctx, double tol, const SumScale& sc, StateSlot* slot) {
+  XPeers xp{};
+  for (int r = 0; r < ctx->xchg_ranks; ++r) xp.rows[r] = ctx->xchg_peer[r];
+  xp.n_ranks = ctx->xchg_ranks;
+  xp.rank = ctx->xchg_rank;
+  const unsigned long long ticks = (unsigned long long)ctx->xchg_timeout_ms * 100000ull;      // wall_clock64: 100 MHz
+  hipLaunchKernelGGL(k_reduce_exchange_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<long long>(),
+                     ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<long long>(), ctx->ticket.as<uint32_t>(),
+                     ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(), ctx->seg_order.as<uint32_t>(),
+                     ctx->last_gshift, ctx->host_done, slot ? &slot->s : ctx->host_state_out, slot, sc, xp, ctx->xchg_seq, ticks);
+  HIPCHK(hipGetLastError());
+  return MA_OK;
+}
 
 int launch_begin_run(ma_ctx* ctx, const DevState& s, const ListCtl& c) {
   hipLaunchKernelGGL(k_begin_run, dim3(1), dim3(kWave), 0, ctx->stream, s, c, ctx->state.as<DevState>(), ctx->listctl.as<ListCtl>());

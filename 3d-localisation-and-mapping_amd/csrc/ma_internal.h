@@ -159,12 +159,39 @@ constexpr int kSumLane = kWave - 1;
 
 // The same two for 64-bit INTEGERS (the exact sums of row a5, host_math.h "Exact sums"): an add of a DPP-shifted copy
 // and the wavefront total in lane 63.  Lanes without a source read 0 (bound_ctrl), the identity of the sum.
+// Two instructions: the low halves with carry out, the high halves with carry in, each taking its first operand through
+// the DPP network (v_add_co_u32_dpp / v_addc_co_u32_dpp: VOP2, so the shifted copy costs no move of its own — the fp64
+// form above is three).  Spelled in assembly because the compiler turns the C form into two moves, two zero-extensions
+// and two 64-bit adds; the s_nop covers the two wait states a DPP read of a just-written VGPR needs (the scheduler does
+// not look inside an asm block).
+#define MA_DPP_ADD_U64(NAME, CTRL_TEXT)                                                                                  \
+  __device__ __forceinline__ unsigned long long NAME(const unsigned long long v) {                                       \
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);                                                            \
+    uint32_t rlo, rhi;                                                                                                    \
+    asm volatile("s_nop 1\n\t"                                                                                            \
+                 "v_add_co_u32_dpp %0, vcc, %2, %2 " CTRL_TEXT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"              \
+                 "v_addc_co_u32_dpp %1, vcc, %3, %3, vcc " CTRL_TEXT " row_mask:0xf bank_mask:0xf bound_ctrl:1"            \
+                 : "=&v"(rlo), "=&v"(rhi)                                                                                 \
+                 : "v"(lo), "v"(hi)                                                                                       \
+                 : "vcc");                                                                                                \
+    return ((unsigned long long)rhi << 32) | rlo;                                                                         \
+  }
+MA_DPP_ADD_U64(dpp_add_u64_shr1, "row_shr:1")
+MA_DPP_ADD_U64(dpp_add_u64_shr2, "row_shr:2")
+MA_DPP_ADD_U64(dpp_add_u64_shr4, "row_shr:4")
+MA_DPP_ADD_U64(dpp_add_u64_shr8, "row_shr:8")
+MA_DPP_ADD_U64(dpp_add_u64_bcast15, "row_bcast:15")
+MA_DPP_ADD_U64(dpp_add_u64_bcast31, "row_bcast:31")
+#undef MA_DPP_ADD_U64
 template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_add_u64(unsigned long long v) {
-  const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
-  const uint32_t lo2 = (uint32_t)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, true);
-  const uint32_t hi2 = (uint32_t)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true);
-  return v + (((unsigned long long)hi2 << 32) | lo2);
+__device__ __forceinline__ unsigned long long dpp_add_u64(const unsigned long long v) {
+  static_assert(CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118 || CTRL == 0x142 || CTRL == 0x143, "DPP control");
+  if constexpr (CTRL == 0x111) return dpp_add_u64_shr1(v);
+  else if constexpr (CTRL == 0x112) return dpp_add_u64_shr2(v);
+  else if constexpr (CTRL == 0x114) return dpp_add_u64_shr4(v);
+  else if constexpr (CTRL == 0x118) return dpp_add_u64_shr8(v);
+  else if constexpr (CTRL == 0x142) return dpp_add_u64_bcast15(v);
+  else return dpp_add_u64_bcast31(v);
 }
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
   v = dpp_add_u64<0x111>(v);  // row_shr:1
@@ -319,6 +346,8 @@ struct ma_ctx {
   // batched box lifting (a10 over many frames)
   DevBuf lift_poses, lift_frames;
   DevBuf unproj_cnt;             // valid pixels per workgroup of the last k_unproject launch (frames too large for the pinned block)
+  char* batch_stage = nullptr;   // pinned staging of ma_map_add_depth_batch: the frames' poses going in, their counts coming back
+  size_t batch_stage_cap = 0;
   bool unproj_pending = false;   // a k_unproject launch whose count of valid pixels has not been added up yet (finish_unproject)
   bool unproj_is_source = false; //   ... and it wrote the source cloud: the count settles n_pts / src_holes / MA_ERR_EMPTY
   uint32_t unproj_blocks = 0, unproj_total = 0;
@@ -361,6 +390,18 @@ struct ma_ctx {
   // RCCL communicator of the sharded-source mode (ma_comm_init); opaque here
   void* comm = nullptr;
   int comm_ranks = 0, comm_rank = 0;
+  // peer-to-peer exchange of the sums (ma_p2p_export / ma_p2p_init; comm.hip): this rank's rows, every rank's rows as
+  // mapped here, and the number of iterations the ranks have solved together so far
+  unsigned long long* xchg = nullptr;          // kXWords words of this device's memory (fine-grained where the runtime allows)
+  bool xchg_finegrained = false;
+  unsigned long long* xchg_peer[ma::kXMaxRanks] = {};
+  bool xchg_peer_ipc[ma::kXMaxRanks] = {};     // opened with hipIpcOpenMemHandle (to be closed)
+  int xchg_ranks = 0, xchg_rank = 0;           // 0 ranks: no exchange set up
+  unsigned long long xchg_seq = 0;
+  unsigned long long xchg_agree_gen = 0;       // bounds agreements done over the exchange (the tag of the next one)
+  bool xchg_broken = false;                    // a run ended in a communication failure: the ranks' counters may differ; set up again
+  int comm_transport = 0;                      // ma_comm_config: 0 = RCCL all-reduce, 1 = the peer-to-peer exchange
+  int xchg_timeout_ms = 2000;                  // how long the solving wave waits for its peers' rows (MAPALIGN_P2P_TIMEOUT_MS at ma_create)
   int trace_cap = 0;
   int last_G = 0;
   uint32_t last_gshift = 0;
@@ -446,6 +487,11 @@ int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float
 // stable radix sort of (key, index) pairs; tmp == nullptr asks for the temporary bytes
 hipError_t sort_pairs_u32(void* tmp, size_t& tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
                           uint32_t* vals_out, uint32_t n, int bits, hipStream_t stream);
+hipError_t sort_pairs_u64(void* tmp, size_t& tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
+                          const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, int bits, hipStream_t stream);
+// exclusive prefix sum of n 32-bit words (out may be in); tmp: scan_tmp_bytes(n) bytes
+size_t scan_tmp_bytes(uint32_t n);
+hipError_t scan_exclusive_u32(void* tmp, const uint32_t* in, uint32_t* out, uint32_t n, hipStream_t stream);
 int ensure_levels_for(ma_ctx* ctx, double max_corr_dist);
 // Builds the gold map (level-0 grid, distance table) from the n x 3 fp32 world-frame points already resident in
 // ctx->raw; ev0 must have been recorded by the caller.
@@ -467,6 +513,8 @@ int launch_begin_run(ma_ctx* ctx, const DevState& s, const ListCtl& c);
 int launch_reduce(ma_ctx* ctx, bool with_rank = false);
 int launch_reduce_solve(ma_ctx* ctx, double tol, const SumScale& sc, StateSlot* slot = nullptr);
 int launch_solve(ma_ctx* ctx, double tol, const SumScale& sc, bool in_loop = false, StateSlot* slot = nullptr);
+// the sharded iteration's second launch with the exchange inside: sum, write to every peer, wait, add, solve
+int launch_reduce_exchange_solve(ma_ctx* ctx, double tol, const SumScale& sc, StateSlot* slot);
 
 // kernels_depth.hip
 int finish_unproject(ma_ctx* ctx);
@@ -495,6 +543,9 @@ void comm_destroy(ma_ctx* ctx);
 int comm_allreduce_sums(ma_ctx* ctx);
 // every rank's (n, wmax, rs) -> the whole cloud's, installed as this context's sum bounds (one small collective per source cloud)
 int comm_agree_sum_bounds(ma_ctx* ctx);
+void p2p_release(ma_ctx* ctx);
+// does a sharded run on this context exchange peer to peer (else: RCCL)?
+inline bool use_p2p(const ma_ctx* ctx) { return ctx->xchg_ranks > 0 && (ctx->comm_transport == 1 || !ctx->comm); }
 
 // host_ctx.hip
 void list_config_from_env(ma_ctx* ctx);

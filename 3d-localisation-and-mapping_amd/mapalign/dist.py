@@ -87,6 +87,29 @@ def bootstrap_comm(aligner, group=None):
     return world, rank
 
 
+def bootstrap_p2p(aligner, group=None):
+    """Set up the peer-to-peer exchange of ``aligner`` over the ranks of ``group``: every rank exports its rows, the blobs
+    travel through ``torch.distributed`` (any backend; the all-gather is also the barrier after which rows may be
+    written), every rank maps all of them.  Without a process group: a 1-rank exchange."""
+    import torch.distributed as dist
+
+    world, rank = _world(group)
+    mine = None
+    try:
+        mine = aligner.p2p_export()
+    except Exception as e:              # the other ranks are about to enter the all-gather: never leave them hanging
+        mine = f"{type(e).__name__}: {e}"
+    blobs = [mine]
+    if world > 1:
+        blobs = [None] * world
+        dist.all_gather_object(blobs, mine, group=group)
+    bad = [f"rank {r}: {b}" for r, b in enumerate(blobs) if not isinstance(b, (bytes, bytearray))]
+    if bad:
+        raise RuntimeError("p2p bootstrap failed — " + "; ".join(bad))
+    aligner.p2p_init(blobs, rank)
+    return world, rank
+
+
 class HipShardEngine:
     """Python-stepping view of one :class:`mapalign.MapAligner` (see ``sharded_icp``)."""
 
@@ -158,9 +181,13 @@ def sharded_icp(engine, acc, max_iter=50, init=None, group=None, all_reduce=None
 
 
 def sharded_align(gold_cloud, comparison_cloud, *, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None,
-                  cell=0.0, device=None, group=None, return_info=False):
+                  cell=0.0, device=None, group=None, return_info=False, transport="rccl"):
     """One pair over all ranks of ``group`` (every rank passes the same full clouds).  The
-    loop, including the RCCL all-reduce, runs inside the library (``ma_icp_sharded``)."""
+    loop, including the exchange of the 17 sums, runs inside the library (``ma_icp_sharded``):
+    ``transport="rccl"`` an ``ncclAllReduce`` per iteration, ``"p2p"`` the peer-to-peer exchange
+    inside the iteration's second kernel (no library collective).  Same bits either way."""
+    if transport not in ("rccl", "p2p"):
+        raise ValueError("transport must be 'rccl' or 'p2p'")
     import torch
 
     from .engine import MapAligner
@@ -179,18 +206,28 @@ def sharded_align(gold_cloud, comparison_cloud, *, max_iter=50, tol=0.0, max_cor
         try:
             eng.set_gold(gold_cloud, cell)
             eng.set_source(comp[lo:hi])
-            if rank != 0:
+            if rank != 0 and transport == "rccl":
                 eng.comm_unique_id()     # can this rank load librccl at all?  (rank 0 finds out in bootstrap_comm)
         except Exception as e:           # noqa: BLE001 - reported on every rank below
             err = e
         if not all_ranks_ready(err is None, group, device):
             raise RuntimeError(f"sharded_align: staging failed on rank {rank}: {err}" if err is not None else
                                "sharded_align: staging failed on another rank of the group")
-        bootstrap_comm(eng, group)
+        if transport == "p2p":
+            bootstrap_p2p(eng, group)
+        else:
+            bootstrap_comm(eng, group)
         # (an error returned from ma_icp_sharded mid-loop leaves the communicator unusable: its peers may still
-        # sit in an all-reduce; tear the process group down rather than retrying on it)
+        # sit in an all-reduce; tear the process group down rather than retrying on it.  The p2p exchange times out
+        # instead — MA_ERR_COMM on every rank — and has to be set up again.)
         res = eng.icp_sharded(max_iter=max_iter, tol=tol, max_corr_dist=max_corr_dist, init=init)
-        eng.comm_destroy()
+        if transport == "p2p":
+            if world > 1:               # nobody unmaps rows a peer may still be writing its last iteration into
+                import torch.distributed as dist
+                dist.barrier(group=group)
+            eng.p2p_destroy()
+        else:
+            eng.comm_destroy()
     if return_info:
         return res.R, res.t, {"iterations": res.iterations, "rmse": res.rmse, "inliers": res.inliers,
                               "converged": res.converged, "gpu_ms": res.gpu_ms, "ranks": world}

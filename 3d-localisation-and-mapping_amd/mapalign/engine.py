@@ -403,6 +403,37 @@ class MapAligner:
                                              C.byref(nv)))
         return int(nv.value)
 
+    def map_add_depth_batch(self, depths, K, poses, depth_scale=1000.0):
+        """``map_add_depth`` for a run of frames in one call: ``depths`` [F,H,W] (float32 / uint16; host, or this GPU's
+        memory), ``poses`` [F,4,4].  One upload, one kernel launch, one synchronisation; the map holds what F single calls
+        would have left, bit for bit.  Returns the F counts of valid pixels."""
+        dev = _device_array(depths, "depths", self.device, None, ("<f4", "<u2"))
+        if dev is not None:
+            ptr, shape, typestr, _keep = dev
+            if len(shape) != 3:
+                raise ValueError("depths must be [frames, height, width]")
+            d_p, dtype = C.c_void_p(ptr), 1 if typestr == "<u2" else 0
+        else:
+            d = np.asarray(depths)
+            if d.ndim != 3:
+                raise ValueError("depths must be [frames, height, width]")
+            dtype = 1 if d.dtype == np.uint16 else 0
+            d = np.ascontiguousarray(d if dtype == 1 else d.astype(np.float32, copy=False))
+            d_p, shape, _keep = d.ctypes.data_as(C.c_void_p), d.shape, d
+        n_frames, height, width = (int(v) for v in shape)
+        T = np.array(poses, dtype=np.float64).reshape(n_frames, 4, 4)
+        if self._map_shift is None:      # georeferenced poses: integer-metre host shift, as for clouds
+            t = T[0, :3, 3]
+            self._map_shift = np.round(t) if np.abs(t).max() > LARGE_COORDINATE_M else np.zeros(3)
+        T[:, :3, 3] -= self._map_shift
+        T = np.ascontiguousarray(T)
+        Kf = np.ascontiguousarray(K, dtype=np.float32).reshape(4)
+        counts = np.zeros(n_frames, dtype=np.uint64)
+        self._chk(self._lib.ma_map_add_depth_batch(self._ctx, d_p, dtype, width, height, n_frames,
+                                                   Kf.ctypes.data_as(C.POINTER(C.c_float)), _f64p(T), float(depth_scale),
+                                                   counts.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return counts.astype(np.int64)
+
     def map_finish(self, as_gold=False, cell=0.0, fetch=True):
         """Voxel centroids of everything added since map_begin.  ``as_gold`` installs them as this
         context's gold map on the device.  Returns the [V,3] array (float64 if shifted) or the count."""
@@ -694,10 +725,34 @@ class MapAligner:
     def comm_destroy(self):
         self._chk(self._lib.ma_comm_destroy(self._ctx))
 
+    # -- peer-to-peer exchange of the sums (no library collective on the data path; include/mapalign.h) ----------
+    def p2p_export(self):
+        """This context's rows, allocated and zeroed: the MA_P2P_BLOB_BYTES to hand to every rank (any channel, rank order)."""
+        buf = (C.c_ubyte * _lib.MA_P2P_BLOB_BYTES)()
+        self._chk(self._lib.ma_p2p_export(self._ctx, buf))
+        return bytes(buf)
+
+    def p2p_init(self, blobs, rank):
+        """Map every rank's rows (``blobs``: the exports of all ranks, in rank order) and join as ``rank``."""
+        blobs = [bytes(b) for b in blobs]
+        if any(len(b) != _lib.MA_P2P_BLOB_BYTES for b in blobs):
+            raise ValueError(f"every blob must be {_lib.MA_P2P_BLOB_BYTES} bytes")
+        raw = b"".join(blobs)
+        buf = (C.c_ubyte * len(raw)).from_buffer_copy(raw)
+        self._chk(self._lib.ma_p2p_init(self._ctx, buf, len(blobs), int(rank)))
+
+    def p2p_destroy(self):
+        self._chk(self._lib.ma_p2p_destroy(self._ctx))
+
+    def comm_config(self, transport):
+        """Which exchange :meth:`icp_sharded` uses when both exist: ``"rccl"`` (default) or ``"p2p"``."""
+        self._chk(self._lib.ma_comm_config(self._ctx, {"rccl": _lib.MA_TRANSPORT_RCCL, "p2p": _lib.MA_TRANSPORT_P2P}[transport]))
+
     def icp_sharded(self, max_iter=50, tol=0.0, max_corr_dist=0.10, init=None, count_work=False, with_trace=False, lists=None):
         """The whole sharded-source loop in the library: per iteration search (or list launch) -> 19-way sum ->
-        ncclAllReduce(17 doubles) -> solve, all enqueued from C on the context stream; planner, candidate lists and
-        early exit as in :meth:`icp`."""
+        ncclAllReduce(17 x int64) -> solve — or, over the peer-to-peer exchange, search -> sum + exchange + solve in one
+        launch — all enqueued from C on the context stream; planner, candidate lists and early exit as in :meth:`icp`.
+        The sums are exact integers: the result is :meth:`icp`'s of the whole cloud on one GPU, bit for bit."""
         p = self._params(max_iter, tol, max_corr_dist, count_work, False, lists)
         Tin = _conj_shift(_as_T(init), self._shift, inverse=True)
         Tout = np.empty((4, 4), dtype=np.float64)

@@ -229,6 +229,12 @@ int ma_last_device_ms(const ma_ctx* ctx, double* ms);
 int ma_map_begin(ma_ctx* ctx, float voxel, uint64_t capacity_points);
 int ma_map_add_depth(ma_ctx* ctx, const void* depth, int dtype, int width, int height, const float K[4],
                      const double T_cam_to_world[16], float depth_scale, uint64_t* n_added);
+/* The same for a run of n_frames frames of one size in ONE call (the reference walks its frames one by one,
+ * pose_processor.py:88-122): frames stored back to back, n_frames x 16 doubles of poses, one intrinsics set; one upload,
+ * one kernel launch over all frames, one synchronisation.  n_added (optional): n_frames counts of valid pixels.  The map
+ * afterwards holds exactly — bit for bit — what n_frames ma_map_add_depth calls in the same order would have left. */
+int ma_map_add_depth_batch(ma_ctx* ctx, const void* depth_frames, int dtype, int width, int height, uint32_t n_frames,
+                           const float K[4], const double* T_cam_to_world, float depth_scale, uint64_t* n_added);
 int ma_map_finish(ma_ctx* ctx, int as_gold, float cell, float* xyz_out, uint64_t* n);
 
 /* Row a10: lift 2-D box corners to 3-D global coordinates (pose_processor.py:172-208):
@@ -374,6 +380,28 @@ int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev);
  * for bit.  ma_comm_allgather_f64 / ma_comm_allreduce_f64 (op 0 = sum, 1 = max) move small
  * HOST vectors through the same communicator (pair-per-GPU result gather, fleet statistics). */
 int ma_comm_unique_id(void* id_out /* MA_COMM_ID_BYTES */);
+/* The same sharded loop WITHOUT a library collective on the data path (row e; north_star "all-reduce only of the per-pair
+ * 3x3 covariance/centroid accumulators"): the all-reduce of 17 integers is done by the iteration's second kernel itself.
+ * Every rank owns a small array of rows in its device memory, mapped into every peer; the wave that has summed a rank's 17
+ * sums writes them, as self-validating tagged 8-byte words, straight into its row in EVERY rank's array (over xGMI between
+ * GPUs), waits until the rows of all ranks have arrived in its own array, adds them (integers: any order, same bits) and
+ * solves — two launches per iteration, as in ma_icp, where the RCCL path has three and a library call.  The wait is
+ * bounded (2 s, MAPALIGN_P2P_TIMEOUT_MS at ma_create): a rank whose peers stay silent stops its loop and ma_icp_sharded
+ * returns MA_ERR_COMM — never a hang; the exchange must then be set up again.
+ * Bootstrap: every rank calls ma_p2p_export (allocates and zeroes its rows, fills MA_P2P_BLOB_BYTES opaque bytes), the
+ * blobs travel to all ranks by any channel IN RANK ORDER (torch.distributed all_gather, a file, MPI ...: that exchange is
+ * also the barrier after which rows may be written), every rank calls ma_p2p_init with all of them.  Ranks may be
+ * processes (the rows are mapped with hipIpcOpenMemHandle) or contexts of one process (pointers are used directly; on
+ * different devices peer access is enabled); at most 16.  An exchange and an RCCL communicator may exist side by side:
+ * ma_comm_config chooses which one ma_icp_sharded uses (MA_TRANSPORT_RCCL, the default while both exist, or
+ * MA_TRANSPORT_P2P; with only one of them set up, that one).  Results are the same bits either way, and the single GPU's. */
+#define MA_P2P_BLOB_BYTES 128
+#define MA_TRANSPORT_RCCL 0
+#define MA_TRANSPORT_P2P 1
+int ma_p2p_export(ma_ctx* ctx, void* blob_out /* MA_P2P_BLOB_BYTES */);
+int ma_p2p_init(ma_ctx* ctx, const void* blobs /* n_ranks x MA_P2P_BLOB_BYTES, rank order */, int n_ranks, int rank);
+int ma_p2p_destroy(ma_ctx* ctx);
+int ma_comm_config(ma_ctx* ctx, int transport);
 int ma_comm_init(ma_ctx* ctx, const void* id, int n_ranks, int rank);
 int ma_comm_destroy(ma_ctx* ctx);
 int ma_icp_sharded(ma_ctx* ctx, const ma_params* params, const double init[16], double T_out[16],

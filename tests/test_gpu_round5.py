@@ -8,6 +8,7 @@
 * the count of valid pixels of a frame too large for the pinned count block (> 16.7 MP) decides what it decides for
   every other frame.
 """
+import os
 import time
 
 import numpy as np
@@ -106,3 +107,133 @@ def test_count_of_a_frame_above_16_7_megapixels_settles_the_source(engine):
     with pytest.raises(mapalign.MapAlignError) as e:
         engine.set_source_from_depth(np.zeros((h, w), dtype=np.uint16), K, T, 1000.0, count=False)
     assert e.value.status == mapalign._lib.MA_ERR_EMPTY
+
+
+# ----------------------------------------------------------------------------- the peer-to-peer exchange (row e), rehearsed on one GPU
+def _rehearse(*args, env=None, timeout=600):
+    """tools/p2p_rehearsal.py in a FRESH process (its contexts' streams must sit on different hardware queues: see the
+    script) -> its JSON line."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "p2p_rehearsal.py"), *args], capture_output=True, text=True,
+                       timeout=timeout, env=e)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("ranks,points", [(2, 300_000), (4, 1_000_000)])
+def test_p2p_exchange_contexts_of_one_process_return_the_single_context_bits(lib_built, ranks, points):
+    """ma_icp_sharded over the peer-to-peer exchange (k_reduce_exchange_solve: sum -> write the 17 tagged words into every
+    peer's rows -> wait -> add -> solve, one launch), `ranks` contexts of one process on this GPU, one host thread each,
+    block-partitioned comparison cloud: every rank must return ma_icp's result for the whole cloud BIT FOR BIT (exact
+    integer sums; bounds agreed over the exchange itself), run after run (5 runs: the rows' tags go round more than once)."""
+    res = _rehearse("--mode", "threads", "--ranks", str(ranks), "--points", str(points), "--iters", "50")
+    print(res)
+    assert res["ok"] and res["bitwise_equal_to_one_context"] and res["iterations"] == 50, res
+
+
+def test_p2p_exchange_two_processes_over_ipc_handles(lib_built):
+    """The same with the ranks as PROCESSES: rows mapped with hipIpcGetMemHandle / hipIpcOpenMemHandle, blobs carried by a
+    gloo all-gather (mapalign.dist.bootstrap_p2p), tol > 0 so that the ranks also have to stop together."""
+    res = _rehearse("--mode", "procs", "--ranks", "2", "--points", "300000", "--iters", "60", "--tol", "1e-7", "--reps", "3")
+    print(res)
+    assert res["ok"] and res["bitwise_equal_to_one_context"], res
+
+
+def test_p2p_exchange_times_out_instead_of_hanging(lib_built):
+    """A rank whose peer never writes its rows: the solving wave gives up after the exchange's timeout (300 ms here),
+    ma_icp_sharded returns MA_ERR_COMM, a second call refuses until the exchange is set up again, and the context still
+    aligns on its own."""
+    res = _rehearse("--mode", "timeout")
+    print(res)
+    assert res["ok"], res
+
+
+# ----------------------------------------------------------------------------- row N4: the map builder's frames in one launch
+def test_map_add_depth_batch_equals_single_calls_bitwise(engine):
+    """ma_map_add_depth_batch: n frames, one upload, ONE k_unproject launch (blockIdx.y = frame).  The map it leaves must
+    be the map of n ma_map_add_depth calls bit for bit (same voxel centroids from ma_map_finish), for float32 and uint16
+    frames, host and device-resident input, with holes, and a batch appended behind single frames."""
+    import torch
+    K = (250.0, 250.0, 159.5, 119.5)
+    rects = syn.carriage_rectangles(np.random.default_rng(8))
+    poses = []
+    for k, x in enumerate((-3.0, 1.0, 2.5, 5.0, 6.0, 7.5)):
+        T = syn.default_camera_pose()
+        T[:3, 3] = (x, 1.4 + 0.05 * k, 1.3)
+        T[:3, :3] = T[:3, :3] @ syn.rotation_about_axis([0, 1, 0], 0.07 * k)
+        poses.append(T)
+    frames = np.stack([syn.render_depth(rects, T, 320, 240, *K) for T in poses])
+    frames[2, 50:90, 100:180] = 0.0                                          # holes
+    frames[4, 10, 10] = np.nan
+    for cast in (lambda a: a, lambda a: np.clip(np.round(np.nan_to_num(a)), 0, 65535).astype(np.uint16)):
+        fr = cast(frames)
+        engine.map_begin(0.03, 6 * 320 * 240)
+        single = [engine.map_add_depth(d, K, T) for d, T in zip(fr, poses)]
+        ref = engine.map_finish()
+        engine.map_begin(0.03, 6 * 320 * 240)
+        counts = engine.map_add_depth_batch(fr, K, poses)
+        assert list(counts) == single
+        got = engine.map_finish()
+        assert np.array_equal(got, ref)
+        # device-resident frames; and a batch behind two single frames
+        engine.map_begin(0.03, 6 * 320 * 240)
+        engine.map_add_depth(fr[0], K, poses[0])
+        engine.map_add_depth(fr[1], K, poses[1])
+        dev = torch.as_tensor(np.ascontiguousarray(fr[2:])).to("cuda:0")
+        torch.cuda.synchronize()
+        counts2 = engine.map_add_depth_batch(dev, K, poses[2:])
+        assert list(counts2) == single[2:]
+        assert np.array_equal(engine.map_finish(), ref)
+    pts = np.concatenate([orc.unproject_oracle(d, K, T, 1000.0)[0] for d, T in zip(frames, poses)])
+    engine.map_begin(0.03, 6 * 320 * 240)
+    assert int(engine.map_add_depth_batch(frames, K, poses).sum()) == len(pts)
+    cloud = engine.map_finish()
+    refo = orc.voxel_centroids_oracle(pts, 0.03, np.round(poses[0][:3, 3]))
+    assert cloud.shape == refo.shape and np.abs(cloud.astype(np.float64) - refo).max() <= 2e-5
+    with pytest.raises(mapalign.MapAlignError) as e:                         # capacity is checked for the whole batch
+        engine.map_begin(0.03, 5 * 320 * 240)
+        engine.map_add_depth_batch(frames, K, poses)
+    assert e.value.status == mapalign._lib.MA_ERR_TOO_LARGE
+
+
+def test_own_scan_and_64_bit_sort_on_a_large_map_and_a_5m_cloud(engine):
+    """Round 5 took hipCUB / rocPRIM out of the product: the map builder's 64-bit voxel-key sort and its scan, the rank map
+    of a cloud with holes and the cell sort of clouds above 4M points are the library's own three-kernel passes now.  A map
+    of 24 frames (7.4M slots, keys of ~33 bits, with holes) against the NumPy restatement; and a 5M-point source cloud's
+    sort through ma_nn against a brute-force check of a sample."""
+    depth, K, T = syn.make_depth_frame(0, width=640, height=480, fx=500.0, fy=500.0, cx=320.0, cy=240.0)
+    poses = []
+    for k in range(24):
+        P = T.copy()
+        P[:3, 3] += [0.35 * k, 0.02 * (k % 3), 0.0]
+        poses.append(P)
+    frames = np.repeat(depth[None], 24, axis=0)
+    engine.map_begin(0.02, 24 * depth.size)
+    counts = engine.map_add_depth_batch(frames, K, poses)
+    cloud = engine.map_finish()
+    pts = np.concatenate([orc.unproject_oracle(depth, K, P, 1000.0)[0] for P in poses])
+    assert int(counts.sum()) == len(pts)
+    ref = orc.voxel_centroids_oracle(pts, 0.02, np.round(poses[0][:3, 3]))
+    assert cloud.shape == ref.shape and np.abs(cloud.astype(np.float64) - ref).max() <= 3e-5
+    # the rank map (own scan) of a cloud with holes: get_source returns the valid pixels in row-major order
+    gold, _, _, _ = syn.make_pair(2, 200_000)
+    engine.set_gold(gold)
+    n = engine.set_source_from_depth(depth, K, T, 1000.0)
+    opts, _ = orc.unproject_oracle(depth, K, T, 1000.0)
+    got = engine.get_source()
+    assert n == len(opts) and got.shape == (n, 3) and np.abs(got - opts).max() <= 8e-6
+    # a 5M-point cloud: the own sort beyond the old 4M hand-over to the library
+    rng = np.random.default_rng(12)
+    big = (gold[rng.integers(0, len(gold), 5_000_000)] + rng.normal(0, 0.01, (5_000_000, 3))).astype(np.float32)
+    engine.set_source(big)
+    idx, d2 = engine.nn(None, 0.10)
+    sample = rng.integers(0, len(big), 400)
+    bi, bd = orc.nn_bruteforce(gold, big[sample].astype(np.float64))
+    m = bd <= 0.10 ** 2
+    assert np.array_equal(idx[sample][m], bi[m]) or np.allclose(d2[sample][m], bd[m], rtol=1e-4)

@@ -208,6 +208,70 @@ int main() {
     const ma::SumScale s1m = ma::sum_scale(ma::SumBounds{1e6, 1.0, 12.0}, 10.3, 0.10, 0.0);
     std::printf("sums1m %d %d %d %d %d\n", s1m.e[0], s1m.e[1], s1m.e[2], s1m.e[3], s1m.e[4]);
   }
+  // ---- peer-to-peer exchange: the tagged words, and the protocol under arbitrary delivery delays
+  {
+    int bad = 0;
+    for (long long v : {0ll, 1ll, -1ll, (1ll << 61) - 1, -(1ll << 61), 123456789012345ll, -98765432109876ll})
+      for (unsigned long long seq : {0ull, 1ull, 3ull, 4ull, 7ull, 8ull, 12ull, 15ull, 16ull, 1000003ull}) {
+        const unsigned long long w = ma::xword_encode(v, seq);
+        bad += ma::xword_value(w) != v || (unsigned)(w >> 62) != ma::xword_tag(seq);
+      }
+    for (unsigned long long seq = 0; seq < 64; ++seq) {
+      bad += ma::xword_tag(seq) == ma::xword_tag(seq + ma::kXSlots);          // the word this slot held one generation ago is never taken for this one's
+      if (seq < (unsigned long long)ma::kXSlots) bad += ma::xword_tag(seq) == 0u;      // nor is a zeroed buffer's
+    }
+    // g ranks, each iteration: write 17 words to every rank's row (each word lands after its own random delay, in any
+    // order, possibly long after the writer has gone on), then wait until its own g rows carry the tag, then "solve"
+    // (needs every rank's row) and go on.  A rank can never be more than one iteration ahead of a peer; a reader must
+    // never see a word of another iteration pass for this one's, and nobody may wait for ever.
+    for (int g : {2, 3, 8}) {
+      struct Write { double at; int dst, src, slot, word; unsigned long long w; };
+      std::vector<Write> flight;
+      std::vector<std::vector<unsigned long long>> mem(g, std::vector<unsigned long long>((size_t)ma::kXSlots * ma::kXMaxRanks * ma::kXRowWords, 0ull));
+      std::vector<int> it(g, 0);
+      std::vector<bool> wrote(g, false);
+      const int iters = 40;
+      double now = 0;
+      auto value = [&](int r, int i, int word) { return (long long)(r + 1) * 1000003ll * (i + 1) - (long long)word * 77ll * ((i & 1) ? 1 : -1); };
+      long guard = 0;
+      while (true) {
+        bool all_done = true;
+        for (int r = 0; r < g; ++r) all_done = all_done && it[r] >= iters;
+        if (all_done) break;
+        if (++guard > 2000000) { ++bad; break; }                              // a deadlock
+        now += 0.05;
+        for (size_t k = 0; k < flight.size();) {                              // deliveries
+          if (flight[k].at <= now) {
+            const Write& f = flight[k];
+            mem[f.dst][((size_t)f.slot * ma::kXMaxRanks + f.src) * ma::kXRowWords + f.word] = f.w;
+            flight[k] = flight.back(); flight.pop_back();
+          } else ++k;
+        }
+        const int r = (int)(rng() % (unsigned long long)g);                   // one rank gets a turn
+        if (it[r] >= iters) continue;
+        const unsigned long long seq = (unsigned long long)it[r];
+        const int slot = (int)(seq % ma::kXSlots);
+        if (!wrote[r]) {
+          for (int dst = 0; dst < g; ++dst)
+            for (int word = 0; word < 17; ++word)
+              flight.push_back({now + 3.0 * std::fabs(U(rng)) * std::fabs(U(rng)), dst, r, slot, word, ma::xword_encode(value(r, it[r], word), seq)});
+          wrote[r] = true;
+          continue;
+        }
+        bool all = true;
+        for (int src = 0; src < g && all; ++src)
+          for (int word = 0; word < 17; ++word)
+            if ((unsigned)(mem[r][((size_t)slot * ma::kXMaxRanks + src) * ma::kXRowWords + word] >> 62) != ma::xword_tag(seq)) { all = false; break; }
+        if (!all) continue;
+        for (int src = 0; src < g; ++src)
+          for (int word = 0; word < 17; ++word)
+            bad += ma::xword_value(mem[r][((size_t)slot * ma::kXMaxRanks + src) * ma::kXRowWords + word]) != value(src, it[r], word);
+        ++it[r];
+        wrote[r] = false;
+      }
+    }
+    std::printf("xchg %d\n", bad);
+  }
   // ---- large-coordinate shift of fp64 clouds: none below the threshold, box centre rounded half-to-even above it
   {
     const double lo_s[3] = {-10.0, 2.0, 0.0}, hi_s[3] = {999.0, 3.0, 1.0};
@@ -306,3 +370,11 @@ def test_exact_sums_never_overflow_and_do_not_depend_on_partition_or_order(repor
     e = [int(v) for v in report["sums1m"][0]]
     # 1M points, |q| <= 10.3 m, gate 0.10 m: budget 41 bits per term; S's quantum is 2^-34 m^2, E's 2^-47 m^2
     assert e == [41 - 1, 41 - 4, 41 - 4, 41 - 7, 41 + 6]
+
+
+def test_p2p_exchange_words_and_protocol_under_arbitrary_delays(report):
+    """csrc/host_math.h "Peer-to-peer exchange": the tagged 8-byte words round-trip 62-bit signed sums, a slot's tag differs
+    from its previous generation's and from a zeroed buffer's; and a discrete simulation of 2, 3 and 8 ranks exchanging 40
+    iterations with every word delivered after its own random delay (in any order, long after its writer has moved on)
+    never takes a word of another iteration for this one's and never deadlocks."""
+    assert int(report["xchg"][0][0]) == 0
