@@ -631,7 +631,7 @@ def sharded_region(args, world, rank, local_rank, barrier, dist, torch):
         res = {"value": args.steps * ITERS / elapsed, "unit": "ICP iterations/s", "ms_per_step": elapsed / args.steps * 1e3,
                "scaling": "strong", "workload": f"ONE {args.points}-point pair, comparison cloud block-partitioned over {world} GPUs, "
                                                f"gold map replicated, 50 iterations",
-               "library_rccl": "ma_icp_sharded: ncclAllReduce(17 x f64) per iteration inside libmapalign",
+               "library_rccl": "ma_icp_sharded: ncclAllReduce(17 x int64 fixed point: exact, order-free) per iteration inside libmapalign",
                "final_error_vs_truth": {"R_fro": float(np.linalg.norm(out.R - R0)), "t_m": float(np.linalg.norm(out.t - t0))}}
         eng.comm_destroy()
     except Exception as e:       # pragma: no cover - depends on the node
@@ -697,7 +697,7 @@ def main():
         lo, hi = mdist.shard_bounds(len(comp), world, rank)
         eng.set_source(comp[lo:hi])
         mdist.bootstrap_comm(eng)                        # ncclUniqueId over torch.distributed; the collective itself is in the library
-        lib_rccl = "ma_icp_sharded: ncclAllReduce(17 x f64) per iteration inside libmapalign"
+        lib_rccl = "ma_icp_sharded: ncclAllReduce(17 x int64 fixed point: exact, order-free) per iteration inside libmapalign"
 
         def step():
             return eng.icp_sharded(ITERS, 0.0, GATE)
@@ -843,7 +843,7 @@ def main():
             if not args.no_cpu_baseline:
                 cpu, parity = cpu_baseline_and_parity(eng, gold, comp, args.cpu_iters)
             if not args.no_extra_configs and args.points == N_POINTS:
-                for name, fn in (("c3", lambda: config_c3(eng, gold)), ("c4", lambda: config_c4(eng, local_rank)),
+                for name, fn in (("c3", lambda: config_c3(eng, gold, 0 if args.no_cpu_baseline else ITERS)), ("c4", lambda: config_c4(eng, local_rank)),
                                  ("c5_per_gpu", lambda: config_c5(eng, cpu_iters=0 if args.no_cpu_baseline else ITERS)),
                                  ("concurrent_pairs", lambda: config_concurrent(gold, comp, local_rank, R0))):
                     try:

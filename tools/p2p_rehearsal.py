@@ -7,8 +7,9 @@ without a multi-GPU node: the protocol, the kernel, the bootstrap, the timeout. 
 
 Every mode compares with ma_icp of the whole cloud on one context: the transforms must be the same BITS.
 Run in a fresh process: the contexts' streams must land on different hardware queues (a waiting exchange kernel in front
-of a peer's search kernel in the same queue would only end by the timeout), which the runtime's round-robin gives a fresh
-process with <= GPU_MAX_HW_QUEUES streams (default 4; the script sets it for more ranks).
+of a peer's search kernel in the same queue would only end by the timeout — which is what happened to the 4-context run
+of profiles/r05_variants_ab.txt call 3 under the runtime's default of 4 queues per process): the script raises
+GPU_MAX_HW_QUEUES before the runtime starts.
 """
 import argparse
 import json
@@ -182,8 +183,11 @@ def run_timeout(a):
 
 def main():
     a = parse()
-    if a.mode == "threads" and a.ranks > 4:
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(a.ranks))
+    if a.mode == "threads":
+        # every context's stream on a hardware queue of its own (the runtime's default is 4 queues for all streams of a
+        # process, and this process also holds the reference context's streams); ranks on different GPUs or in different
+        # processes — the real thing — have their own queues anyway
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 2 * a.ranks + 4)))
     res = {"threads": run_threads, "procs": run_procs, "timeout": run_timeout}[a.mode](a)
     print(json.dumps(res))
     sys.exit(0 if res.get("ok") else 1)
