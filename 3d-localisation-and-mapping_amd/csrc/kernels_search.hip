@@ -726,6 +726,7 @@ __device__ __forceinline__ void reduce_chunk(const unsigned long long (&acc)[kNA
 __device__ unsigned long long g_wgt[64][4096][2];
 __device__ uint32_t g_wghw[64][4096][2];
 __device__ uint32_t g_wgph[64][4096][4];   // wave 0: ticks from the start to: search begins, 3x3 block done, search done, sums formed
+__device__ uint32_t g_wvt[16][4096][4];    // iterations 0-15, EVERY wavefront: ticks from the workgroup's start to the end of its search (tools/wavetimeline.py)
 #endif
 
 // Waves per SIMD the register allocator must make room for: 8 (<= 64 VGPRs) for the search and the list launch — every
@@ -903,6 +904,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   if constexpr (lmode != 2) dbg_t2 = sh_w[wv].q.dbg_round0;
   const unsigned long long dbg_t3 = wall_clock64();
   unsigned long long dbg_t4 = 0;
+  if (lane == 0 && MODE == 0 && st->iter < 16 && blockIdx.x < 4096 && wv < 4) g_wvt[st->iter][blockIdx.x][wv] = (uint32_t)(dbg_t3 - wg_start);
 #endif
 
   // the 17 terms as integer bit patterns (pair_terms); a lane without a correspondence carries the bare magic constant
@@ -1035,6 +1037,10 @@ int ma_debug_fetch(ma_ctx* ctx, int what, uint32_t* out, uint64_t count) {
 #if MA_WGTIMES
 int ma_debug_wgphases(ma_ctx* ctx, uint32_t* ph) {
   HIPCHK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_wgph), sizeof(g_wgph)));
+  return MA_OK;
+}
+int ma_debug_wavetimes(ma_ctx* ctx, uint32_t* wt) {
+  HIPCHK(hipMemcpyFromSymbol(wt, HIP_SYMBOL(g_wvt), sizeof(g_wvt)));
   return MA_OK;
 }
 int ma_debug_wgtimes(ma_ctx* ctx, unsigned long long* times, uint32_t* hw) {
