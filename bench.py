@@ -599,8 +599,8 @@ def sharded_region(args, world, rank, local_rank, barrier, dist, torch):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return float(t.item()) >= 1.0
 
-    if args.backend != "nccl":
-        return {"skipped": "single-GPU rehearsal over gloo: RCCL cannot join two ranks that share one device"}
+    rccl = args.backend == "nccl"        # (a single-GPU rehearsal over gloo: RCCL cannot join two ranks that share one device;
+    tdev = dev if rccl else "cpu"        #  the peer-to-peer exchange can — its rows are mapped through IPC handles either way)
     eng, err = None, None
     try:
         gold, comp, R0, t0 = syn.make_pair(0, args.points)
@@ -608,14 +608,18 @@ def sharded_region(args, world, rank, local_rank, barrier, dist, torch):
         eng = mapalign.MapAligner(local_rank)
         eng.set_gold(gold, args.cell)
         eng.set_source(comp[lo:hi])
-        eng.comm_unique_id()                 # can this rank reach librccl at all?
+        if rccl:
+            eng.comm_unique_id()             # can this rank reach librccl at all?
     except Exception as e:
         err = f"{type(e).__name__}: {e}"
     if not all_ok(err is None):
         if eng is not None:
             eng.close()
         return {"error": err or "another rank could not stage its shard / load librccl"}
+    T_rccl = None
     try:
+        if not rccl:
+            raise RuntimeError("skipped: single-GPU rehearsal over gloo (RCCL cannot join two ranks that share one device)")
         mdist.bootstrap_comm(eng)
         for _ in range(args.warmup):
             out = eng.icp_sharded(ITERS, 0.0, GATE)
@@ -625,7 +629,7 @@ def sharded_region(args, world, rank, local_rank, barrier, dist, torch):
             out = eng.icp_sharded(ITERS, 0.0, GATE)
         barrier()
         elapsed = time.perf_counter() - t_start
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         res = {"value": args.steps * ITERS / elapsed, "unit": "ICP iterations/s", "ms_per_step": elapsed / args.steps * 1e3,
@@ -633,9 +637,42 @@ def sharded_region(args, world, rank, local_rank, barrier, dist, torch):
                                                f"gold map replicated, 50 iterations",
                "library_rccl": "ma_icp_sharded: ncclAllReduce(17 x int64 fixed point: exact, order-free) per iteration inside libmapalign",
                "final_error_vs_truth": {"R_fro": float(np.linalg.norm(out.R - R0)), "t_m": float(np.linalg.norm(out.t - t0))}}
+        T_rccl = out.T.copy()
         eng.comm_destroy()
     except Exception as e:       # pragma: no cover - depends on the node
-        res = {"error": f"{type(e).__name__}: {e}"}
+        res = {"skipped": str(e)[9:]} if str(e).startswith("skipped: ") else {"error": f"{type(e).__name__}: {e}"}
+    # ---- the same pair through the peer-to-peer exchange (no library collective on the data path; two launches per iteration)
+    p2p, err = None, None
+    try:
+        mdist.bootstrap_p2p(eng)
+        eng.comm_config("p2p")
+    except Exception as e:       # pragma: no cover - depends on the node (IPC handles, peer access)
+        err = f"{type(e).__name__}: {e}"
+    if not all_ok(err is None):
+        p2p = {"error": err or "another rank could not set up the exchange"}
+    else:
+        try:
+            for _ in range(args.warmup):
+                out = eng.icp_sharded(ITERS, 0.0, GATE)
+            barrier()
+            t_start = time.perf_counter()
+            for _ in range(args.steps):
+                out = eng.icp_sharded(ITERS, 0.0, GATE)
+            barrier()
+            elapsed = time.perf_counter() - t_start
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            p2p = {"value": args.steps * ITERS / elapsed, "unit": "ICP iterations/s", "ms_per_step": elapsed / args.steps * 1e3,
+                   "transport": "ma_p2p_*: the 17 sums written as tagged 8-byte words into every peer's rows by k_reduce_exchange_solve "
+                                "(sum + exchange + solve in one launch), rows mapped with hipIpcOpenMemHandle",
+                   "bitwise_equal_to_rccl_leg": None if T_rccl is None else bool(np.array_equal(out.T, T_rccl)),
+                   "final_error_vs_truth": {"R_fro": float(np.linalg.norm(out.R - R0)), "t_m": float(np.linalg.norm(out.t - t0))}}
+            barrier()
+            eng.p2p_destroy()
+        except Exception as e:   # pragma: no cover - depends on the node; the exchange's wait is bounded (MA_ERR_COMM after 2 s)
+            p2p = {"error": f"{type(e).__name__}: {e}"}
+    res["p2p"] = p2p
     eng.close()
     return res
 

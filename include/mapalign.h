@@ -373,7 +373,10 @@ int ma_step_solve(ma_ctx* ctx, const ma_params* params, const void* acc_dev);
  * with the loop in C and no host synchronisation — the loop of ma_icp: the same candidate lists (each rank plans
  * its own shard's; which kernel a rank launches changes no bit of its sums), the same early exit with tol > 0 (decided
  * from the iteration at which the loop stopped, so that every rank issues the same number of collectives), the final
- * state read from pinned host memory.  Bootstrap: rank 0 obtains an id with
+ * state read from pinned host memory.  The early exit needs the pinned slots: runs of 13 ... 4096 iterations have it (a
+ * stopped loop enqueues at most 8 launches past its stop, the same number on every rank whatever their list settings);
+ * a sharded run of <= 12 or > 4096 iterations enqueues all max_iter iterations — correct (launches after the stop do
+ * nothing and their collectives carry zeros), just not short.  Bootstrap: rank 0 obtains an id with
  * ma_comm_unique_id and hands the MA_COMM_ID_BYTES bytes to the other ranks by any channel
  * (torch.distributed broadcast, a file, MPI ...); every rank then calls ma_comm_init
  * (collective).  A 1-rank communicator is valid and makes ma_icp_sharded equal ma_icp bit

@@ -31,3 +31,12 @@ a = sorted(eng.icp(50, 0.0, 0.1).gpu_ms for _ in range(9)); b = sorted(eng.icp_s
 print(f"whole scan: ma_icp {a[0]:.3f} / {a[4]:.3f} ms, ma_icp_sharded (1-rank communicator: k_reduce19 + all-reduce + k_solve) {b[0]:.3f} / {b[4]:.3f} ms "
       f"-> {(b[4] - a[4]) / 50 * 1e3:.1f} us per iteration for the split launches and the (1-rank) collective")
 eng.comm_destroy()
+# the same whole scan through the peer-to-peer exchange with ONE rank (k_reduce_exchange_solve: the sums go to this rank's own
+# row and come straight back — the launch structure of a g-rank run, everything but the peers' write latency)
+eng.p2p_init([eng.p2p_export()], 0)
+for _ in range(3): eng.icp_sharded(50, 0.0, 0.1)
+p = sorted(eng.icp_sharded(50, 0.0, 0.1).gpu_ms for _ in range(9)); a = sorted(eng.icp(50, 0.0, 0.1).gpu_ms for _ in range(9))
+r = eng.icp_sharded(50, 0.0, 0.1)
+print(f"whole scan: ma_icp {a[0]:.3f} / {a[4]:.3f} ms, ma_icp_sharded over the 1-rank peer-to-peer exchange {p[0]:.3f} / {p[4]:.3f} ms "
+      f"-> {(p[4] - a[4]) / 50 * 1e3:.2f} us per iteration for the exchange inside the second launch; bitwise ma_icp: {np.array_equal(r.T, ref.T)}")
+eng.p2p_destroy()
