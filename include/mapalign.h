@@ -335,8 +335,10 @@ int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_o
  *      rs: the largest distance of one of its points from the gold map's centring origin (only ungated runs use it)}.
  * ma_sum_bounds_get returns this context's own three (for its shard); ma_sum_bounds_set installs the whole cloud's:
  * {sum of the n, max of the wmax, max of the rs} over the shards — which is exactly what a single context holding the whole
- * cloud derives for itself.  ma_icp_sharded does this exchange itself (one small all-gather per source cloud); callers of
- * the split stepping below do it with their own collective.  The bounds belong to a source cloud: installing a new one
+ * cloud derives for itself.  ma_icp_sharded does this exchange itself — one small all-gather in the first call after a
+ * context's source cloud (or communicator) changed, so the ranks of a group must replace their shards TOGETHER: a rank
+ * that alone installed a new shard would enter that collective alone.  Callers of the split stepping below do the
+ * exchange with their own collective.  The bounds belong to a source cloud: installing a new one
  * (or a new gold map) clears them; NULL clears them explicitly.  Without agreed bounds results are still correct to
  * rounding (1e-12 relative), just not bit-identical across different partitions.
  * ma_sum_scale_get: the exponents e = {W, s_p, s_q, S, E} in force for a run with these parameters (MA_ACC_LEN int64 v_k

@@ -203,3 +203,120 @@ def test_world2_sharded_and_pair_modes(tmp_path):
     assert int(r0["n_calls"]) == 3 and int(r1["n_calls"]) == 2
     assert np.array_equal(r0["pair_T"], r1["pair_T"])
     assert [int(T[0, 3]) for T in r0["pair_T"]] == [15, 16, 17, 18, 19]
+
+
+# ----------------------------------------------------------------------------- round 5: integer sums, bounds agreement, p2p bootstrap
+class FixedPointShardEngine(OracleShardEngine):
+    """The stand-in with the HIP engine's EXCHANGE FORMAT (round 5): the 17 sums of a shard as int64 fixed point — every
+    correspondence's terms rounded once to a quantum 2^-e — with the exponents derived from bounds the ranks agree on
+    (the arithmetic of csrc/host_math.h::sum_scale, restated)."""
+    GROUP = np.array([0, 1, 1, 1, 2, 2, 2] + [3] * 9 + [4])
+
+    def __init__(self, gold, comp_shard, gate):
+        super().__init__(gold, comp_shard, gate)
+        self.qb = float(np.abs(self.index.gold).max())
+        self.bounds = None
+
+    def sum_bounds(self):
+        return np.array([float(len(self.comp)), 1.0, float(np.linalg.norm(self.comp, axis=1).max())])
+
+    def agree_sum_bounds(self, group=None):
+        mine = torch.from_numpy(self.sum_bounds())
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        out = [torch.empty_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(out, mine, group=group)
+        else:
+            out = [mine]
+        b = torch.stack(out).numpy()
+        self.bounds = np.array([b[:, 0].sum(), b[:, 1].max(), b[:, 2].max()])
+
+    def exponents(self):
+        n, wmax, _ = self.bounds
+        pb = self.qb + self.gate * 1.001 + 1e-6
+        budget = min(50, 61 - int(np.frexp(n)[1]))
+        term = [wmax, wmax * pb, wmax * self.qb, wmax * pb * self.qb, wmax * (self.gate ** 2 * 1.001 + 1e-12)]
+        return np.array([budget - int(np.frexp(v)[1]) for v in term])
+
+    def accumulate_into(self, acc):
+        e = self.exponents()
+        p = self.comp @ self.R.T + self.t
+        idx, d2 = self.index.query(p)
+        m = d2 <= self.gate ** 2
+        p, q, d2 = p[m], self.index.gold[idx[m]], d2[m]
+        terms = np.concatenate([np.ones((len(p), 1)), p, q, (p[:, :, None] * q[:, None, :]).reshape(len(p), 9), d2[:, None]], axis=1)
+        k = np.rint(np.ldexp(terms, e[self.GROUP])).astype(np.int64)          # one rounding per term, ties to even
+        acc.copy_(torch.from_numpy(k.sum(axis=0)))
+
+    def solve_from(self, acc):
+        e = self.exponents()
+        a = np.ldexp(acc.numpy().astype(np.float64), -e[self.GROUP])
+        dR, dt, ok = self.orc.kabsch_from_acc(a)
+        assert ok
+        self.R, self.t = dR @ self.R, dR @ self.t + dt
+        self.iters += 1
+
+
+class FakeP2PAligner:
+    def __init__(self, rank, fail=False):
+        self.rank, self.fail, self.inited = rank, fail, None
+
+    def p2p_export(self):
+        if self.fail:
+            raise RuntimeError("no fine-grained memory today")
+        return bytes([self.rank]) * 128
+
+    def p2p_init(self, blobs, rank):
+        self.inited = (list(blobs), rank)
+
+
+def _round5_worker(rank, world, port, out_dir):
+    for p in (PKG, ROOT):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mapalign import dist as mdist
+    from mapalign import synthetic as syn
+    gold, comp, R0, t0 = syn.make_pair(3, 6000, 5000)
+    # an UNEVEN partition (rank 0 holds 70 %): integer sums do not care
+    cut = int(0.7 * len(comp))
+    lo, hi = (0, cut) if rank == 0 else (cut, len(comp))
+    eng = FixedPointShardEngine(gold, comp[lo:hi], 0.10)
+    acc = torch.zeros(17, dtype=torch.int64)
+    T, info = mdist.sharded_icp(eng, acc, max_iter=15)               # agree_sum_bounds, then 15 x (accumulate, all_reduce(int64), solve)
+    # the same on ONE engine holding the whole cloud, bounds = its own: must be the same BITS
+    whole = FixedPointShardEngine(gold, comp, 0.10)
+    whole.bounds = whole.sum_bounds()
+    assert np.array_equal(whole.bounds[:2], eng.bounds[:2])          # n_total and wmax: what the ranks agreed on
+    acc1 = torch.zeros(17, dtype=torch.int64)
+    whole.state_set(None)
+    for _ in range(15):
+        whole.accumulate_into(acc1)
+        whole.solve_from(acc1)
+    T1, _ = whole.state_get()
+    # p2p bootstrap: blobs gathered in rank order; a failing export reaches every rank as an error, nobody hangs
+    a = FakeP2PAligner(rank)
+    mdist.bootstrap_p2p(a)
+    ok_blobs = a.inited == ([bytes([r]) * 128 for r in range(world)], rank)
+    raised = ""
+    try:
+        mdist.bootstrap_p2p(FakeP2PAligner(rank, fail=(rank == 1)))
+    except RuntimeError as e:
+        raised = str(e)
+    np.savez(os.path.join(out_dir, f"r5_{rank}.npz"), T=T, T1=T1, ok_blobs=ok_blobs, raised=raised, iters=info["iterations"])
+    dist.destroy_process_group()
+
+
+def test_world2_integer_sums_any_partition_gives_the_single_process_bits_and_p2p_bootstrap(tmp_path):
+    """Round 5 on the CPU: mapalign.dist.sharded_icp with the int64 exchange buffer over a 2-rank gloo group and a 70 / 30
+    partition — agree_sum_bounds, integer all-reduce — ends on the bits of ONE engine holding the whole cloud (the property
+    the HIP engine's exact sums exist for; the GPU tests check it on the device); and mapalign.dist.bootstrap_p2p gathers
+    the ranks' blobs in rank order and turns one rank's failure into an error on every rank."""
+    world = 2
+    mp.spawn(_round5_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = [np.load(tmp_path / f"r5_{r}.npz") for r in range(world)]
+    assert np.array_equal(z[0]["T"], z[1]["T"]) and int(z[0]["iters"]) == 15
+    assert np.array_equal(z[0]["T"], z[0]["T1"]) and np.array_equal(z[1]["T"], z[1]["T1"])      # sharded == whole, bit for bit
+    assert bool(z[0]["ok_blobs"]) and bool(z[1]["ok_blobs"])
+    for r in range(world):
+        assert "p2p bootstrap failed" in str(z[r]["raised"]) and "rank 1" in str(z[r]["raised"])

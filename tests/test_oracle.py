@@ -261,3 +261,28 @@ def test_ckdtree_backend_is_the_sklearn_oracle(seed, n, gate):
     assert np.allclose([r["acc"] for r in ra["trace"]], [r["acc"] for r in rb["trace"]], rtol=1e-12, atol=1e-12)
     eR, et = orc.rt_error(ra["R"], ra["t"], rb["R"], rb["t"])
     assert eR < 1e-12 and et < 1e-12, (eR, et)
+
+
+def test_exact_sums_restatement_against_float_arithmetic():
+    """oracle/exact_sums.py (rational arithmetic) on a small case: its integers, read back as numbers, are the plain fp64
+    sums to within n quanta, its fma is numpy's where no rounding is at stake, ties round to even."""
+    from fractions import Fraction
+
+    from oracle import exact_sums as xs
+    assert xs.rne_int(Fraction(5, 2)) == 2 and xs.rne_int(Fraction(7, 2)) == 4 and xs.rne_int(Fraction(-5, 2)) == -2
+    assert xs.rne_int(Fraction(-7, 3)) == -2 and xs.rne_int(Fraction(8, 3)) == 3
+    assert xs.fma(3.0, 4.0, 0.5) == 12.5 and xs.fma(1.0 + 2.0 ** -52, 1.0 + 2.0 ** -52, -1.0) == 2.0 ** -51 + 2.0 ** -104
+    rng = np.random.default_rng(2)
+    n = 300
+    src = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    gold = (src + rng.normal(0, 0.02, (n, 3))).astype(np.float32)
+    R = syn.rotation_about_axis([0.2, 0.5, 0.8], 0.01)
+    t = np.array([0.01, -0.02, 0.005])
+    e = [40, 37, 37, 34, 47]
+    k = xs.sums(R, t, src, None, gold, np.arange(n), e)
+    P = src.astype(np.float64) @ R.T + t
+    acc = orc.accumulate(P, gold.astype(np.float64), np.ones(n), ((P - gold) ** 2).sum(1))
+    back = np.array([k[a] / 2.0 ** e[xs.GROUP[a]] for a in range(17)])
+    quantum = np.array([2.0 ** -e[xs.GROUP[a]] for a in range(17)])
+    assert (np.abs(back - acc) <= n * quantum + 1e-9 * np.abs(acc)).all()
+    assert k[0] == n * 2 ** 40

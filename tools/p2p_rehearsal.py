@@ -84,7 +84,7 @@ def run_threads(a):
     res = {"mode": "threads", "ranks": a.ranks, "points": a.points, "iterations": int(out[0].iterations),
            "bitwise_equal_to_one_context": bool(same),
            "gpu_ms_per_rank": [round(float(o.gpu_ms), 4) for o in out], "ma_icp_gpu_ms": round(float(ref_ms), 4),
-           "wall_ms": round(sorted(times)[len(times) // 2], 3)}
+           "wall_ms": round(sorted(times)[len(times) // 2], 3), "rows": engs[0].p2p_rows}
     for e in engs:
         e.p2p_destroy()
         e.close()
