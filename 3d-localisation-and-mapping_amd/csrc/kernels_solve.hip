@@ -308,8 +308,17 @@ __global__ __launch_bounds__(kBlock) void k_reduce_exchange_solve(
     uint32_t* __restrict__ ticket, double* __restrict__ trace, const int trace_cap, const double tol,
     const uint32_t* __restrict__ wg_cost, uint32_t* __restrict__ order, const uint32_t gshift, int* __restrict__ host_done,
     DevState* __restrict__ host_mirror, StateSlot* __restrict__ slot, const SumScale sc, const XPeers xp,
-    const unsigned long long seq_base, const unsigned long long timeout_ticks) {
+    const unsigned long long* __restrict__ my_rows, const unsigned long long seq_base, const unsigned long long timeout_ticks) {
   const int done = st->done;
+  const unsigned long long t_launch = wall_clock64();      // (read here, beside the first loads: the wait below is timed from the launch)
+  // every peer's row pointer into scalar registers NOW, with the kernel's other arguments: fetched where they are used, each
+  // store waited for a scalar load of its own, one after the other
+  unsigned long long* rowp[ma::kXMaxRanks];
+#pragma unroll
+  for (int r = 0; r < ma::kXMaxRanks; ++r) {
+    rowp[r] = xp.rows[r];
+    asm volatile("" : "+s"(rowp[r]));
+  }
   if (blockIdx.x == kNAcc) {
     rank_groups(G, wg_cost, order, gshift, done);
     return;
@@ -351,37 +360,45 @@ __global__ __launch_bounds__(kBlock) void k_reduce_exchange_solve(
   const uint32_t xslot = (uint32_t)(seq % (unsigned long long)ma::kXSlots);
   const uint32_t tag = ma::xword_tag(seq);
   const long long mine = lane < kNAcc ? __hip_atomic_load(&acc_out[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  // Its own row a rank neither writes nor reads: it holds those sums in registers (a 1-rank exchange touches no row at
+  // all).  The loops over the peers are unrolled over the most ranks there can be, with wave-uniform guards: the row
+  // pointers come from fixed kernarg offsets and the g - 1 stores, then the g - 1 polling loads, are all in flight together
+  // — one peer round trip per poll, not g - 1 (a rolled loop waited for each load before issuing the next).
+  const int n_ranks = xp.n_ranks, rank = xp.rank;
   if (lane < ma::kAccLen) {
     const unsigned long long w = ma::xword_encode(mine, seq);
-    const size_t at = ((size_t)xslot * ma::kXMaxRanks + (size_t)xp.rank) * ma::kXRowWords + (size_t)lane;
-    // (its own row a rank neither writes nor reads: it holds those sums in registers — a 1-rank exchange touches no row at
-    // all, and the g - 1 peers' rows are the only round trip of a g-rank one; 4.4 us per iteration through the own row, measured)
-    for (int r = 0; r < xp.n_ranks; ++r)
-      if (r != xp.rank) __hip_atomic_store(xp.rows[r] + at, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const size_t at = ((size_t)xslot * ma::kXMaxRanks + (size_t)rank) * ma::kXRowWords + (size_t)lane;
+#pragma unroll
+    for (int r = 0; r < ma::kXMaxRanks; ++r)
+      if (r < n_ranks && r != rank) __hip_atomic_store(rowp[r] + at, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  const unsigned long long* my = xp.rows[xp.rank] + (size_t)xslot * ma::kXMaxRanks * ma::kXRowWords;
+  const unsigned long long* my = my_rows + (size_t)xslot * ma::kXMaxRanks * ma::kXRowWords + (size_t)(lane < ma::kAccLen ? lane : 0);
+  const unsigned long long own_word = ma::xword_encode(mine, seq);
   unsigned long long total = 0ull;
   bool arrived_all = false;
-  const unsigned long long t_wait = wall_clock64();
   for (;;) {
+    unsigned long long w[ma::kXMaxRanks];
+#pragma unroll
+    for (int r = 0; r < ma::kXMaxRanks; ++r)
+      w[r] = (r < n_ranks && r != rank) ? __hip_atomic_load(my + (size_t)r * ma::kXRowWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                        : (r == rank ? own_word : ((unsigned long long)tag << 62));      // absent ranks: a valid zero
     bool all = true;
-    total = (unsigned long long)mine;
-    if (lane < ma::kAccLen) {
-      for (int r = 0; r < xp.n_ranks; ++r) {
-        if (r == xp.rank) continue;
-        const unsigned long long w = __hip_atomic_load(my + (size_t)r * ma::kXRowWords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        all = all && (uint32_t)(w >> 62) == tag;
-        total += (unsigned long long)ma::xword_value(w);
-      }
+    total = 0ull;
+#pragma unroll
+    for (int r = 0; r < ma::kXMaxRanks; ++r) {
+      all = all && (uint32_t)(w[r] >> 62) == tag;
+      total += (unsigned long long)ma::xword_value(w[r]);
     }
-    if (__ballot(!all) == 0ull) { arrived_all = true; break; }
-    if (wall_clock64() - t_wait > timeout_ticks) break;
+    if (__ballot(!all && lane < ma::kAccLen) == 0ull) { arrived_all = true; break; }
+    if (wall_clock64() - t_launch > timeout_ticks) break;
     __builtin_amdgcn_s_sleep(1);
   }
   const double mine_value = lane < ma::kAccLen ? sum_value((long long)total, lane, sc) : (double)mine;     // lanes 17, 18: this rank's work counters
+  // lane t's value to the solving lane: v_readlane into scalar registers (a shuffle is an LDS round trip each)
   double a[kNAcc];
+  const int mv_lo = __double2loint(mine_value), mv_hi = __double2hiint(mine_value);
 #pragma unroll
-  for (int t = 0; t < kNAcc; ++t) a[t] = __shfl(mine_value, t, kWave);
+  for (int t = 0; t < kNAcc; ++t) a[t] = __hiloint2double(__builtin_amdgcn_readlane(mv_hi, t), __builtin_amdgcn_readlane(mv_lo, t));
   if (lane != 0) return;
   if (!arrived_all) {
     // a peer's rows did not come: stop the loop where it stands (every rank whose peers are silent does the same after
@@ -414,7 +431,8 @@ int launch_reduce_exchange_solve(ma_ctx* ctx, double tol, const SumScale& sc, St
   hipLaunchKernelGGL(k_reduce_exchange_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<long long>(),
                      ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<long long>(), ctx->ticket.as<uint32_t>(),
                      ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(), ctx->seg_order.as<uint32_t>(),
-                     ctx->last_gshift, ctx->host_done, slot ? &slot->s : ctx->host_state_out, slot, sc, xp, ctx->xchg_seq, ticks);
+                     ctx->last_gshift, ctx->host_done, slot ? &slot->s : ctx->host_state_out, slot, sc, xp,
+                     (const unsigned long long*)ctx->xchg, ctx->xchg_seq, ticks);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }

@@ -287,7 +287,7 @@ def test_the_17_integer_sums_equal_an_exact_arithmetic_restatement(engine, weigh
     and centred-frame transform.  All 17 must be EQUAL, with and without weights, gated, for a general transform."""
     import torch
     from oracle import exact_sums as xs
-    gold, comp, R0, t0 = syn.make_pair(21, 3000, 2500)
+    gold, comp, R0, t0 = syn.make_pair(21, 30_000, 2500)          # a dense enough map for ~2000 matches inside the gate
     w = np.random.default_rng(4).uniform(0.25, 3.0, len(comp)).astype(np.float32) if weighted else None
     engine.set_gold(gold)
     engine.set_source(comp, w)
