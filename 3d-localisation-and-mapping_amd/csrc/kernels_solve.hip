@@ -255,10 +255,14 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const long long* __rest
   __syncthreads();
   if (threadIdx.x != 0) return;
   const long long sum = (long long)(red[0] + red[1] + red[2] + red[3]);
-  __hip_atomic_store(&acc_out[k], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // The sum leaves this workgroup as a NUMBER already (v 2^-e, the bits of the double in the 8-byte slot): nineteen lanes
+  // on nineteen CUs convert side by side, where the solving lane would convert one after the other — on a lone wavefront,
+  // 19 x (int64 -> fp64, scale) is 0.3-0.4 us of the iteration (profiles/r05_variants_ab.txt, call 3: 8.1 -> 8.4 us).
+  const double value = sum_value(sum, k, sc);
+  __hip_atomic_store(&acc_out[k], __double_as_longlong(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // this accumulator's entry of the iteration's trace row (columns 0-16 the sums, 17 the rmse — the solve's —, 18 and 19
   // the two work counters)
-  if (it_now < trace_cap) trace[(size_t)it_now * MA_TRACE_STRIDE + (k < ma::kAccLen ? k : k + 1)] = sum_value(sum, k, sc);
+  if (it_now < trace_cap) trace[(size_t)it_now * MA_TRACE_STRIDE + (k < ma::kAccLen ? k : k + 1)] = value;
 #if MA_WGTIMES
   if (dbg_it < 64) g_rs[dbg_it][k][1] = wall_clock64();
 #endif
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const long long* __rest
   __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   double a[kNAcc];
 #pragma unroll
-  for (int t = 0; t < kNAcc; ++t) a[t] = sum_value(__hip_atomic_load(&acc_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), t, sc);
+  for (int t = 0; t < kNAcc; ++t) a[t] = __longlong_as_double(__hip_atomic_load(&acc_out[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #if MA_WGTIMES
   asm volatile("" :: "v"(a[0]), "v"(a[18]));
   if (dbg_it < 64) g_rs[dbg_it][k][3] = wall_clock64();
@@ -299,10 +303,18 @@ __global__ __launch_bounds__(kWave) void k_begin_run(const DevState s, const Lis
 //      wave leaves the kernel whatever the peers do;
 //   3. adds the g rows (integers: any order gives the same bits), converts, and lane 0 solves.
 // Every rank computes the same sums, hence the same state: nothing else is exchanged.
+// NP = the number of PEERS (ranks - 1) as a template parameter, 0 ... 7 exact, 15 = "up to 15, guarded": the loops over the
+// peers are unrolled without guards, the peers' row pointers are plain kernel arguments fetched with the others at the top,
+// and the g - 1 stores, then the g - 1 polling loads, are in flight together — one peer round trip per poll.  (A lone
+// wavefront issues an instruction every ~8 cycles: the first form, unrolled over 16 possible ranks with a uniform guard
+// each, spent 1.2 us of every iteration on guards; a rolled loop waited for each peer's load before issuing the next.)
+// A rank neither writes nor reads its own row: it holds those sums in registers (a 1-rank exchange touches no row).
 struct XPeers {
-  unsigned long long* rows[ma::kXMaxRanks];
-  int n_ranks, rank;
+  unsigned long long* rows[ma::kXMaxRanks - 1];      // the PEERS' arrays as mapped here, in rank order without this rank
+  int rank_of[ma::kXMaxRanks - 1];                   // their ranks (which row of MY array each of them writes)
+  int n_peers, rank;
 };
+template <int NP>
 __global__ __launch_bounds__(kBlock) void k_reduce_exchange_solve(
     const long long* __restrict__ partials, const int G, DevState* __restrict__ st, long long* __restrict__ acc_out,
     uint32_t* __restrict__ ticket, double* __restrict__ trace, const int trace_cap, const double tol,
@@ -311,14 +323,6 @@ __global__ __launch_bounds__(kBlock) void k_reduce_exchange_solve(
     const unsigned long long* __restrict__ my_rows, const unsigned long long seq_base, const unsigned long long timeout_ticks) {
   const int done = st->done;
   const unsigned long long t_launch = wall_clock64();      // (read here, beside the first loads: the wait below is timed from the launch)
-  // every peer's row pointer into scalar registers NOW, with the kernel's other arguments: fetched where they are used, each
-  // store waited for a scalar load of its own, one after the other
-  unsigned long long* rowp[ma::kXMaxRanks];
-#pragma unroll
-  for (int r = 0; r < ma::kXMaxRanks; ++r) {
-    rowp[r] = xp.rows[r];
-    asm volatile("" : "+s"(rowp[r]));
-  }
   if (blockIdx.x == kNAcc) {
     rank_groups(G, wg_cost, order, gshift, done);
     return;
@@ -360,38 +364,37 @@ __global__ __launch_bounds__(kBlock) void k_reduce_exchange_solve(
   const uint32_t xslot = (uint32_t)(seq % (unsigned long long)ma::kXSlots);
   const uint32_t tag = ma::xword_tag(seq);
   const long long mine = lane < kNAcc ? __hip_atomic_load(&acc_out[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-  // Its own row a rank neither writes nor reads: it holds those sums in registers (a 1-rank exchange touches no row at
-  // all).  The loops over the peers are unrolled over the most ranks there can be, with wave-uniform guards: the row
-  // pointers come from fixed kernarg offsets and the g - 1 stores, then the g - 1 polling loads, are all in flight together
-  // — one peer round trip per poll, not g - 1 (a rolled loop waited for each load before issuing the next).
-  const int n_ranks = xp.n_ranks, rank = xp.rank;
-  if (lane < ma::kAccLen) {
+  const int word = lane < ma::kAccLen ? lane : 0;
+  const int np = NP <= 7 ? NP : xp.n_peers;
+  if (NP > 0 && lane < ma::kAccLen) {
     const unsigned long long w = ma::xword_encode(mine, seq);
-    const size_t at = ((size_t)xslot * ma::kXMaxRanks + (size_t)rank) * ma::kXRowWords + (size_t)lane;
+    const size_t at = ((size_t)xslot * ma::kXMaxRanks + (size_t)xp.rank) * ma::kXRowWords + (size_t)lane;
 #pragma unroll
-    for (int r = 0; r < ma::kXMaxRanks; ++r)
-      if (r < n_ranks && r != rank) __hip_atomic_store(rowp[r] + at, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int j = 0; j < NP; ++j)
+      if (NP <= 7 || j < np) __hip_atomic_store(xp.rows[j] + at, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  const unsigned long long* my = my_rows + (size_t)xslot * ma::kXMaxRanks * ma::kXRowWords + (size_t)(lane < ma::kAccLen ? lane : 0);
-  const unsigned long long own_word = ma::xword_encode(mine, seq);
-  unsigned long long total = 0ull;
-  bool arrived_all = false;
-  for (;;) {
-    unsigned long long w[ma::kXMaxRanks];
+  unsigned long long total = (unsigned long long)mine;
+  bool arrived_all = true;
+  if (NP > 0) {
+    const unsigned long long* my = my_rows + (size_t)xslot * ma::kXMaxRanks * ma::kXRowWords + (size_t)word;
+    arrived_all = false;
+    for (;;) {
+      unsigned long long w[NP > 0 ? NP : 1];
 #pragma unroll
-    for (int r = 0; r < ma::kXMaxRanks; ++r)
-      w[r] = (r < n_ranks && r != rank) ? __hip_atomic_load(my + (size_t)r * ma::kXRowWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                        : (r == rank ? own_word : ((unsigned long long)tag << 62));      // absent ranks: a valid zero
-    bool all = true;
-    total = 0ull;
+      for (int j = 0; j < NP; ++j)
+        w[j] = (NP <= 7 || j < np) ? __hip_atomic_load(my + (size_t)xp.rank_of[j] * ma::kXRowWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                   : ((unsigned long long)tag << 62);      // an absent peer: a valid zero
+      bool all = true;
+      total = (unsigned long long)mine;
 #pragma unroll
-    for (int r = 0; r < ma::kXMaxRanks; ++r) {
-      all = all && (uint32_t)(w[r] >> 62) == tag;
-      total += (unsigned long long)ma::xword_value(w[r]);
+      for (int j = 0; j < NP; ++j) {
+        all = all && (uint32_t)(w[j] >> 62) == tag;
+        total += (unsigned long long)ma::xword_value(w[j]);
+      }
+      if (__ballot(!all && lane < ma::kAccLen) == 0ull) { arrived_all = true; break; }
+      if (wall_clock64() - t_launch > timeout_ticks) break;
+      __builtin_amdgcn_s_sleep(1);
     }
-    if (__ballot(!all && lane < ma::kAccLen) == 0ull) { arrived_all = true; break; }
-    if (wall_clock64() - t_launch > timeout_ticks) break;
-    __builtin_amdgcn_s_sleep(1);
   }
   const double mine_value = lane < ma::kAccLen ? sum_value((long long)total, lane, sc) : (double)mine;     // lanes 17, 18: this rank's work counters
   // lane t's value to the solving lane: v_readlane into scalar registers (a shuffle is an LDS round trip each)
@@ -424,15 +427,34 @@ namespace mai {
 
 int launch_reduce_exchange_solve(ma_ctx* ctx, double tol, const SumScale& sc, StateSlot* slot) {
   XPeers xp{};
-  for (int r = 0; r < ctx->xchg_ranks; ++r) xp.rows[r] = ctx->xchg_peer[r];
-  xp.n_ranks = ctx->xchg_ranks;
+  int np = 0;
+  for (int r = 0; r < ctx->xchg_ranks; ++r) {
+    if (r == ctx->xchg_rank) continue;
+    xp.rows[np] = ctx->xchg_peer[r];
+    xp.rank_of[np] = r;
+    ++np;
+  }
+  xp.n_peers = np;
   xp.rank = ctx->xchg_rank;
   const unsigned long long ticks = (unsigned long long)ctx->xchg_timeout_ms * 100000ull;      // wall_clock64: 100 MHz
-  hipLaunchKernelGGL(k_reduce_exchange_solve, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<long long>(),
-                     ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<long long>(), ctx->ticket.as<uint32_t>(),
-                     ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(), ctx->seg_order.as<uint32_t>(),
-                     ctx->last_gshift, ctx->host_done, slot ? &slot->s : ctx->host_state_out, slot, sc, xp,
-                     (const unsigned long long*)ctx->xchg, ctx->xchg_seq, ticks);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(kNAcc + 1), dim3(kBlock), 0, ctx->stream, ctx->partials.as<long long>(),
+                       ctx->last_G, ctx->state.as<DevState>(), ctx->acc19.as<long long>(), ctx->ticket.as<uint32_t>(),
+                       ctx->trace.as<double>(), ctx->trace_cap, tol, ctx->wg_cost.as<uint32_t>(), ctx->seg_order.as<uint32_t>(),
+                       ctx->last_gshift, ctx->host_done, slot ? &slot->s : ctx->host_state_out, slot, sc, xp,
+                       (const unsigned long long*)ctx->xchg, ctx->xchg_seq, ticks);
+  };
+  switch (np) {
+    case 0: go(k_reduce_exchange_solve<0>); break;
+    case 1: go(k_reduce_exchange_solve<1>); break;
+    case 2: go(k_reduce_exchange_solve<2>); break;
+    case 3: go(k_reduce_exchange_solve<3>); break;
+    case 4: go(k_reduce_exchange_solve<4>); break;
+    case 5: go(k_reduce_exchange_solve<5>); break;
+    case 6: go(k_reduce_exchange_solve<6>); break;
+    case 7: go(k_reduce_exchange_solve<7>); break;
+    default: go(k_reduce_exchange_solve<15>); break;
+  }
   HIPCHK(hipGetLastError());
   return MA_OK;
 }
