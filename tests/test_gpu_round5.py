@@ -291,9 +291,9 @@ def test_the_17_integer_sums_equal_an_exact_arithmetic_restatement(engine, weigh
     w = np.random.default_rng(4).uniform(0.25, 3.0, len(comp)).astype(np.float32) if weighted else None
     engine.set_gold(gold)
     engine.set_source(comp, w)
-    T = np.eye(4)
-    T[:3, :3] = syn.rotation_about_axis([0.3, -0.5, 0.81], np.deg2rad(1.1))
-    T[:3, 3] = [0.04, -0.03, 0.02]
+    T = np.eye(4)                                                  # a general transform near the pair's truth: most points match
+    T[:3, :3] = syn.rotation_about_axis([0.3, -0.5, 0.81], np.deg2rad(0.2)) @ R0
+    T[:3, 3] = t0 + [0.01, -0.008, 0.005]
     gate = 0.10
     origin = np.asarray(engine.grid_info()["origin"], dtype=np.float64)
     # the state as the library centres it (host_math.h::world_to_centred, the same operations in the same order)
@@ -313,7 +313,7 @@ def test_the_17_integer_sums_equal_an_exact_arithmetic_restatement(engine, weigh
     engine.sync()
     dev = [int(v) for v in acc.cpu().numpy()]
     ref = xs.sums(R, t, s_c, w, g_c, match, e)
-    assert (match >= 0).sum() > 1500
+    assert (match >= 0).sum() > 1000, (match >= 0).sum()
     assert dev == ref, [(a, d - r) for a, (d, r) in enumerate(zip(dev, ref)) if d != r]
     if not weighted:
         assert dev[0] == int((match >= 0).sum()) << int(e[0])
