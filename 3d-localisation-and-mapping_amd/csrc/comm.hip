@@ -124,7 +124,7 @@ int comm_agree_sum_bounds(ma_ctx* ctx) {
   if ((rc = ensure_source_box(ctx))) return rc;
   const bool p2p = use_p2p(ctx);
   const int g = p2p ? ctx->xchg_ranks : ctx->comm_ranks;
-  double mine[3] = {(double)ctx->n, ctx->src_wmax, (double)ctx->src_rs};
+  double mine[3] = {(double)ctx->n, ctx->src_wmax, sum_rs(ctx)};
   std::vector<double> all(3 * (size_t)std::max(g, 1));
   if (g > 1 && p2p) {
     if ((rc = p2p_agree_sum_bounds(ctx, mine, all))) return rc;

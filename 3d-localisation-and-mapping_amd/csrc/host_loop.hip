@@ -31,6 +31,7 @@ int ensure_source_box(ma_ctx* ctx) {
     ctx->src_lo[a] = (float)((double)lo[a] - pad);
     ctx->src_hi[a] = (float)((double)hi[a] + pad);
     r2 += std::max((double)lo[a] * lo[a], (double)hi[a] * hi[a]);
+    ctx->src_amax = std::max({ctx->src_amax, std::fabs((double)lo[a]), std::fabs((double)hi[a])});
   }
   ctx->src_rs = (float)(std::sqrt(r2) * 1.001 + 1e-4);
   ctx->src_box_pending = false;
@@ -43,7 +44,7 @@ int run_sum_scale(ma_ctx* ctx, double gate, SumScale* out) {
     if (!std::isfinite(gate)) { const int rc = ensure_source_box(ctx); if (rc) return rc; }     // only an ungated run's bounds look at rs
     b.n_total = (double)ctx->n;
     b.wmax = ctx->src_wmax;
-    b.rs = (double)ctx->src_rs;
+    b.rs = sum_rs(ctx);
   }
   *out = ma::sum_scale(b, ctx->gold_qb, gate, ctx->run_t0);
   return MA_OK;
@@ -509,7 +510,7 @@ int ma_sum_bounds_get(ma_ctx* ctx, double out[3]) {
   if ((rc = ensure_source_box(ctx))) return rc;
   out[0] = (double)ctx->n;
   out[1] = ctx->src_wmax;
-  out[2] = (double)ctx->src_rs;
+  out[2] = sum_rs(ctx);
   return MA_OK;
   });
 }

@@ -1182,6 +1182,7 @@ int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const f
       ctx->src_lo[a] = (float)(l - pad);
       ctx->src_hi[a] = (float)(h + pad);
       r2 += std::max(l * l, h * h);
+      ctx->src_amax = std::max({ctx->src_amax, std::fabs(l), std::fabs(h)});
     }
     ctx->src_rs = (float)(std::sqrt(r2) * 1.001 + 1e-4);
     ctx->src_box_pending = false;

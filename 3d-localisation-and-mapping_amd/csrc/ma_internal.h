@@ -361,6 +361,8 @@ struct ma_ctx {
   bool src_box_pending = false;                // source from a depth frame: the box is computed by the first run that can use it
   // exact sums (host_math.h): what bounds a correspondence's terms
   double src_wmax = 1.0;                       // largest weight of the source cloud (1 without weights)
+  double src_amax = 0.0;                       // largest |coordinate| of the source cloud (centred frame; with the box): what its radius for the sum
+                                               //   bounds derives from — a MAXIMUM, so that the largest over the shards of a cloud is the whole cloud's, exactly
   double gold_qb = 0.0;                        // largest |coordinate| of the gold map's grid box, centred frame
   double run_t0 = 0.0;                         // |t| of the transform the current run / stepping sequence started from (centred frame)
   bool sum_bounds_set = false;                 // ma_sum_bounds_set: the bounds of the WHOLE cloud of a sharded run ...
@@ -529,7 +531,10 @@ int ensure_source_box(ma_ctx* ctx);
 // the fixed-point scale of the 17 sums for a run gated at `gate` on the clouds and bounds in force (host_math.h)
 int run_sum_scale(ma_ctx* ctx, double gate, SumScale* out);
 // a new source cloud (or gold map): whatever was agreed for the old one no longer holds
-inline void source_replaced(ma_ctx* ctx) { ctx->sum_bounds_set = false; ctx->src_wmax = 1.0; }
+inline void source_replaced(ma_ctx* ctx) { ctx->sum_bounds_set = false; ctx->src_wmax = 1.0; ctx->src_amax = 0.0; }
+// radius of the source cloud for the sum bounds: |p| <= sqrt(3) max|coordinate| (a little padding for the fp32 rounding of the
+// stored coordinates; monotone in src_amax, so the maximum over shards stays the whole cloud's)
+inline double sum_rs(const ma_ctx* ctx) { return 1.7320508075688772 * ctx->src_amax * (1.0 + 1e-6) + 1e-6; }
 int need_ready(ma_ctx* ctx);
 int ensure_loop_buffers(ma_ctx* ctx, int trace_rows);
 int upload_state(ma_ctx* ctx, const double* T);

@@ -332,7 +332,8 @@ int ma_nn(ma_ctx* ctx, const double T[16], double max_corr_dist, uint32_t* idx_o
  * exponents e, i.e. agree on what bounds a term: the gold map's box (the same everywhere by construction), the gate (a
  * parameter), and three numbers of the comparison cloud —
  *     {n_total: points of the WHOLE cloud, wmax: its largest weight (1 without weights),
- *      rs: the largest distance of one of its points from the gold map's centring origin (only ungated runs use it)}.
+ *      rs: a radius of the cloud about the gold map's centring origin — sqrt(3) times its largest |coordinate| there, so that
+ *          the largest rs over the shards of a cloud IS the whole cloud's (only ungated runs use it)}.
  * ma_sum_bounds_get returns this context's own three (for its shard); ma_sum_bounds_set installs the whole cloud's:
  * {sum of the n, max of the wmax, max of the rs} over the shards — which is exactly what a single context holding the whole
  * cloud derives for itself.  ma_icp_sharded does this exchange itself — one small all-gather in the first call after a

@@ -317,3 +317,51 @@ def test_the_17_integer_sums_equal_an_exact_arithmetic_restatement(engine, weigh
     assert dev == ref, [(a, d - r) for a, (d, r) in enumerate(zip(dev, ref)) if d != r]
     if not weighted:
         assert dev[0] == int((match >= 0).sum()) << int(e[0])
+
+
+@pytest.mark.parametrize("gate,weighted", [(np.inf, False), (0.25, True)])
+def test_uneven_shards_ungated_and_weighted_equal_one_context_bitwise(lib_built, gate, weighted):
+    """The other bounds of the exact sums: an UNGATED run scales its terms from the comparison cloud's radius and the start
+    (so the shards must agree on rs), a weighted one from the largest weight (so they must agree on wmax).  Three uneven
+    random shards of a 90k-point cloud with the whole cloud's bounds installed, stepped with the sums added as integers:
+    the transform after 20 iterations is the single context's, bit for bit."""
+    import torch
+    from mapalign import dist as mdist
+    gold, comp, R0, t0 = syn.make_pair(13, 120_000, 90_000)
+    rng = np.random.default_rng(8)
+    w = rng.uniform(0.05, 7.5, len(comp)).astype(np.float32) if weighted else None
+    iters = 20
+    with mapalign.MapAligner(0) as full:
+        full.set_gold(gold)
+        full.set_source(comp, w)
+        ref = full.icp(iters, 0.0, gate, with_trace=True)
+        own = full.sum_bounds()
+    owner = rng.choice(3, size=len(comp), p=[0.55, 0.35, 0.10])
+    engs, accs = [], []
+    for r in range(3):
+        idx = np.flatnonzero(owner == r)
+        a = mapalign.MapAligner(0)
+        a.set_gold(gold)
+        a.set_source(comp[idx], None if w is None else w[idx])
+        he = mdist.HipShardEngine(a, gate, 0.0)
+        he.bind_current_stream()
+        engs.append(he)
+        accs.append(he.new_acc())
+    whole = mapalign.MapAligner.combine_sum_bounds([he.aligner.sum_bounds() for he in engs])
+    assert np.array_equal(whole, own)          # (sum n, max wmax, max rs) over the shards: the whole cloud's own bounds, exactly
+    for he in engs:
+        he.aligner.set_sum_bounds(whole)
+        he.state_set(None)
+    for _ in range(iters):
+        for he, acc in zip(engs, accs):
+            he.accumulate_into(acc)
+        total = accs[0] + accs[1] + accs[2]
+        for he, acc in zip(engs, accs):
+            acc.copy_(total)
+            he.solve_from(acc)
+    states = [he.state_get() for he in engs]
+    for he in engs:
+        he.aligner.use_own_stream()
+        he.aligner.close()
+    for T, info in states:
+        assert np.array_equal(T, ref.T) and info["rmse"] == ref.rmse and info["inliers"] == ref.inliers
