@@ -815,6 +815,10 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     }
   }
   uint32_t ndismissed = 0;
+  // The five exponents of the sums into scalar registers HERE, with the level set's fetch: left to the compiler they are
+  // fetched where they are first used — after the search, one scalar round trip in front of every workgroup's sums.
+  SumScale scl = sc;
+  if (MODE == 0) asm volatile("" : "+s"(scl.e[0]), "+s"(scl.e[1]), "+s"(scl.e[2]), "+s"(scl.e[3]), "+s"(scl.e[4]));
 #if MA_WGTIMES
   const unsigned long long dbg_t1 = wall_clock64();
 #endif
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       float3 q;
       if constexpr (lmode == 2) q = make_float3(wqx, wqy, wqz);     // carried with the minimum: the very bits of the gold array
       else q = ld_xyz(S.gold[0], bestj);           // the winner's coordinates (level 0 holds every point)
-      pair_terms(acc, (double)s.w, Px, Py, Pz, q, sc);
+      pair_terms(acc, (double)s.w, Px, Py, Pz, q, scl);
     }
     if (COUNT) { acc[17] = nrows; acc[18] = ncand; }
   }

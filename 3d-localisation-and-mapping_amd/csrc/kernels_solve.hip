@@ -236,6 +236,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const long long* __rest
   const int it_now = st->iter;
   DevState s0;
   if (threadIdx.x == 0) s0 = *st;   // whoever arrives last will need it: read it now, not after the hand-off
+  // this accumulator's exponent: fetched now (a scalar load beside the partials' loads), used after the sum
+  int e_k = k < ma::kAccLen ? sc.e[ma::sum_group(k)] : 0;
   const long long* __restrict__ p = partials + (size_t)k * G;
   unsigned long long v = 0ull;
   for (int b0 = threadIdx.x; b0 < G; b0 += 16 * kBlock) {
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const long long* __rest
     for (int t = 0; t < 16; ++t) v += (unsigned long long)u[t];
   }
   if (done) return;
+  asm volatile("" : "+s"(e_k));
   __shared__ unsigned long long red[kBlock / kWave];
   v = wave_sum_u64(v);
   if ((threadIdx.x & (kWave - 1)) == kSumLane) red[threadIdx.x / kWave] = v;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const long long* __rest
   // The sum leaves this workgroup as a NUMBER already (v 2^-e, the bits of the double in the 8-byte slot): nineteen lanes
   // on nineteen CUs convert side by side, where the solving lane would convert one after the other — on a lone wavefront,
   // 19 x (int64 -> fp64, scale) is 0.3-0.4 us of the iteration (profiles/r05_variants_ab.txt, call 3: 8.1 -> 8.4 us).
-  const double value = sum_value(sum, k, sc);
+  const double value = k < ma::kAccLen ? (double)sum * pow2_f64(-e_k) : (double)sum;
   __hip_atomic_store(&acc_out[k], __double_as_longlong(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // this accumulator's entry of the iteration's trace row (columns 0-16 the sums, 17 the rmse — the solve's —, 18 and 19
   // the two work counters)
