@@ -691,12 +691,23 @@ __device__ __forceinline__ void reduce_chunk(const unsigned long long (&acc)[kNA
   constexpr int kNW = kNNBlock / kWave;
   constexpr int kLive = COUNT ? kNAcc : ma::kAccLen;
   constexpr int kVals = kNW * 16, kPer = kVals / kRedParts;
+  // two passes over the accumulators instead of two steps per accumulator: the DPP read of a value then comes >= 16
+  // instruction pairs after the add that wrote it, so the adds need no wait states of their own (dpp_add_u64_far: the
+  // general form without its s_nop; tests/test_isa_hazards.py checks the distance in the built code).
+  // MA_REDUCE_ONEPASS=1 keeps the round's first form (both steps per accumulator, s_nop each) for tools/variants.py.
+  unsigned long long v[kLive];
+#if MA_REDUCE_ONEPASS
 #pragma unroll
-  for (int k = 0; k < kLive; ++k) {
-    unsigned long long v = dpp_add_u64<0x111>(acc[k]);
-    v = dpp_add_u64<0x112>(v);
-    if ((lane & 3) == 3) sh_w[wv].v[k][lane >> 2] = v;
-  }
+  for (int k = 0; k < kLive; ++k) v[k] = dpp_add_u64<0x112>(dpp_add_u64<0x111>(acc[k]));
+#else
+#pragma unroll
+  for (int k = 0; k < kLive; ++k) v[k] = dpp_add_u64_far<0x111>(acc[k]);
+#pragma unroll
+  for (int k = 0; k < kLive; ++k) v[k] = dpp_add_u64_far<0x112>(v[k]);
+#endif
+#pragma unroll
+  for (int k = 0; k < kLive; ++k)
+    if ((lane & 3) == 3) sh_w[wv].v[k][lane >> 2] = v[k];
   __syncthreads();
   if (threadIdx.x < kLive * kRedParts) {
     const int k = threadIdx.x / kRedParts, part = threadIdx.x % kRedParts;
@@ -815,10 +826,6 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     }
   }
   uint32_t ndismissed = 0;
-  // The five exponents of the sums into scalar registers HERE, with the level set's fetch: left to the compiler they are
-  // fetched where they are first used — after the search, one scalar round trip in front of every workgroup's sums.
-  SumScale scl = sc;
-  if (MODE == 0) asm volatile("" : "+s"(scl.e[0]), "+s"(scl.e[1]), "+s"(scl.e[2]), "+s"(scl.e[3]), "+s"(scl.e[4]));
 #if MA_WGTIMES
   const unsigned long long dbg_t1 = wall_clock64();
 #endif
@@ -936,7 +943,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       float3 q;
       if constexpr (lmode == 2) q = make_float3(wqx, wqy, wqz);     // carried with the minimum: the very bits of the gold array
       else q = ld_xyz(S.gold[0], bestj);           // the winner's coordinates (level 0 holds every point)
-      pair_terms(acc, (double)s.w, Px, Py, Pz, q, scl);
+      pair_terms(acc, (double)s.w, Px, Py, Pz, q, sc);
     }
     if (COUNT) { acc[17] = nrows; acc[18] = ncand; }
   }

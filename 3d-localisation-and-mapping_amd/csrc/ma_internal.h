@@ -61,6 +61,9 @@
 #include "kabsch.h"          // (header-only: kAccLen here, the solve itself in kernels_solve.hip)
 #include "list_planner.h"
 
+#ifndef MA_REDUCE_ONEPASS
+#define MA_REDUCE_ONEPASS 0      // 1: reduce_chunk with both DPP steps per accumulator (A/B; kernels_search.hip)
+#endif
 #ifndef MA_SCHED
 #define MA_SCHED 1      // longest-first schedule of the search launch's chunks (0: cloud order; A/B)
 #endif
@@ -176,6 +179,27 @@ constexpr int kSumLane = kWave - 1;
                  : "vcc");                                                                                                \
     return ((unsigned long long)rhi << 32) | rlo;                                                                         \
   }
+// ... and without the wait states, for callers that keep the producer of `v` at least two instructions away (reduce_chunk's
+// two passes over 17 values)
+#define MA_DPP_ADD_U64_FAR(NAME, CTRL_TEXT)                                                                              \
+  __device__ __forceinline__ unsigned long long NAME(const unsigned long long v) {                                       \
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);      /* in place: an instruction reads every lane's operands before it writes */ \
+    asm volatile("v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL_TEXT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"              \
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL_TEXT " row_mask:0xf bank_mask:0xf bound_ctrl:1"            \
+                 : "+v"(lo), "+v"(hi)                                                                                     \
+                 :                                                                                                        \
+                 : "vcc");                                                                                                \
+    return ((unsigned long long)hi << 32) | lo;                                                                           \
+  }
+MA_DPP_ADD_U64_FAR(dpp_add_u64_far_shr1, "row_shr:1")
+MA_DPP_ADD_U64_FAR(dpp_add_u64_far_shr2, "row_shr:2")
+#undef MA_DPP_ADD_U64_FAR
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_add_u64_far(const unsigned long long v) {
+  static_assert(CTRL == 0x111 || CTRL == 0x112, "DPP control");
+  if constexpr (CTRL == 0x111) return dpp_add_u64_far_shr1(v);
+  else return dpp_add_u64_far_shr2(v);
+}
 MA_DPP_ADD_U64(dpp_add_u64_shr1, "row_shr:1")
 MA_DPP_ADD_U64(dpp_add_u64_shr2, "row_shr:2")
 MA_DPP_ADD_U64(dpp_add_u64_shr4, "row_shr:4")
