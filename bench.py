@@ -81,12 +81,19 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=ITERS, help="oracle iterations for parity_vs_cpu (default: all 50)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs.c3 / c4 / c5_per_gpu objects")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the timed region and the roofline passes only (no end-to-end / CPU / extra legs, whose concurrent "
+                         "alignments would mix overlapped launches into a profiler's per-kernel averages): the run "
+                         "tools/profile_round.sh puts under rocprofv3 --kernel-trace --stats")
     # rehearsal on a one-GPU box only: several ranks share device 0 and rendezvous over gloo
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
     ap.add_argument("--force-device", type=int, default=None, help=argparse.SUPPRESS)
     # rehearsal of the N > 1 run's second region on ONE GPU: a 1-rank RCCL process group and communicator
     ap.add_argument("--rehearse-sharded", action="store_true", help=argparse.SUPPRESS)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_extra_configs = True
+    return args
 
 
 def launcher_command(args_list, n_gpus, port):
@@ -876,7 +883,8 @@ def main():
                     roof["survey_8d_cell"] = survey_cell_leg(gold, comp, local_rank)
                 except Exception as e:   # an auxiliary leg must never take the headline line down
                     roof["survey_8d_cell"] = {"error": f"{type(e).__name__}: {e}"}
-            e2e = end_to_end(gold, comp, local_rank)
+            if not args.headline_only:
+                e2e = end_to_end(gold, comp, local_rank)
             if not args.no_cpu_baseline:
                 cpu, parity = cpu_baseline_and_parity(eng, gold, comp, args.cpu_iters)
             if not args.no_extra_configs and args.points == N_POINTS:

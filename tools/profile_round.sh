@@ -24,7 +24,7 @@ if [[ $STEPS == *1* ]]; then
 echo "[1/5] kernel trace + stats of bench.py"
 rm -rf $R/gpurun_out/prof_bench
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -- \
-  python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extra-configs > $OUT/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof_bench.err \
+  python3 $R/bench.py --steps 5 --warmup 1 --headline-only > $OUT/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof_bench.err \
   || echo "bench under rocprof failed"
 python3 $R/tools/prof_summary.py $R/gpurun_out/prof_bench $OUT/${TAG}_kernel_trace_stats.txt > /dev/null
 fi
