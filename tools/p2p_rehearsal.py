@@ -78,7 +78,13 @@ def run_threads(a):
         times.append((time.perf_counter() - t0) * 1e3)
         bad = [f"rank {r}: {o}" for r, o in enumerate(out) if isinstance(o, Exception)]
         if bad:
-            return {"ok": False, "error": "; ".join(bad)}
+            res = {"ok": False, "mode": "threads", "ranks": a.ranks, "error": "; ".join(bad)}
+            if all("did not arrive within" in b for b in bad):
+                res["note"] = ("every rank ended by the bounded wait: contexts of ONE process share the runtime's hardware queues, and a "
+                               "waiting exchange kernel in front of a peer's search kernel in the same queue can only end by the timeout "
+                               "- an artefact of rehearsing several ranks in one process on one GPU (ranks in processes of their own, "
+                               "--mode procs, have their own queues)")
+            return res
     same = all(np.array_equal(o.T, ref.T) and o.iterations == ref.iterations and o.rmse == ref.rmse and o.inliers == ref.inliers
                for o in out)
     res = {"mode": "threads", "ranks": a.ranks, "points": a.points, "iterations": int(out[0].iterations),
