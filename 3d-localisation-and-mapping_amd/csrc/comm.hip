@@ -1,6 +1,7 @@
 // comm.hip — row e: the RCCL shim (librccl loaded with dlopen on first use), the communicator entry points and
 // ma_icp_sharded, the loop of host_loop.hip with the iteration's 17 sums all-reduced over the communicator's ranks.
 #include "ma_internal.h"
+#include <random>
 #include <rccl/rccl.h>   // types and prototypes only: librccl is loaded with dlopen at ma_comm_init
 #include <dlfcn.h>
 #include <unistd.h>
@@ -155,12 +156,22 @@ int comm_agree_sum_bounds(ma_ctx* ctx) {
 struct P2PBlob {
   unsigned long long magic;
   long long pid;
+  unsigned long long nonce;              // drawn once per process: equal pids in different pid namespaces are not one process
   int device, finegrained;
   unsigned long long ptr;
   hipIpcMemHandle_t handle;
 };
 static_assert(sizeof(P2PBlob) <= MA_P2P_BLOB_BYTES, "blob size");
-constexpr unsigned long long kP2PMagic = 0x4D41503250763031ull;      // "MAP2Pv01"
+constexpr unsigned long long kP2PMagic = 0x4D41503250763032ull;      // "MAP2Pv02"
+unsigned long long process_nonce() {
+  static const unsigned long long nonce = [] {
+    std::random_device rd;
+    unsigned long long v = ((unsigned long long)rd() << 32) ^ (unsigned long long)rd();
+    v ^= (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull;
+    return v ? v : 1ull;
+  }();
+  return nonce;
+}
 
 void p2p_release(ma_ctx* ctx) {
   for (int r = 0; r < ma::kXMaxRanks; ++r) {
@@ -283,9 +294,11 @@ int ma_p2p_export(ma_ctx* ctx, void* blob_out) {
   ctx->xchg_seq = 0;
   ctx->xchg_agree_gen = 0;
   ctx->xchg_broken = false;
+  ctx->xchg_fresh = true;
   P2PBlob b{};
   b.magic = kP2PMagic;
   b.pid = (long long)getpid();
+  b.nonce = process_nonce();
   b.device = ctx->device;
   b.finegrained = ctx->xchg_finegrained ? 1 : 0;
   b.ptr = (unsigned long long)reinterpret_cast<uintptr_t>(ctx->xchg);
@@ -306,7 +319,9 @@ int ma_p2p_init(ma_ctx* ctx, const void* blobs, int n_ranks, int rank) {
   if (!ctx) return MA_ERR_INVALID;
   if (!blobs || n_ranks < 1 || n_ranks > ma::kXMaxRanks || rank < 0 || rank >= n_ranks)
     return ctx->fail(MA_ERR_INVALID, "bad arguments (1 <= n_ranks <= 16, 0 <= rank < n_ranks)");
-  if (!ctx->xchg) return ctx->fail(MA_ERR_STATE, "ma_p2p_export first");
+  if (!ctx->xchg || !ctx->xchg_fresh)
+    return ctx->fail(MA_ERR_STATE, "ma_p2p_export before every ma_p2p_init (the export zeroes this rank's rows; rows of an earlier set-up "
+                                   "would pass for the new one's)");
   HIPCHK(hipSetDevice(ctx->device));
   p2p_release(ctx);
   const char* base = static_cast<const char*>(blobs);
@@ -314,13 +329,14 @@ int ma_p2p_init(ma_ctx* ctx, const void* blobs, int n_ranks, int rank) {
     P2PBlob b;
     std::memcpy(&b, base + (size_t)r * MA_P2P_BLOB_BYTES, sizeof(b));
     if (b.magic != kP2PMagic) { p2p_release(ctx); return ctx->fail(MA_ERR_INVALID, "blob " + std::to_string(r) + " is not a ma_p2p_export blob"); }
+    const bool same_process = b.pid == (long long)getpid() && b.nonce == process_nonce();
     if (r == rank) {
-      if (b.pid != (long long)getpid() || b.ptr != (unsigned long long)reinterpret_cast<uintptr_t>(ctx->xchg)) {
+      if (!same_process || b.ptr != (unsigned long long)reinterpret_cast<uintptr_t>(ctx->xchg)) {
         p2p_release(ctx);
         return ctx->fail(MA_ERR_INVALID, "blob [rank] is not this context's own export");
       }
       ctx->xchg_peer[r] = ctx->xchg;
-    } else if (b.pid == (long long)getpid()) {
+    } else if (same_process) {
       if (b.device != ctx->device) {     // another device of this process: direct access over xGMI
         int can = 0;
         (void)hipDeviceCanAccessPeer(&can, ctx->device, b.device);
@@ -341,6 +357,7 @@ int ma_p2p_init(ma_ctx* ctx, const void* blobs, int n_ranks, int rank) {
   }
   ctx->xchg_ranks = n_ranks;
   ctx->xchg_rank = rank;
+  ctx->xchg_fresh = false;
   ctx->xchg_seq = 0;
   ctx->xchg_agree_gen = 0;
   ctx->xchg_broken = false;

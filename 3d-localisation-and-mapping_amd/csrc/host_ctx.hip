@@ -49,6 +49,8 @@ void list_config_from_env(ma_ctx* ctx) {
   e = std::getenv("MAPALIGN_P2P_TIMEOUT_MS");           // how long a solving wave waits for its peers' sums (tests shorten it)
   const long tp = e ? std::atol(e) : 0;
   if (tp >= 1 && tp <= 30000) ctx->xchg_timeout_ms = (int)tp;
+  e = std::getenv("MAPALIGN_P2P_GENERIC");              // tests: exercise the instantiation that 9-16 ranks use with fewer ranks
+  ctx->xchg_force_generic = e && std::atoi(e) == 1;
 }
 
 }  // namespace mai

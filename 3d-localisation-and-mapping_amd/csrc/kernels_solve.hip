@@ -447,7 +447,7 @@ int launch_reduce_exchange_solve(ma_ctx* ctx, double tol, const SumScale& sc, St
                        ctx->last_gshift, ctx->host_done, slot ? &slot->s : ctx->host_state_out, slot, sc, xp,
                        (const unsigned long long*)ctx->xchg, ctx->xchg_seq, ticks);
   };
-  switch (np) {
+  switch (ctx->xchg_force_generic && np > 0 ? 15 : np) {
     case 0: go(k_reduce_exchange_solve<0>); break;
     case 1: go(k_reduce_exchange_solve<1>); break;
     case 2: go(k_reduce_exchange_solve<2>); break;

@@ -428,6 +428,9 @@ struct ma_ctx {
   bool xchg_broken = false;                    // a run ended in a communication failure: the ranks' counters may differ; set up again
   int comm_transport = 0;                      // ma_comm_config: 0 = RCCL all-reduce, 1 = the peer-to-peer exchange
   int xchg_timeout_ms = 2000;                  // how long the solving wave waits for its peers' rows (MAPALIGN_P2P_TIMEOUT_MS at ma_create)
+  bool xchg_fresh = false;                     // rows zeroed by ma_p2p_export and not yet used by a ma_p2p_init (one export per init:
+                                               // rows of an earlier set-up carry tags a new count from 0 would accept)
+  bool xchg_force_generic = false;             // MAPALIGN_P2P_GENERIC=1 at ma_create: always the guarded up-to-15-peers kernel (tests)
   int trace_cap = 0;
   int last_G = 0;
   uint32_t last_gshift = 0;

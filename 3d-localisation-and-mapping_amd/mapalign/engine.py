@@ -730,8 +730,8 @@ class MapAligner:
         """This context's rows, allocated and zeroed: the MA_P2P_BLOB_BYTES to hand to every rank (any channel, rank order)."""
         buf = (C.c_ubyte * _lib.MA_P2P_BLOB_BYTES)()
         self._chk(self._lib.ma_p2p_export(self._ctx, buf))
-        # (bytes 20-23 of the blob: bit 0 = the rows are fine-grained device memory, bit 1 = no IPC handle could be made)
-        flags = int.from_bytes(bytes(buf[20:24]), "little")
+        # (bytes 28-31 of the blob: bit 0 = the rows are fine-grained device memory, bit 1 = no IPC handle could be made)
+        flags = int.from_bytes(bytes(buf[28:32]), "little")
         self.p2p_rows = {"fine_grained": bool(flags & 1), "ipc_handle": not (flags & 2)}
         return bytes(buf)
 

@@ -396,7 +396,8 @@ int ma_comm_unique_id(void* id_out /* MA_COMM_ID_BYTES */);
  * returns MA_ERR_COMM — never a hang; the exchange must then be set up again.
  * Bootstrap: every rank calls ma_p2p_export (allocates and zeroes its rows, fills MA_P2P_BLOB_BYTES opaque bytes), the
  * blobs travel to all ranks by any channel IN RANK ORDER (torch.distributed all_gather, a file, MPI ...: that exchange is
- * also the barrier after which rows may be written), every rank calls ma_p2p_init with all of them.  Ranks may be
+ * also the barrier after which rows may be written), every rank calls ma_p2p_init with all of them — one export per
+ * init: a second ma_p2p_init on rows an earlier set-up has used returns MA_ERR_STATE until they are exported again.  Ranks may be
  * processes (the rows are mapped with hipIpcOpenMemHandle) or contexts of one process (pointers are used directly; on
  * different devices peer access is enabled); at most 16.  An exchange and an RCCL communicator may exist side by side:
  * ma_comm_config chooses which one ma_icp_sharded uses (MA_TRANSPORT_RCCL, the default while both exist, or

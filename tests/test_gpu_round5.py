@@ -139,6 +139,34 @@ def test_p2p_exchange_ranks_as_processes_return_the_single_context_bits(lib_buil
     assert res["ok"] and res["bitwise_equal_to_one_context"], res
 
 
+def test_p2p_exchange_guarded_kernel_of_nine_to_sixteen_ranks_with_three(lib_built):
+    """Nine to sixteen ranks run the instantiation of k_reduce_exchange_solve that is unrolled over 15 possible peers with a
+    guard each; no box holds that many ranks, so MAPALIGN_P2P_GENERIC=1 makes every context launch it with the ranks there
+    are: three processes, a convergence test, the single context's bits."""
+    res = _rehearse("--mode", "procs", "--ranks", "3", "--points", "200000", "--iters", "60", "--tol", "1e-7", "--reps", "3",
+                    env={"MAPALIGN_P2P_GENERIC": "1"})
+    print(res)
+    assert res["ok"] and res["bitwise_equal_to_one_context"], res
+
+
+def test_p2p_init_wants_a_fresh_export_and_this_process_own_blob(engine):
+    """ma_p2p_export zeroes this rank's rows; a second ma_p2p_init on the same rows would start counting from 0 again over
+    rows whose tags an earlier set-up left behind, so it is refused (MA_ERR_STATE) until the rows are exported again.  A blob
+    of another process (its nonce differs even where the pid does not) is not accepted as this context's own."""
+    blob = engine.p2p_export()
+    engine.p2p_init([blob], 0)
+    with pytest.raises(mapalign.MapAlignError) as e:
+        engine.p2p_init([blob], 0)
+    assert e.value.status == mapalign._lib.MA_ERR_STATE
+    forged = bytearray(engine.p2p_export())
+    forged[16] ^= 0xFF                                   # the process nonce (after magic and pid)
+    with pytest.raises(mapalign.MapAlignError) as e:
+        engine.p2p_init([bytes(forged)], 0)
+    assert e.value.status == mapalign._lib.MA_ERR_INVALID
+    engine.p2p_init([engine.p2p_export()], 0)            # and a proper bootstrap still works
+    engine.p2p_destroy()
+
+
 def test_p2p_exchange_contexts_of_one_process(lib_built):
     """The same with two CONTEXTS of one process (pointers used directly, one host thread each).  On one device this form
     needs the two contexts' streams on different hardware queues — the runtime decides that, and when it puts them into one
