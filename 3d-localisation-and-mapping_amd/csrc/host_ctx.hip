@@ -121,6 +121,7 @@ int ma_create(int device, ma_ctx** out) {
   static_assert(sizeof(DevState) <= 256, "pinned state slots are 256 bytes apart");
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->host_done), 1280 + kMaxSlots * sizeof(StateSlot), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
   std::memset(ctx->host_done, 0, 1024);
+  ctx->host_clk0 = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->host_done) + 64);
   ctx->host_state_in = reinterpret_cast<DevState*>(reinterpret_cast<char*>(ctx->host_done) + 256);
   ctx->host_state_out = reinterpret_cast<DevState*>(reinterpret_cast<char*>(ctx->host_done) + 512);
   static_assert(sizeof(ListCtl) <= 256 && sizeof(DevState) <= 256, "pinned block slots");

@@ -189,7 +189,6 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
       ctx->batch_ev.push_back(e);
     }
   }
-  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   if (timek) HIPCHK(hipEventRecord(ctx->kev[0], ctx->stream));
   struct ListsScope { ma_ctx* c; ~ListsScope() { c->lists_on = false; } } lists_scope{ctx};
   // Candidate lists (k_nn_accum<.,.,1|2>).  WHICH kernel an iteration launches is decided here, on the host, in
@@ -304,7 +303,6 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
     if (batch_exit && (k + 1) % kBatch == 0) HIPCHK(hipEventRecord(ctx->batch_ev[k / kBatch], ctx->stream));
   }
   ctx->plan_diag[3] = launched;
-  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (slots_used) {      // the state as the last solve that ran left it (the solve that stops a loop writes the last slot)
     *ctx->host_state_out = *ctx->host_state_in;
@@ -318,8 +316,10 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
     ctx->list_builds += ctx->list_plan[(size_t)i] == 1;
     ctx->list_uses += ctx->list_plan[(size_t)i] == 2;
   }
-  float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  // device time of the loop: from k_begin_run's clock stamp to the stamp of the last solve that ran (100 MHz, one clock for
+  // the whole device) — launches enqueued past a stop only find `done` set and are not part of it
+  const unsigned long long clk0 = *ctx->host_clk0;
+  const double ms = s.iter > 0 && s.clk > clk0 ? (double)(s.clk - clk0) * 1e-5 : 0.0;
   if (timek) {
     ctx->ktimes[0] = ctx->ktimes[1] = ctx->ktimes[2] = ctx->ktimes[3] = 0;
     ctx->iter_ms.clear();

@@ -34,6 +34,7 @@ struct DevState {
   int done;
   int converged;
   int degenerate;
+  unsigned long long clk;   // the device's 100 MHz clock when the solve that produced this state finished (ma_stats::gpu_ms)
 };
 
 // A/B knobs of the product build (csrc/Makefile `variant`); the defaults are the measured optimum.

@@ -139,6 +139,7 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
   if (degenerate) {
     s0.degenerate = 1;
     s0.done = 1;
+    s0.clk = wall_clock64();
     *st = s0;
     if (host_mirror) *host_mirror = s0;
     if (host_done) *host_done = s0.iter;     // iterations run when the loop stopped (never 0)
@@ -168,6 +169,7 @@ __device__ __forceinline__ void solve_step(const double (&a)[kNAcc], DevState s0
     if (host_done) *host_done = s0.iter;
   }
   s0.prev_rmse = rmse;
+  s0.clk = wall_clock64();
   *st = s0;
   // pinned host copy of the state (ma_icp): written with every solve, read by the host after its one
   // synchronisation — no device-to-host copy at the end of the loop (posted writes: the solve does not wait for them)
@@ -292,9 +294,12 @@ __global__ __launch_bounds__(kBlock) void k_reduce_solve(const long long* __rest
 // The state and the list control block a run starts from, handed over BY VALUE in the kernel's arguments: one tiny
 // launch instead of two small host-to-device copies in front of every loop (each copy is a DMA or blit of its own on
 // the stream, ~5 us of host time and as much on the device's).
+// It also stamps the run's start (the device's 100 MHz clock, into pinned host memory): the loop's device time is the last
+// solve's stamp minus this one — no timing events around the loop (two host calls and ~10 us of a 2.2 ms alignment,
+// profiles/r04_variants_ab.txt call 57).
 __global__ __launch_bounds__(kWave) void k_begin_run(const DevState s, const ListCtl c, DevState* __restrict__ st,
-                                                     ListCtl* __restrict__ lc) {
-  if (threadIdx.x == 0) { *st = s; *lc = c; }
+                                                     ListCtl* __restrict__ lc, unsigned long long* __restrict__ host_clk0) {
+  if (threadIdx.x == 0) { *host_clk0 = wall_clock64(); *st = s; *lc = c; }
 }
 // Row e without a library collective: a5 (final sum) + the EXCHANGE + a6 + a7 in one launch — a sharded iteration is two
 // launches, as an unsharded one is.  The 19 summing workgroups are k_reduce_solve's; the first wavefront of the one
@@ -412,6 +417,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce_exchange_solve(
     s0.iter = it_now + 1;
     s0.degenerate = 2;
     s0.done = 1;
+    s0.clk = wall_clock64();
     *st = s0;
     if (host_mirror) *host_mirror = s0;
     if (host_done) *host_done = s0.iter;
@@ -463,7 +469,8 @@ int launch_reduce_exchange_solve(ma_ctx* ctx, double tol, const SumScale& sc, St
 }
 
 int launch_begin_run(ma_ctx* ctx, const DevState& s, const ListCtl& c) {
-  hipLaunchKernelGGL(k_begin_run, dim3(1), dim3(kWave), 0, ctx->stream, s, c, ctx->state.as<DevState>(), ctx->listctl.as<ListCtl>());
+  hipLaunchKernelGGL(k_begin_run, dim3(1), dim3(kWave), 0, ctx->stream, s, c, ctx->state.as<DevState>(), ctx->listctl.as<ListCtl>(),
+                     ctx->host_clk0);
   HIPCHK(hipGetLastError());
   return MA_OK;
 }

@@ -320,6 +320,7 @@ struct ma_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned long long* host_clk0 = nullptr;     // pinned: k_begin_run's clock stamp (the start of a loop's device time)
   hipEvent_t evu0 = nullptr, evu1 = nullptr;   // around the last k_unproject launch (its count — and time — may be settled after other work has re-used ev0 / ev1)
   std::string err;
 

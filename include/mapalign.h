@@ -69,7 +69,7 @@ typedef struct ma_stats {
   int32_t reserved;
   double rmse;          /* sqrt(E/W) of the last iteration run (before its update) */
   double inliers;       /* W of the last iteration run */
-  double gpu_ms;        /* device time of the whole loop (hipEvent, on the ctx stream) */
+  double gpu_ms;        /* device time of the whole loop: first kernel of the run to the end of its last solve (the device's clock) */
 } ma_stats;
 
 typedef struct ma_grid_info {
