@@ -5,7 +5,8 @@ hazard recogniser does not look inside an asm block, so the distance rule — a 
 THROUGH DPP only two wait states later — is the source's to keep: the general form carries an ``s_nop 1``, the "far" form
 used by reduce_chunk's two passes relies on the 17 accumulators lying between a value's producer and its DPP read.  This
 test disassembles the gfx950 device code of the kernels that use them (hipcc cross-compiles here, no GPU needed) and checks
-every such instruction: none of the two preceding wait states may write the register it reads through DPP.
+every such instruction: none of the two preceding wait states may write the register it reads through DPP, and none of the
+five preceding ones may be a VALU write of EXEC (v_cmpx).
 """
 import os
 import re
@@ -85,6 +86,14 @@ def test_hand_written_dpp_adds_keep_two_wait_states_from_their_producers(unit):
                     assert not (_written(prev) & src0), (name, prev, line)      # the pair's low half writes another register
                 else:
                     assert not (_written(prev) & src0), f"{name}: `{prev}` writes a register `{line}` reads through DPP {states} wait state(s) later"
+                states += int(prev.split(" ")[1]) + 1 if pop == "s_nop" else 1
+                j -= 1
+            # second rule: a VALU write of EXEC (v_cmpx*) needs five wait states before a DPP instruction
+            states, j = 0, i - 1
+            while states < 5 and j >= 0:
+                prev = ins[j]
+                pop = prev.split(" ")[0]
+                assert not pop.startswith("v_cmpx"), f"{name}: `{prev}` writes EXEC {states} wait state(s) before `{line}`"
                 states += int(prev.split(" ")[1]) + 1 if pop == "s_nop" else 1
                 j -= 1
             checked += 1
