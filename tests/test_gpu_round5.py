@@ -347,6 +347,36 @@ def test_the_17_integer_sums_equal_an_exact_arithmetic_restatement(engine, weigh
         assert dev[0] == int((match >= 0).sum()) << int(e[0])
 
 
+def test_order_of_the_comparison_cloud_does_not_change_a_bit_at_full_size(engine):
+    """A size-independent law the exact sums buy, checked at BASELINE's full size (1M points, 50 iterations, list launches
+    in use): the comparison cloud in ANY order gives the same transform, the same per-iteration sums and the same stop, bit
+    for bit — the device sorts the scan into bricks of its own, a correspondence's 17 terms depend on the point, its match
+    and the transform only, and integer addition does not care in which chunk, workgroup or launch a term is added.
+    (The gold map's order is not free in the same way: an exact distance tie goes to the smaller gold position.)"""
+    gold, comp, _, _ = syn.make_pair(0, 1_000_000)
+    engine.set_gold(gold)
+    engine.set_source(comp)
+    a = engine.icp(50, 0.0, 0.10, with_trace=True)
+    uses = engine.list_stats()["uses"] if hasattr(engine, "list_stats") else None
+    rng = np.random.default_rng(77)
+    for rep in range(2):
+        engine.set_source(comp[rng.permutation(len(comp))])
+        b = engine.icp(50, 0.0, 0.10, with_trace=True)
+        assert np.array_equal(a.T, b.T) and a.rmse == b.rmse and a.inliers == b.inliers
+        assert np.array_equal(a.trace[:, :18], b.trace[:, :18])          # the 17 sums and the rmse of every iteration
+    # a weighted, ungated, early-stopping run of a ragged size as well
+    gold, comp, _, _ = syn.make_pair(5, 300_000, 212_345)
+    w = rng.uniform(0.1, 4.0, len(comp)).astype(np.float32)
+    engine.set_gold(gold)
+    engine.set_source(comp, w)
+    a = engine.icp(60, 1e-7, np.inf, with_trace=True)
+    perm = rng.permutation(len(comp))
+    engine.set_source(comp[perm], w[perm])
+    b = engine.icp(60, 1e-7, np.inf, with_trace=True)
+    assert a.iterations == b.iterations and np.array_equal(a.T, b.T) and np.array_equal(a.trace[:, :18], b.trace[:, :18])
+    print(f"1M pair: 2 permutations bitwise equal over 50 iterations (lists {uses}); weighted ungated 212k: stop at {a.iterations} on both")
+
+
 @pytest.mark.parametrize("gate,weighted", [(np.inf, False), (0.25, True)])
 def test_uneven_shards_ungated_and_weighted_equal_one_context_bitwise(lib_built, gate, weighted):
     """The other bounds of the exact sums: an UNGATED run scales its terms from the comparison cloud's radius and the start
