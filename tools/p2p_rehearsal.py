@@ -3,6 +3,7 @@ without a multi-GPU node: the protocol, the kernel, the bootstrap, the timeout. 
 
   python tools/p2p_rehearsal.py --mode threads --ranks 4      # 4 contexts of one process, one host thread each
   python tools/p2p_rehearsal.py --mode procs --ranks 2        # 2 processes (gloo carries the blobs; rows mapped with hipIpc*)
+  python tools/p2p_rehearsal.py --mode mixed --ranks 8 --procs 4   # 4 processes x 2 contexts: 8 ranks within the box's process limit
   python tools/p2p_rehearsal.py --mode timeout                # one of two ranks never runs: MA_ERR_COMM, not a hang
 
 Every mode compares with ma_icp of the whole cloud on one context: the transforms must be the same BITS.
@@ -25,8 +26,9 @@ sys.path.insert(0, ROOT)
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["threads", "procs", "timeout"], default="threads")
+    ap.add_argument("--mode", choices=["threads", "procs", "mixed", "timeout"], default="threads")
     ap.add_argument("--ranks", type=int, default=2)
+    ap.add_argument("--procs", type=int, default=4, help="mixed: processes the ranks are spread over (ranks / procs contexts each)")
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--tol", type=float, default=0.0)
@@ -150,6 +152,107 @@ def run_procs(a):
             "ma_icp_gpu_ms": round(float(ref_ms), 4)}
 
 
+def _mixed_worker(proc, n_procs, port, a_dict, q):
+    """Process `proc` of `n_procs` holds c = ranks / n_procs contexts (global ranks proc * c ... proc * c + c - 1), one host
+    thread each: rows of the same process are plain pointers, the other processes' come through hipIpcOpenMemHandle."""
+    ranks = a_dict["ranks"]
+    c = ranks // n_procs
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 2 * c + 2)))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import mapalign
+    from mapalign import dist as mdist, synthetic as syn
+    dist.init_process_group("gloo", rank=proc, world_size=n_procs)
+    gold, comp, _, _ = syn.make_pair(0, a_dict["points"])
+    err, out, ms = None, [None] * c, []
+    engs = []
+    try:
+        for k in range(c):
+            lo, hi = mdist.shard_bounds(len(comp), ranks, proc * c + k)
+            e = mapalign.MapAligner(0)
+            e.set_gold(gold)
+            e.set_source(comp[lo:hi])
+            engs.append(e)
+        mine = b"".join(bytes(e.p2p_export()) for e in engs)
+        t = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+        got = [torch.empty_like(t) for _ in range(n_procs)]
+        dist.all_gather(got, t)
+        blob_len = len(mine) // c
+        allb = b"".join(bytes(g.numpy().tobytes()) for g in got)
+        blobs = [allb[i * blob_len:(i + 1) * blob_len] for i in range(ranks)]
+        for k, e in enumerate(engs):
+            e.p2p_init(blobs, proc * c + k)
+        dist.barrier()
+
+        def work(k):
+            try:
+                out[k] = engs[k].icp_sharded(a_dict["iters"], a_dict["tol"], 0.10)
+            except Exception as ex:      # noqa: BLE001
+                out[k] = ex
+
+        for _ in range(a_dict["reps"]):
+            dist.barrier()
+            th = [threading.Thread(target=work, args=(k,)) for k in range(c)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            bad = [f"rank {proc * c + k}: {o}" for k, o in enumerate(out) if isinstance(o, Exception)]
+            if bad:
+                err = "; ".join(bad)
+                break
+            ms.append([float(o.gpu_ms) for o in out])
+    except Exception as ex:              # noqa: BLE001
+        err = f"{type(ex).__name__}: {ex}"
+    if err:
+        q.put((proc, None, err))
+    else:
+        q.put((proc, [(np.asarray(o.T), int(o.iterations), float(o.rmse), float(o.inliers)) for o in out],
+               [round(float(np.median([m[k] for m in ms])), 4) for k in range(c)]))
+    try:
+        dist.barrier()                  # nobody unmaps rows a peer may still be writing into
+        for e in engs:
+            e.p2p_destroy()
+            e.close()
+        dist.destroy_process_group()
+    except Exception:                    # noqa: BLE001 - a peer that failed has left
+        pass
+
+
+def run_mixed(a):
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+    from mapalign import synthetic as syn
+    if a.ranks % a.procs or a.ranks // a.procs < 1:
+        return {"ok": False, "mode": "mixed", "error": "--ranks must be a multiple of --procs"}
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    args = {"points": a.points, "iters": a.iters, "tol": a.tol, "reps": a.reps, "ranks": a.ranks}
+    procs = [ctx.Process(target=_mixed_worker, args=(p, a.procs, port, args, q)) for p in range(a.procs)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    errs = [g[2] for g in got if g[1] is None]
+    if errs:
+        return {"ok": False, "mode": "mixed", "ranks": a.ranks, "procs": a.procs, "error": "; ".join(errs)[:2000]}
+    gold, comp, _, _ = syn.make_pair(0, a.points)
+    ref, ref_ms = reference(gold, comp, a.iters, a.tol)
+    same = all(np.array_equal(T, ref.T) and it == ref.iterations and rm == ref.rmse and inl == ref.inliers
+               for g in got for (T, it, rm, inl) in g[1])
+    return {"ok": bool(same), "mode": "mixed", "ranks": a.ranks, "procs": a.procs, "contexts_per_process": a.ranks // a.procs,
+            "points": a.points, "iterations": int(got[0][1][0][1]), "bitwise_equal_to_one_context": bool(same),
+            "gpu_ms_per_rank": [v for g in sorted(got, key=lambda g: g[0]) for v in g[2]], "ma_icp_gpu_ms": round(float(ref_ms), 4)}
+
+
 def run_timeout(a):
     os.environ["MAPALIGN_P2P_TIMEOUT_MS"] = "300"
     import mapalign
@@ -194,7 +297,7 @@ def main():
         # process, and this process also holds the reference context's streams); ranks on different GPUs or in different
         # processes — the real thing — have their own queues anyway
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 2 * a.ranks + 4)))
-    res = {"threads": run_threads, "procs": run_procs, "timeout": run_timeout}[a.mode](a)
+    res = {"threads": run_threads, "procs": run_procs, "mixed": run_mixed, "timeout": run_timeout}[a.mode](a)
     print(json.dumps(res))
     sys.exit(0 if res.get("ok") else 1)
 
