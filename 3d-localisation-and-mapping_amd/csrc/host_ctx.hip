@@ -213,6 +213,14 @@ int ma_grid_info_get(const ma_ctx* ctx, ma_grid_info* out) {
   return MA_OK;
 }
 
+int ma_grid_box_get(const ma_ctx* ctx, double lo[3], double hi[3], int* bulk_only) {
+  if (!ctx || !lo || !hi) return MA_ERR_INVALID;
+  if (!ctx->have_gold) return MA_ERR_STATE;
+  for (int a = 0; a < 3; ++a) { lo[a] = (double)ctx->grid_lo[a]; hi[a] = (double)ctx->grid_hi[a]; }
+  if (bulk_only) *bulk_only = ctx->grid_halo ? 1 : 0;
+  return MA_OK;
+}
+
 int ma_set_source(ma_ctx* ctx, const float* xyz, const float* weights, uint64_t n64) {
   return guarded(ctx, [&]() -> int {
   if (!ctx) return MA_ERR_INVALID;

@@ -206,6 +206,52 @@ inline float clamp_cell_to_budget(const float lo[3], const float hi[3], float c,
   return c;
 }
 
+// ---- Robust grid box (stray points far from the scene) --------------------------------------------------------------------
+// The grid is a dense table over a box.  A handful of stray points far from the scene (reflections through windows,
+// sensor noise: RTAB-Map exports carry them) blow the bounding box up, the table budget then forces a coarse cell edge, and
+// a search that examines hundreds of candidates per cell runs 20-10 000 times longer (tools/outlier_probe.py: 20 stray
+// points over 5 / 50 times the scene's extent: 2.2 -> 43 ms / 7.9 s per alignment).  When the budget binds, the build
+// therefore histograms the coordinates per axis and puts the grid over the box that holds the bulk of the points: per axis
+// the central (1 - 2 kRobustTail) of the mass, widened by kRobustWiden of its width on either side (a uniformly filled
+// axis [0, 1] gives [0.05, 0.95] -> [-0.175, 1.175]: a clean scene keeps its own box), cut to the true bounds.  Points
+// outside it are STORED IN THE BOUNDARY CELLS (cell_of clamps its indices) with their true coordinates, and the search
+// (kernels_search.hip, HALO instantiations) treats a boundary cell as reaching outwards without limit: gaps to it drop
+// their outward term, cell indices are clamped for query and content alike (clamping both ends of a distance to an
+// interval never lengthens it), distances are formed from the true coordinates — exact for every query.  The grid then
+// goes over the bounds of the points INSIDE that box.  Any box is correct — the choice only decides how fast the search runs.
+constexpr int kAxisBins = 128;                 // histogram bins per axis and pass (+ one count below, one above the range)
+constexpr double kRobustTail = 0.05, kRobustWiden = 0.25;
+// One axis: the bin-edge interval [a, b] of [lo, hi] that leaves at most `tail` of the n points on either side.
+// h[0] = points below lo, h[1 .. bins] = the bins, h[bins + 1] = points above hi.
+inline void central_interval(const uint64_t* h, int bins, double lo, double hi, uint64_t n, double tail, double* a, double* b) {
+  const uint64_t allow = (uint64_t)std::floor(tail * (double)n);
+  const double w = (hi - lo) / (double)bins;
+  uint64_t cum = h[0];
+  int first = 0;
+  while (first < bins - 1 && cum + h[1 + first] <= allow) { cum += h[1 + first]; ++first; }
+  cum = h[bins + 1];
+  int last = bins - 1;
+  while (last > first && cum + h[1 + last] <= allow) { cum += h[1 + last]; --last; }
+  *a = lo + w * (double)first;
+  *b = lo + w * (double)(last + 1);
+}
+// The box from the central intervals of the three axes (widened, cut to the true bounds); true if it is smaller than the
+// true box along some axis by more than a twentieth — otherwise the true box stays (nothing to gain).
+inline bool robust_box(const double ca[3], const double cb[3], const float lo[3], const float hi[3], float rlo[3], float rhi[3]) {
+  bool smaller = false;
+  for (int k = 0; k < 3; ++k) {
+    const double w = std::max(cb[k] - ca[k], 0.0), pad = kRobustWiden * w + 1e-6;
+    const double l = std::max((double)lo[k], ca[k] - pad), h = std::min((double)hi[k], cb[k] + pad);
+    rlo[k] = (float)l;
+    rhi[k] = (float)h;
+    if (!(rhi[k] > rlo[k])) { rlo[k] = lo[k]; rhi[k] = hi[k]; }      // (a degenerate axis: all points in one plane)
+    if (rlo[k] > lo[k]) rlo[k] = std::nextafterf(rlo[k], -INFINITY);
+    if (rhi[k] < hi[k]) rhi[k] = std::nextafterf(rhi[k], INFINITY);
+    if ((double)rhi[k] - rlo[k] < 0.95 * ((double)hi[k] - lo[k])) smaller = true;
+  }
+  return smaller;
+}
+
 // Launch geometry of the search kernel: one source point per thread, kSearchBlock points per
 // chunk.  G (chunks, = workgroups) is a multiple of 8 * kXcdSegment (the XCD remap is a
 // bijection) and of kXcdSegment << gshift, where 2^gshift segments form one scheduling group

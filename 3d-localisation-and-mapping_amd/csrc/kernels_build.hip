@@ -11,15 +11,22 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // Per-workgroup min / max / non-finite count of an n x 3 fp32 cloud.
 // STRIDE floats per point: 3 for raw clouds, 4 for the float4 buffers.
+// `within`: only the points inside this box count towards the bounds (the rest is counted in slot 7) — the bounds of a
+// cloud's bulk once a box around it is known (host_math.h "Robust grid box"); (-inf, +inf) for the plain bounds.
+struct BoundsBox { float lo[3], hi[3]; };
 template <int STRIDE>
 __global__ __launch_bounds__(kBlock) void k_minmax(const float* __restrict__ xyz, uint32_t n,
-                                                   float* __restrict__ out /*[grid][8]*/, const int holes_ok) {
+                                                   float* __restrict__ out /*[grid][8]*/, const int holes_ok, const BoundsBox within) {
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  float bad = 0.f;
+  float bad = 0.f, outside = 0.f;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const float x = xyz[STRIDE * (size_t)i], y = xyz[STRIDE * (size_t)i + 1], z = xyz[STRIDE * (size_t)i + 2];
     if (holes_ok && __float_as_uint(x) == kHoleBits) continue;     // a hole of the in-place unprojection (float4 buffers)
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      if (x < within.lo[0] || x > within.hi[0] || y < within.lo[1] || y > within.hi[1] || z < within.lo[2] || z > within.hi[2]) {
+        outside += 1.f;
+        continue;
+      }
       lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
       lo[1] = fminf(lo[1], y); hi[1] = fmaxf(hi[1], y);
       lo[2] = fminf(lo[2], z); hi[2] = fmaxf(hi[2], z);
@@ -37,10 +44,11 @@ __global__ __launch_bounds__(kBlock) void k_minmax(const float* __restrict__ xyz
       hi[a] = fmaxf(hi[a], __shfl_down(hi[a], off, kWave));
     }
     bad += __shfl_down(bad, off, kWave);
+    outside += __shfl_down(outside, off, kWave);
   }
   if (lane == 0) {
     for (int a = 0; a < 3; ++a) { red[wv][a] = lo[a]; red[wv][3 + a] = hi[a]; }
-    red[wv][6] = bad; red[wv][7] = 0.f;
+    red[wv][6] = bad; red[wv][7] = outside;
   }
   __syncthreads();
   if (threadIdx.x < 8) {
@@ -50,6 +58,43 @@ __global__ __launch_bounds__(kBlock) void k_minmax(const float* __restrict__ xyz
       const float u = red[w][k];
       v = (k < 3) ? fminf(v, u) : (k < 6 ? fmaxf(v, u) : v + u);
     }
+    out[blockIdx.x * 8 + k] = v;
+  }
+}
+
+// What a HALO grid's boundary cells hold beyond their own interval (ma_internal.h HaloBox): per axis, the coordinate nearest
+// to the grid's box T among the points outside T that lie beyond it ALONG THAT AXIS — a point outside T may lie inside T's
+// range along two of the three axes.  out[b][0..2] = largest coordinate below T per axis (-inf: none), [3..5] = smallest
+// above it (+inf: none).
+__global__ __launch_bounds__(kBlock) void k_beyond(const float* __restrict__ xyz, uint32_t n, const BoundsBox T,
+                                                   float* __restrict__ out /*[grid][8]*/) {
+  float below[3] = {-INFINITY, -INFINITY, -INFINITY}, above[3] = {INFINITY, INFINITY, INFINITY};
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = xyz[3 * (size_t)i + a];
+      if (v < T.lo[a]) below[a] = fmaxf(below[a], v);
+      if (v > T.hi[a]) above[a] = fminf(above[a], v);
+    }
+  }
+  __shared__ float red[kBlock / kWave][8];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      below[a] = fmaxf(below[a], __shfl_down(below[a], off, kWave));
+      above[a] = fminf(above[a], __shfl_down(above[a], off, kWave));
+    }
+  }
+  if (lane == 0) {
+    for (int a = 0; a < 3; ++a) { red[wv][a] = below[a]; red[wv][3 + a] = above[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    float v = red[0][k];
+    for (int w = 1; w < kBlock / kWave; ++w) v = k < 3 ? fmaxf(v, red[w][k]) : fminf(v, red[w][k]);
     out[blockIdx.x * 8 + k] = v;
   }
 }
@@ -701,21 +746,48 @@ __global__ __launch_bounds__(kBlock) void k_occ_axis(const uint8_t* __restrict__
 
 static_assert(kMaxProbes * kProbeBlocks * 8 <= kMailWord - kMailProbe, "probe region of the mailbox");
 
+// Per-axis coordinate histograms of a cloud over the ranges [lo, lo + bins w] (host_math.h "Robust grid box"): slot 0 counts
+// what lies below a range, slot bins + 1 what lies above.  Integer LDS atomics, one partial histogram per workgroup
+// written straight into the pinned mailbox (the bounds region: the bounds have been read by then) and added up by the
+// host.  Only run when a cloud's bounding box is too large for the cell edge its density asks for — never for a clean scene.
+constexpr int kHistBlocks = 40, kHistSlots = ma::kAxisBins + 2;
+static_assert((size_t)kHistBlocks * 3 * kHistSlots * 4 <= kMailProbe, "bounds region of the mailbox");
+struct AxisRange { double lo[3], inv_w[3]; };
+__global__ __launch_bounds__(kBlock) void k_axis_hist(const float* __restrict__ xyz, const uint32_t n, const uint32_t step,
+                                                      const AxisRange r, uint32_t* __restrict__ out /*[grid][3][kHistSlots]*/) {
+  __shared__ uint32_t h[3][kHistSlots];
+  for (int k = threadIdx.x; k < 3 * kHistSlots; k += kBlock) (&h[0][0])[k] = 0u;
+  __syncthreads();
+  for (uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * step; i < n; i += (uint64_t)gridDim.x * kBlock * step) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double t = ((double)xyz[3 * (size_t)i + a] - r.lo[a]) * r.inv_w[a];
+      const int slot = t < 0.0 ? 0 : (t >= (double)ma::kAxisBins ? ma::kAxisBins + 1 : 1 + (int)t);
+      atomicAdd(&h[a][slot], 1u);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 3 * kHistSlots; k += kBlock) out[(size_t)blockIdx.x * 3 * kHistSlots + k] = (&h[0][0])[k];
+}
+
 }  // namespace
 
 namespace mai {
 
 // bounding box (and finiteness check) of a device-resident n x 3 cloud
-int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3], int stride, bool holes_ok, const Lane* lane) {
+int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3], int stride, bool holes_ok, const Lane* lane,
+                 const float* within_lo, const float* within_hi, double* n_outside) {
   const Lane ml = main_lane(ctx);
   const Lane& L = lane ? *lane : ml;
   const int nb = std::min<uint32_t>(div_up(n, kBlock), 1024);
   float* h = reinterpret_cast<float*>(L.mail);          // [nb][8], written by the kernel
-  if (stride == 4) hipLaunchKernelGGL(k_minmax<4>, dim3(nb), dim3(kBlock), 0, L.stream, d_xyz, n, h, holes_ok ? 1 : 0);
-  else hipLaunchKernelGGL(k_minmax<3>, dim3(nb), dim3(kBlock), 0, L.stream, d_xyz, n, h, 0);
+  BoundsBox within{{-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+  if (within_lo && within_hi) for (int a = 0; a < 3; ++a) { within.lo[a] = within_lo[a]; within.hi[a] = within_hi[a]; }
+  if (stride == 4) hipLaunchKernelGGL(k_minmax<4>, dim3(nb), dim3(kBlock), 0, L.stream, d_xyz, n, h, holes_ok ? 1 : 0, within);
+  else hipLaunchKernelGGL(k_minmax<3>, dim3(nb), dim3(kBlock), 0, L.stream, d_xyz, n, h, 0, within);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(L.stream));
-  double bad = 0;
+  double bad = 0, outside = 0;
   for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
   for (int b = 0; b < nb; ++b) {
     for (int a = 0; a < 3; ++a) {
@@ -723,8 +795,64 @@ int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float
       hi[a] = std::max(hi[a], h[(size_t)b * 8 + 3 + a]);
     }
     bad += h[(size_t)b * 8 + 6];
+    outside += h[(size_t)b * 8 + 7];
   }
+  if (n_outside) *n_outside = outside;
   if (bad > 0) return ctx->fail(MA_ERR_INVALID, "cloud has non-finite coordinates (filter them first, as the reference's read_point_cloud(remove_nan_points=True, remove_infinite_points=True) does)");
+  return MA_OK;
+}
+// k_beyond over a raw cloud: below[a] / above[a] as described there
+static int nearest_beyond(ma_ctx* ctx, const float* d_xyz, uint32_t n, const float lo[3], const float hi[3], float below[3], float above[3]) {
+  const int nb = std::min<uint32_t>(div_up(n, kBlock), 1024);
+  float* h = reinterpret_cast<float*>(ctx->mailbox);
+  BoundsBox T{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+  hipLaunchKernelGGL(k_beyond, dim3(nb), dim3(kBlock), 0, ctx->stream, d_xyz, n, T, h);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int a = 0; a < 3; ++a) { below[a] = -INFINITY; above[a] = INFINITY; }
+  for (int b = 0; b < nb; ++b)
+    for (int a = 0; a < 3; ++a) {
+      below[a] = std::max(below[a], h[(size_t)b * 8 + a]);
+      above[a] = std::min(above[a], h[(size_t)b * 8 + 3 + a]);
+    }
+  return MA_OK;
+}
+
+// Central interval of the cloud's mass along every axis (host_math.h "Robust grid box"): histogram passes over the true
+// bounds, zooming into the interval found while it is much narrower than the range it was found in (a stray point a
+// thousand scene-widths away leaves the whole scene in one bin of the first pass).  <= 4 passes, one synchronisation each.
+static int axis_central(ma_ctx* ctx, const float* d_xyz, uint32_t n, const float lo[3], const float hi[3], const Lane& L,
+                        double ca[3], double cb[3]) {
+  double rlo[3], rhi[3];
+  for (int a = 0; a < 3; ++a) { rlo[a] = lo[a]; rhi[a] = hi[a]; ca[a] = lo[a]; cb[a] = hi[a]; }
+  uint32_t* part = reinterpret_cast<uint32_t*>(L.mail);
+  const uint32_t step = std::max<uint32_t>(1u, n / (2u << 20));      // every step-th point: a sample of <= ~2M points says where the bulk is
+  for (int pass = 0; pass < 4; ++pass) {
+    AxisRange r{};
+    for (int a = 0; a < 3; ++a) {
+      const double w = (rhi[a] - rlo[a]) / (double)ma::kAxisBins;
+      r.lo[a] = rlo[a];
+      r.inv_w[a] = w > 0.0 ? 1.0 / w : 0.0;       // (a flat axis: every point in slot 1)
+    }
+    hipLaunchKernelGGL(k_axis_hist, dim3(kHistBlocks), dim3(kBlock), 0, L.stream, d_xyz, n, step, r, part);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(L.stream));
+    bool zoom = false;
+    for (int a = 0; a < 3; ++a) {
+      uint64_t h[kHistSlots] = {0};
+      for (int b = 0; b < kHistBlocks; ++b)
+        for (int k = 0; k < kHistSlots; ++k) h[k] += part[((size_t)b * 3 + a) * kHistSlots + k];
+      if (!(rhi[a] > rlo[a])) continue;
+      uint64_t sampled = 0;
+      for (int k = 0; k < kHistSlots; ++k) sampled += h[k];
+      ma::central_interval(h, ma::kAxisBins, rlo[a], rhi[a], sampled, ma::kRobustTail, &ca[a], &cb[a]);
+      if (cb[a] - ca[a] < (rhi[a] - rlo[a]) / 8.0 && cb[a] - ca[a] > 1e-9 * (std::fabs(ca[a]) + std::fabs(cb[a]) + 1e-30)) {
+        rlo[a] = ca[a]; rhi[a] = cb[a];
+        zoom = true;
+      }
+    }
+    if (!zoom) break;
+  }
   return MA_OK;
 }
 // Stable radix sort of (key, index) pairs, 32- or 64-bit keys: the three-kernel passes above.  Two-call pattern:
@@ -938,10 +1066,18 @@ int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   int rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, lo, hi);
   if (rc) return rc;
   MA_PT("gold: bounds read");
-  // centring origin: bounding-box centre, rounded to fp32 so that (x - o) is exact-ish
+  const float true_lo[3] = {lo[0], lo[1], lo[2]}, true_hi[3] = {hi[0], hi[1], hi[2]};
+  bool halo = false;            // the grid covers the bulk of the map only: points outside it sit in its boundary cells
+  float wlo[3] = {0, 0, 0}, whi[3] = {0, 0, 0};      // ... per axis, the nearest coordinate of such a point below / above the grid's box (raw frame)
+  float c = cell;
+  // Two attempts at most: over the bounding box, and — when the table budget forced a coarser cell edge than the map's
+  // density (or the caller) asked for — over the box that holds the bulk of the points (host_math.h "Robust grid box").
+  for (int attempt = 0; attempt < 2; ++attempt) {
+  bool binding = false;         // the table budget decided the cell edge
+  // centring origin: the box's centre, rounded to fp32 so that (x - o) is exact-ish
   for (int a = 0; a < 3; ++a) ctx->origin[a] = (double)(float)(0.5 * ((double)lo[a] + (double)hi[a]));
 
-  float c = cell;
+  c = cell;
   if (!(c > 0.f)) {
     // density-driven cell edge: aim at ~4.5 points per occupied cell (measured optimum of
     // table reads vs candidates on MI355X).  Scans are surfaces,
@@ -980,6 +1116,7 @@ int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
     double expo = 2.0;
     float c1 = (float)(c0 * std::pow(target / rho0, 1.0 / expo));
     c1 = std::min(std::max(c1, c0 / 16.f), c0 * 16.f);
+    float wanted = c1;
     c1 = clamp_cell_to_budget(lo, hi, c1, auto_cells);
     if (std::fabs(c1 / c0 - 1.f) > 0.05f) {
       GridP g1 = make_grid(lo, hi, ctx->origin, c1);
@@ -991,13 +1128,36 @@ int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
       }
       float c2 = (float)(c1 * std::pow(target / rho1, 1.0 / expo));
       c2 = std::min(std::max(c2, c1 / 4.f), c1 * 4.f);
+      wanted = c2;
       c = clamp_cell_to_budget(lo, hi, c2, auto_cells);
     } else {
       c = c1;
     }
+    binding = c > 1.15f * wanted;
   }
-  c = clamp_cell_to_budget(lo, hi, c, kMaxCells);
+  {
+    const float fits = clamp_cell_to_budget(lo, hi, c, kMaxCells);
+    binding = binding || fits > 1.0001f * c;
+    c = fits;
+  }
   if (!(c > 0.f) || !std::isfinite(c)) return ctx->fail(MA_ERR_INVALID, "could not choose a cell edge");
+  if (!binding || attempt == 1) break;
+  // The budget, not the map, decided the cell edge: is the bounding box that of a few stray points?
+  double ca[3], cb[3];
+  float rlo[3], rhi[3];
+  if ((rc = axis_central(ctx, ctx->raw.as<float>(), n, lo, hi, main_lane(ctx), ca, cb))) return rc;
+  if (!ma::robust_box(ca, cb, lo, hi, rlo, rhi)) break;      // no: a large or dense scene, the box stays
+  // yes: the grid goes over the bounds of the points INSIDE that box — the scene's own extent where the strays lie beyond it
+  float tlo[3], thi[3];
+  double n_out = 0;
+  if ((rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, tlo, thi, 3, false, nullptr, rlo, rhi, &n_out))) return rc;
+  if (!(n_out > 0) || !(thi[0] >= tlo[0])) break;
+  for (int a = 0; a < 3; ++a) { lo[a] = tlo[a]; hi[a] = thi[a]; }
+  // ... and, per axis, how near to that box the points outside it come along that axis (HaloBox)
+  if ((rc = nearest_beyond(ctx, ctx->raw.as<float>(), n, lo, hi, wlo, whi))) return rc;
+  halo = true;
+  MA_PT("gold: robust box chosen");
+  }
   MA_PT("gold: cell edge chosen");
   if (ctx->pair_handoff) ctx->pair_handoff->set(1, c);     // ma_set_pair: the scan's sort may start (origin and cell edge are final)
 
@@ -1102,10 +1262,20 @@ int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   }
   ctx->coarse_built = false;
   for (int a = 0; a < 3; ++a) { ctx->grid_lo[a] = lo[a]; ctx->grid_hi[a] = hi[a]; }
-  {   // largest |coordinate| a gold point can have in the centred frame (row a5's sum bounds)
+  {   // largest |coordinate| a gold point can have in the centred frame (row a5's sum bounds): of the TRUE bounds — a
+      // point beyond the grid's box is a gold point like any other
     double qb = 0.0;
-    for (int a = 0; a < 3; ++a) qb = std::max({qb, std::fabs((double)lo[a] - ctx->origin[a]), std::fabs((double)hi[a] - ctx->origin[a])});
+    for (int a = 0; a < 3; ++a) {
+      qb = std::max({qb, std::fabs((double)std::min(lo[a], true_lo[a]) - ctx->origin[a]), std::fabs((double)std::max(hi[a], true_hi[a]) - ctx->origin[a])});
+    }
     ctx->gold_qb = qb * (1.0 + 1e-6) + 1e-6;
+  }
+  ctx->grid_halo = halo;      // launch_nn picks the kernels that know what the boundary cells hold beyond their own interval
+  for (int a = 0; a < 3; ++a) {
+    // (centred like the stored points — the same subtraction, rounded to fp32 as k_gather rounds them — and moved one
+    // ulp towards the grid: what the boundary cells hold beyond their interval lies at or beyond these values)
+    ctx->halo_box.lo[a] = (halo && std::isfinite(wlo[a])) ? std::nextafterf((float)((double)wlo[a] - ctx->origin[a]), INFINITY) : -INFINITY;
+    ctx->halo_box.hi[a] = (halo && std::isfinite(whi[a])) ? std::nextafterf((float)((double)whi[a] - ctx->origin[a]), -INFINITY) : INFINITY;
   }
   // distance-to-occupied table of level 0: three separable passes, x (from the cell table), y, z
   {
@@ -1173,16 +1343,36 @@ int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const f
   // sort in the cloud's own frame with the gold map's cell edge (coarsened to fit 2^27
   // cells), brick-major: 256 consecutive points then form a compact patch, so that a
   // workgroup's queries share one small block of the gold grid under any rigid motion.
-  const float c = clamp_cell_to_budget(lo, hi, gold_cell, kMaxCells);
-  const GridP g = make_grid(lo, hi, ctx->origin, c);
+  float c = clamp_cell_to_budget(lo, hi, gold_cell, kMaxCells);
+  // The box the sort, the list planner and the lists' rounding allowance work with: the cloud's bounding box — or, when
+  // that box is too large for the gold map's cell edge (stray points far from the scene: host_math.h "Robust grid box"),
+  // the box of the bulk of the points.  Points outside it get the keys of its boundary bricks (cell_of clamps) and
+  // keep no candidate list (k_nn_accum, list-writing launch); they are queries like any other.
+  float blo[3] = {lo[0], lo[1], lo[2]}, bhi[3] = {hi[0], hi[1], hi[2]};
+  if (c > 1.0001f * gold_cell) {
+    double ca[3], cb[3];
+    float rlo[3], rhi[3];
+    if ((rc = axis_central(ctx, d_raw, n, lo, hi, L, ca, cb))) return rc;
+    if (ma::robust_box(ca, cb, lo, hi, rlo, rhi)) {
+      float tlo[3], thi[3];
+      double n_out = 0;
+      if ((rc = cloud_bounds(ctx, d_raw, n, tlo, thi, 3, false, &L, rlo, rhi, &n_out))) return rc;
+      if (n_out > 0 && thi[0] >= tlo[0]) {
+        for (int a = 0; a < 3; ++a) { blo[a] = tlo[a]; bhi[a] = thi[a]; }
+        c = clamp_cell_to_budget(blo, bhi, gold_cell, kMaxCells);
+      }
+    }
+  }
+  const GridP g = make_grid(blo, bhi, ctx->origin, c);
   {
     double r2 = 0.0;
     for (int a = 0; a < 3; ++a) {
-      const double l = (double)lo[a] - ctx->origin[a], h = (double)hi[a] - ctx->origin[a], pad = 1e-4 + 1e-6 * (std::fabs(l) + std::fabs(h));
+      const double l = (double)blo[a] - ctx->origin[a], h = (double)bhi[a] - ctx->origin[a], pad = 1e-4 + 1e-6 * (std::fabs(l) + std::fabs(h));
       ctx->src_lo[a] = (float)(l - pad);
       ctx->src_hi[a] = (float)(h + pad);
       r2 += std::max(l * l, h * h);
-      ctx->src_amax = std::max({ctx->src_amax, std::fabs(l), std::fabs(h)});
+      // (the sums' bound on |p| is that of EVERY point: the true bounds)
+      ctx->src_amax = std::max({ctx->src_amax, std::fabs((double)lo[a] - ctx->origin[a]), std::fabs((double)hi[a] - ctx->origin[a])});
     }
     ctx->src_rs = (float)(std::sqrt(r2) * 1.001 + 1e-4);
     ctx->src_box_pending = false;

@@ -105,12 +105,49 @@ __device__ __forceinline__ void scan_run(const float px, const float py, const f
   best2 = __uint_as_float((uint32_t)(key >> 32) + (bestj == kNoMatch ? 1u : 0u));
 }
 
+// HALO (host_math.h "Robust grid box"): the grid covers only the bulk of the gold map, and the points beyond its box are
+// stored in its BOUNDARY cells (cell_of clamps its indices) with their true coordinates.  Along an axis the content of a
+// boundary cell is then its own interval plus a part of the half-line that starts at the nearest such point's coordinate
+// (HaloBox: w_lo / w_hi), with nothing in between, and every test of cell geometry knows it:
+//   * the gap between a query and a row (or slab) of boundary index is the smaller of the gap to the row's own interval
+//     and the gap to that half-line — for a query near the scene the former, exactly what an ordinary grid computes
+//     (stray points are usually far), for a stray query out there zero;
+//   * along x a sphere that ends beyond the row's end reaches the end cell only if it reaches that half-line;
+//   * ring bounds and the distance-to-occupied table work on cell indices, which are clamped for query and content
+//     alike — clamping both ends of a distance to an interval never lengthens it — and hold as they are.
+// Distances are formed from the true coordinates, so the search stays exact for every query, inside the box or not.
+// A compile-time switch: for an ordinary map (every point inside its cell) the kernels are instruction for instruction
+// what they were.
+template <bool HALO>
+__device__ __forceinline__ float row_gap(const float below, const float above, const int idx, const int n, const float q,
+                                         const float w_lo, const float w_hi) {
+  // below = (row's lower edge - slack) - q, above = q - (row's upper edge + slack): the gap is the positive one, if any
+  float t = fmaxf(0.f, fmaxf(below, above));
+  if (HALO) {
+    if (idx == n - 1) t = fminf(t, fmaxf(0.f, w_hi - q));
+    if (idx == 0) t = fminf(t, fmaxf(0.f, q - w_lo));
+  }
+  return t;
+}
+template <bool HALO>
+__device__ __forceinline__ void x_cells(const float px, const float rx, const float ox, const float inv_c, const int nx, int& x0, int& x1,
+                                        const float w_lo, const float w_hi) {
+  const float f0 = floorf((px - rx - ox) * inv_c), f1 = floorf((px + rx - ox) * inv_c);
+  x0 = (int)fmaxf(f0, 0.f);
+  x1 = (int)fminf(f1, (float)(nx - 1));
+  if (HALO) {
+    // a sphere that lies beyond the row's end still reaches what the end cell holds out there, if it reaches the nearest of it
+    if (f0 > (float)(nx - 1) && px + rx >= w_hi) x0 = x1 = nx - 1;
+    if (f1 < 0.f && px - rx <= w_lo) x0 = x1 = 0;
+  }
+}
+
 // One pass at one level: the 3 x 3 rows around the query's row (rings 0 and 1), each over
 // the x-run the current best sphere reaches.  Exact for every gold point within
 // (c - delta) of the query.
-template <bool COUNT>
+template <bool COUNT, bool HALO>
 __device__ __forceinline__ void level_pass(const float px, const float py, const float pz,
-                                           const LevelView& V, const LevelSet& S, float& best2,
+                                           const LevelView& V, const LevelSet& S, const HaloBox& hb, float& best2,
                                            uint32_t& bestj, uint32_t& nrows, uint32_t& ncand) {
   const float uy = fminf(fmaxf((py - S.oy) * V.inv_c, -1.f), (float)V.ny);
   const float uz = fminf(fmaxf((pz - S.oz) * V.inv_c, -1.f), (float)V.nz);
@@ -121,7 +158,7 @@ __device__ __forceinline__ void level_pass(const float px, const float py, const
     const int z = cz + (sl == 0 ? 0 : (sl == 1 ? -1 : 1));
     if ((unsigned)z >= (unsigned)V.nz) continue;
     const float zlo = S.oz + (float)z * V.c;
-    const float dzq = fmaxf(0.f, fmaxf(zlo - S.delta - pz, pz - (zlo + V.c + S.delta)));
+    const float dzq = row_gap<HALO>(zlo - S.delta - pz, pz - (zlo + V.c + S.delta), z, V.nz, pz, hb.lo[2], hb.hi[2]);
     if (dzq * dzq > best2) continue;      // (>, <= below: a tie at distance 0 must still be examined)
     uint32_t a[3], b[3];
     // phase 1: the slab's three row tests + table reads, independent => one round trip
@@ -132,12 +169,12 @@ __device__ __forceinline__ void level_pass(const float px, const float py, const
       b[k] = 0u;
       if ((unsigned)y < (unsigned)V.ny) {
         const float ylo = S.oy + (float)y * V.c;
-        const float dyq = fmaxf(0.f, fmaxf(ylo - S.delta - py, py - (ylo + V.c + S.delta)));
+        const float dyq = row_gap<HALO>(ylo - S.delta - py, py - (ylo + V.c + S.delta), y, V.ny, py, hb.lo[1], hb.hi[1]);
         const float d2yz = dyq * dyq + dzq * dzq;
         if (d2yz <= best2) {
           const float rx = fast_sqrt(best2 - d2yz) + S.delta;  // +inf while ungated and unmatched
-          const int x0 = (int)fmaxf(floorf((px - rx - S.ox) * V.inv_c), 0.f);
-          const int x1 = (int)fminf(floorf((px + rx - S.ox) * V.inv_c), (float)(V.nx - 1));
+          int x0, x1;
+          x_cells<HALO>(px, rx, S.ox, V.inv_c, V.nx, x0, x1, hb.lo[0], hb.hi[0]);
           if (x0 <= x1) {
             const uint32_t cell = (uint32_t)((z * V.ny + y) * V.nx + x0);
             const int span = x1 - x0;  // cells beyond the first
@@ -166,9 +203,9 @@ __device__ __forceinline__ void level_pass(const float px, const float py, const
 // distance found.  Inside a row only the x-run the best sphere can reach is scanned — one
 // contiguous slice of the level's array.  Rows are handled four at a time: their tests
 // and table reads are independent, so a batch costs one memory round trip, not four.
-template <bool COUNT>
+template <bool COUNT, bool HALO>
 __device__ __forceinline__ void ring_walk(const float px, const float py, const float pz,
-                                          const LevelView& V, const LevelSet& S, const int r_start,
+                                          const LevelView& V, const LevelSet& S, const HaloBox& hb, const int r_start,
                                           float& best2, uint32_t& bestj, uint32_t& nrows,
                                           uint32_t& ncand) {
   // centre row, clamped to one cell outside the grid: for a query outside the grid the
@@ -201,13 +238,13 @@ __device__ __forceinline__ void ring_walk(const float px, const float py, const 
             const int y = cy + dy, z = cz + dz;
             if ((unsigned)y < (unsigned)V.ny && (unsigned)z < (unsigned)V.nz) {
               const float ylo = S.oy + (float)y * V.c, zlo = S.oz + (float)z * V.c;
-              const float dyq = fmaxf(0.f, fmaxf(ylo - S.delta - py, py - (ylo + V.c + S.delta)));
-              const float dzq = fmaxf(0.f, fmaxf(zlo - S.delta - pz, pz - (zlo + V.c + S.delta)));
+              const float dyq = row_gap<HALO>(ylo - S.delta - py, py - (ylo + V.c + S.delta), y, V.ny, py, hb.lo[1], hb.hi[1]);
+              const float dzq = row_gap<HALO>(zlo - S.delta - pz, pz - (zlo + V.c + S.delta), z, V.nz, pz, hb.lo[2], hb.hi[2]);
               const float d2yz = dyq * dyq + dzq * dzq;
               if (d2yz <= best2) {
                 const float rx = fast_sqrt(best2 - d2yz) + S.delta;
-                const int x0 = (int)fmaxf(floorf((px - rx - S.ox) * V.inv_c), 0.f);
-                const int x1 = (int)fminf(floorf((px + rx - S.ox) * V.inv_c), (float)(V.nx - 1));
+                int x0, x1;
+                x_cells<HALO>(px, rx, S.ox, V.inv_c, V.nx, x0, x1, hb.lo[0], hb.hi[0]);
                 if (x0 <= x1) {
                   const uint32_t row = (uint32_t)((z * V.ny + y) * V.nx);
                   a[u] = ld_cell(V.cs, row + (uint32_t)x0);
@@ -229,9 +266,9 @@ __device__ __forceinline__ void ring_walk(const float px, const float py, const 
 // iteration's match, which is a valid candidate and usually already the answer.
 // The level is a WAVE-UNIFORM loop variable: all lanes still searching work on the same
 // level, so its array bases and grid constants live in scalar registers.
-template <bool COUNT>
+template <bool COUNT, bool HALO>
 __device__ __forceinline__ void nn_find(const float px, const float py, const float pz,
-                                        const LevelSet& S, float& best2, uint32_t& bestj,
+                                        const LevelSet& S, const HaloBox& hb, float& best2, uint32_t& bestj,
                                         uint32_t& nrows, uint32_t& ncand) {
   // 1. Probe the 3 x 3 rows of the finest level: the true neighbour of a point on a
   //    scanned surface is almost always there, and the pass is then already exact.
@@ -263,13 +300,13 @@ __device__ __forceinline__ void nn_find(const float px, const float py, const fl
     if (!__any(active)) break;
     const LevelView V{S.gold[l], S.cs[l], S.c[l], S.inv_c[l], S.nx[l], S.ny[l], S.nz[l]};
     if (active) {
-      level_pass<COUNT>(px, py, pz, V, S, best2, bestj, nrows, ncand);
+      level_pass<COUNT, HALO>(px, py, pz, V, S, hb, best2, bestj, nrows, ncand);
       const float lim = V.c - S.delta, wide = kWalkCells * V.c;
       if (best2 <= lim * lim) {
         active = false;  // the pass covered the whole best sphere: exact
       } else if (l == kLevels - 1 || best2 <= wide * wide) {
         // rings 0 and 1 are done (the pass scanned the full x-run of each of its rows)
-        ring_walk<COUNT>(px, py, pz, V, S, 2, best2, bestj, nrows, ncand);
+        ring_walk<COUNT, HALO>(px, py, pz, V, S, hb, 2, best2, bestj, nrows, ncand);
         active = false;
       }
     }
@@ -388,8 +425,8 @@ __device__ __forceinline__ void wq_flush_chunks(WaveLds& W, const int lane, cons
 }
 
 
-template <bool COUNT, bool BUILD>
-__device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const LevelSet& S, uint32_t& nrow,
+template <bool COUNT, bool BUILD, bool HALO>
+__device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const LevelSet& S, const HaloBox& hb, uint32_t& nrow,
                                               uint32_t& nchunk, uint32_t& nrows_cnt, uint32_t& ncand, const float skin,
                                               const ListPlanes& lp, const uint32_t slot0) {
   const float4* __restrict__ gold0 = S.gold[0];
@@ -414,8 +451,8 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
         if (BUILD) { const float r = fast_sqrt(b2) + skin; b2 = r * r; }
         if (d2yz <= b2) {
           const float rx = fast_sqrt(b2 - d2yz) + S.delta;
-          const int x0 = (int)fmaxf(floorf((p.x - rx - S.ox) * inv_c), 0.f);
-          const int x1 = (int)fminf(floorf((p.x + rx - S.ox) * inv_c), (float)(nx - 1));
+          int x0, x1;
+          x_cells<HALO>(p.x, rx, S.ox, inv_c, nx, x0, x1, hb.lo[0], hb.hi[0]);
           if (x0 <= x1) {
             const uint32_t cell = W.row_cell[i] + (uint32_t)x0;
             const int span = x1 - x0;
@@ -455,9 +492,9 @@ __device__ __forceinline__ void wq_flush_rows(WaveLds& W, const int lane, const 
 }
 
 // All 64 lanes of the wavefront must call this together.
-template <bool COUNT, bool BUILD>
+template <bool COUNT, bool BUILD, bool HALO>
 __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bool has_query, const float px,
-                                            const float py, const float pz, const LevelSet& S, float& best2,
+                                            const float py, const float pz, const LevelSet& S, const HaloBox& hb, float& best2,
                                             uint32_t& bestj, uint32_t& nrows_cnt, uint32_t& ncand,
                                             uint32_t& ndismissed, const float skin = 0.f,
                                             const ListPlanes& lp = ListPlanes{}, const uint32_t slot0 = 0) {
@@ -486,7 +523,7 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     const unsigned long long mask = __ballot(pred);
     const uint32_t cnt = (uint32_t)__popcll(mask);
     if (cnt == 0u) return;
-    if (nrow + cnt > (uint32_t)kRowCap) wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lp, slot0);
+    if (nrow + cnt > (uint32_t)kRowCap) wq_flush_rows<COUNT, BUILD, HALO>(W, lane, S, hb, nrow, nchunk, nrows_cnt, ncand, skin, lp, slot0);
     if (pred) {
       const uint32_t pos = nrow + lane_prefix(mask);
       W.row_cell[pos] = (uint32_t)((z * ny + y) * nx);
@@ -501,14 +538,15 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
   // then one add and one compare per row (the direct form costs 22 VALU ops per row, a
   // quarter of a converged iteration).  Same bounds up to rounding, which `delta` covers.
   const float fy = py - (S.oy + (float)cy * c), fz = pz - (S.oz + (float)cz * c);
-  auto gap2 = [&](const int d, const float f, const int ci, const int n) -> float {
+  auto gap2 = [&](const int d, const float f, const int ci, const int n, const int axis /* 1 = y, 2 = z */) -> float {
     const float lo = ((float)d * c - S.delta) - f, hi = f - ((float)(d + 1) * c + S.delta);
-    const float t = fmaxf(0.f, fmaxf(lo, hi));
+    const bool is_y = axis == 1;
+    const float t = row_gap<HALO>(lo, hi, ci + d, n, is_y ? py : pz, is_y ? hb.lo[1] : hb.lo[2], is_y ? hb.hi[1] : hb.hi[2]);
     return (unsigned)(ci + d) < (unsigned)n ? t * t : NAN;     // outside the grid: no comparison with it holds (<= included)
   };
   {
-    const float gy[3] = {gap2(0, fy, cy, ny), gap2(-1, fy, cy, ny), gap2(1, fy, cy, ny)};
-    const float gz[3] = {gap2(0, fz, cz, nz), gap2(-1, fz, cz, nz), gap2(1, fz, cz, nz)};
+    const float gy[3] = {gap2(0, fy, cy, ny, 1), gap2(-1, fy, cy, ny, 1), gap2(1, fy, cy, ny, 1)};
+    const float gz[3] = {gap2(0, fz, cz, nz, 2), gap2(-1, fz, cz, nz, 2), gap2(1, fz, cz, nz, 2)};
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int dy = (k % 3 == 0) ? 0 : (k % 3 == 1 ? -1 : 1), dz = (k / 3 == 0) ? 0 : (k / 3 == 1 ? -1 : 1);
@@ -516,7 +554,7 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
       push_row(finite && d2yz <= bi, cy + dy, cz + dz, d2yz);
     }
   }
-  wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lp, slot0);
+  wq_flush_rows<COUNT, BUILD, HALO>(W, lane, S, hb, nrow, nchunk, nrows_cnt, ncand, skin, lp, slot0);
   wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lp, slot0);
 #if MA_WGTIMES
   if (lane == 0) W.dbg_round0 = wall_clock64();
@@ -560,22 +598,22 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
       const int dfix = (side == 0 || side == 3) ? -r : r;
       const float ffix = zfixed ? fz : fy, fvar = zfixed ? fy : fz;
       const int cfix = zfixed ? cz : cy, cvar = zfixed ? cy : cz, nfix = zfixed ? nz : ny, nvar = zfixed ? ny : nz;
-      const float gfix = gap2(dfix, ffix, cfix, nfix);
+      const float gfix = gap2(dfix, ffix, cfix, nfix, zfixed ? 2 : 1);
       for (int o = 0; o < 2 * r; ++o) {
         const int dvar = side < 2 ? o - r : r - o;
-        const float d2yz = gfix + gap2(dvar, fvar, cvar, nvar);
+        const float d2yz = gfix + gap2(dvar, fvar, cvar, nvar, zfixed ? 1 : 2);
         const int dy = zfixed ? dvar : dfix, dz = zfixed ? dfix : dvar;
         push_row(more && d2yz <= bi, cy + dy, cz + dz, d2yz);
       }
     }
-    wq_flush_rows<COUNT, BUILD>(W, lane, S, nrow, nchunk, nrows_cnt, ncand, skin, lp, slot0);
+    wq_flush_rows<COUNT, BUILD, HALO>(W, lane, S, hb, nrow, nchunk, nrows_cnt, ncand, skin, lp, slot0);
     wq_flush_chunks<COUNT, BUILD>(W, lane, gold0, nchunk, ncand, skin, lp, slot0);
     const unsigned long long key = W.best[lane];
     best2 = held_d2(key);
     bestj = (uint32_t)key;
     bi = reach(best2);
   }
-  if (fallback) nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows_cnt, ncand);
+  if (fallback) nn_find<COUNT, HALO>(px, py, pz, S, hb, best2, bestj, nrows_cnt, ncand);
   if (BUILD) {
     // The list is complete inside the radius L: everything within (match distance + skin) was examined — the
     // block and the rings cover the widened sphere, a dismissed query has nothing that near at all — and put on
@@ -586,6 +624,10 @@ __device__ __forceinline__ void wave_search(WaveLds& W, const int lane, const bo
     float L = fallback ? 0.f : fast_sqrt(best2) + skin;
     if (cnt > (uint32_t)kListLen) L = fminf(L, fast_sqrt(__uint_as_float(W.minx[lane])));
     L *= 1.f - 4e-6f;
+    // The query's own rounding allowance: its fp32 image is within an ulp of where the fp64 transform puts it, now and in
+    // the launches that read the list — 1.2e-7 |p| each.  ListCtl::slack covers that for a point inside the cloud's box
+    // (or the box of its bulk, build_source_from_raw); a stray point a kilometre away pays for itself here.
+    L = fmaxf(L - 1.5e-6f * (fabsf(px) + fabsf(py) + fabsf(pz)), 0.f);
     if (!finite) L = INFINITY;
     const uint32_t kept = min(cnt, (uint32_t)kListLen);
     if (has_query) {
@@ -747,12 +789,16 @@ __device__ uint32_t g_wvt[16][4096][4];    // iterations 0-15, EVERY wavefront: 
 #ifdef MA_NN_WAVES
 #define MA_NN_ATTR __attribute__((amdgpu_waves_per_eu(MA_NN_WAVES, MA_NN_WAVES)))
 #else
-#define MA_NN_ATTR __attribute__((amdgpu_waves_per_eu((MODE == 0 && LISTS != 1 && !COUNT) ? 8 : 4, 8)))
+// (HALO instantiations, A/B knob MA_HALO_MIN_WAVES: forced to 8 waves the boundary-cell tests spill 8-9 dwords)
+#ifndef MA_HALO_MIN_WAVES
+#define MA_HALO_MIN_WAVES 7
+#endif
+#define MA_NN_ATTR __attribute__((amdgpu_waves_per_eu((MODE == 0 && LISTS != 1 && !COUNT) ? (HALO ? MA_HALO_MIN_WAVES : 8) : 4, 8)))
 #endif
 // LISTS (compile time, so that the plain search launch keeps its 63 VGPRs — a run-time switch between the three bodies
 // cost 6 VGPRs, a wavefront per SIMD and 10 % of every search launch): 0 search; 1 search and write the candidate lists;
 // 2 read the lists.  The host picks the kernel per iteration from the step sizes the solve reports (ma_icp).
-template <bool COUNT, int MODE, int LISTS>
+template <bool COUNT, int MODE, int LISTS, bool HALO>
 // (Argument order: the first 16 dwords are preloaded into scalar registers at dispatch — csrc/Makefile — so the state,
 // the source cloud, the remembered matches and the schedule, which the first instructions of a workgroup need, come
 // first; the level set, 200 bytes by value, is fetched while the first loads are in flight.)
@@ -760,7 +806,8 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
     const DevState* __restrict__ st, const float4* __restrict__ src, const uint32_t n, const int warm_hint,
     uint32_t* __restrict__ prev, const Sched sched, long long* __restrict__ partials, const float best2_init,
     const LevelSet S, const uint32_t* __restrict__ perm0, uint32_t* __restrict__ nn_idx,
-    float* __restrict__ nn_d2, const ListCtl* __restrict__ lc, const ListPlanes lp, const SumScale sc) {
+    float* __restrict__ nn_d2, const ListCtl* __restrict__ lc, const ListPlanes lp, const SumScale sc, const HaloBox hb) {
+  // (hb, the last argument: only the HALO instantiations read it — an ordinary map's kernels never fetch those bytes)
   if (MODE == 0 && st->done) return;      // a stopped loop: nothing to do
   constexpr int lmode = MODE == 0 ? LISTS : 0;
   const unsigned long long wg_start = wall_clock64();
@@ -892,12 +939,12 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       if (!finite) {
         bestj = kNoMatch;
       } else if (!(fast_sqrt(best2) + moved < Lq)) {
-        nn_find<COUNT>(px, py, pz, S, best2, bestj, nrows, ncand);
+        nn_find<COUNT, HALO>(px, py, pz, S, hb, best2, bestj, nrows, ncand);
         if (bestj != kNoMatch) { const float3 q = ld_xyz(S.gold[0], bestj); wqx = q.x; wqy = q.y; wqz = q.z; }
       }
     }
   } else if constexpr (lmode == 1) {
-    wave_search<COUNT, true>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand, ndismissed, lc->skin,
+    wave_search<COUNT, true, HALO>(sh_w[wv].q, lane, has, px, py, pz, S, hb, best2, bestj, nrows, ncand, ndismissed, lc->skin,
                              lp, i - (uint32_t)lane);
     if (blockIdx.x == 0 && threadIdx.x == 0) {      // the transform these lists belong to
       ListCtl* __restrict__ w = const_cast<ListCtl*>(lc);
@@ -908,7 +955,7 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
       w->have = 1;
     }
   } else {
-    wave_search<COUNT, false>(sh_w[wv].q, lane, has, px, py, pz, S, best2, bestj, nrows, ncand, ndismissed);
+    wave_search<COUNT, false, HALO>(sh_w[wv].q, lane, has, px, py, pz, S, hb, best2, bestj, nrows, ncand, ndismissed);
   }
 #if MA_WGTIMES
   unsigned long long dbg_t2 = 0;
@@ -1010,21 +1057,27 @@ int launch_nn(ma_ctx* ctx, const int mode, bool count, float best2_init, uint32_
     hipLaunchKernelGGL(kern, dim3(G), dim3(kNNBlock), 0, ctx->stream, ctx->state.as<DevState>(), ctx->src.as<float4>(), ctx->n,
                        warm_hint, mode == 0 ? ctx->prev.as<uint32_t>() : (uint32_t*)nullptr, sched,
                        ctx->partials.as<long long>(), best2_init, ctx->levels, ctx->perm0.as<uint32_t>(), nn_idx, nn_d2,
-                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, lp, sc);
+                       with_lists ? ctx->listctl.as<ListCtl>() : (const ListCtl*)nullptr, lp, sc, ctx->halo_box);
   };
-  if (mode == 1) {                       // ma_nn: per-point outputs, always a search
-    if (count) args(k_nn_accum<true, 1, 0>);
-    else args(k_nn_accum<false, 1, 0>);
-  } else if (with_lists && list_kind == 1) {
-    if (count) args(k_nn_accum<true, 0, 1>);
-    else args(k_nn_accum<false, 0, 1>);
-  } else if (with_lists && list_kind == 2) {
-    if (count) args(k_nn_accum<true, 0, 2>);
-    else args(k_nn_accum<false, 0, 2>);
-  } else {
-    if (count) args(k_nn_accum<true, 0, 0>);
-    else args(k_nn_accum<false, 0, 0>);
-  }
+  // (HALO: the instantiations for a grid that covers the bulk of the gold map only — strays in its boundary cells)
+  auto pick = [&](auto halo) {
+    constexpr bool H = decltype(halo)::value;
+    if (mode == 1) {                       // ma_nn: per-point outputs, always a search
+      if (count) args(k_nn_accum<true, 1, 0, H>);
+      else args(k_nn_accum<false, 1, 0, H>);
+    } else if (with_lists && list_kind == 1) {
+      if (count) args(k_nn_accum<true, 0, 1, H>);
+      else args(k_nn_accum<false, 0, 1, H>);
+    } else if (with_lists && list_kind == 2) {
+      if (count) args(k_nn_accum<true, 0, 2, H>);
+      else args(k_nn_accum<false, 0, 2, H>);
+    } else {
+      if (count) args(k_nn_accum<true, 0, 0, H>);
+      else args(k_nn_accum<false, 0, 0, H>);
+    }
+  };
+  if (ctx->grid_halo) pick(std::true_type{});
+  else pick(std::false_type{});
   HIPCHK(hipGetLastError());
   return MA_OK;
 }

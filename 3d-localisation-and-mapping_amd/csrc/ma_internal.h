@@ -259,6 +259,12 @@ struct LevelSet {
   const uint8_t* occ_dist;         // level 0: Chebyshev distance (cells, capped) to the nearest occupied cell
 };
 
+// HALO grids (host_math.h "Robust grid box"), centred frame: per axis, the coordinate nearest to the grid's box among the
+// gold points stored in its boundary cells that lie beyond the box ALONG THAT AXIS — lo[a] the largest below it (-inf:
+// none), hi[a] the smallest above it (+inf: none).  Along axis a the content of a boundary cell is its own interval plus
+// a part of (-inf, lo[a]] or [hi[a], +inf), with nothing in between.
+struct HaloBox { float lo[3], hi[3]; };
+
 struct Pinhole {
   double fx_inv, fy_inv, cx, cy, inv_scale;
   double T[12];  // camera->world rows 0..2, translation already minus the centring origin
@@ -336,6 +342,8 @@ struct ma_ctx {
   // levels 1..3 serve only search spheres wider than 6 level-0 cells (ungated or widely gated
   // runs): they are built when such a run first asks for them, not with every gold map
   bool coarse_built = false;
+  HaloBox halo_box{{0, 0, 0}, {0, 0, 0}};     // with grid_halo (kernels_search.hip HALO)
+  bool grid_halo = false;                      // the grid covers the bulk of the gold map only (host_math.h "Robust grid box"): strays sit in its boundary cells
   float grid_lo[3] = {0, 0, 0}, grid_hi[3] = {0, 0, 0};   // box of the grid (after the phase shift)
 
   // source cloud
@@ -513,7 +521,8 @@ int guarded(ma_ctx* ctx, F&& body) noexcept {
 // kernels_build.hip: staging of clouds on the device
 // bounding box (and finiteness check) of a device-resident n x 3 (stride 3) or float4 (stride 4) cloud
 int cloud_bounds(ma_ctx* ctx, const float* d_xyz, uint32_t n, float lo[3], float hi[3], int stride = 3, bool holes_ok = false,
-                 const Lane* lane = nullptr);
+                 const Lane* lane = nullptr, const float* within_lo = nullptr, const float* within_hi = nullptr,
+                 double* n_outside = nullptr);
 // stable radix sort of (key, index) pairs; tmp == nullptr asks for the temporary bytes
 hipError_t sort_pairs_u32(void* tmp, size_t& tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
                           uint32_t* vals_out, uint32_t n, int bits, hipStream_t stream);

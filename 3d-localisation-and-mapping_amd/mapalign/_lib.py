@@ -90,6 +90,7 @@ ABI = {
     "ma_sync": (C.c_int, [_ctx_p]),
     "ma_set_gold": (C.c_int, [_ctx_p, _f32p, C.c_uint64, C.c_float]),
     "ma_grid_info_get": (C.c_int, [_ctx_p, C.POINTER(ma_grid_info)]),
+    "ma_grid_box_get": (C.c_int, [_ctx_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ma_set_source": (C.c_int, [_ctx_p, _f32p, _f32p, C.c_uint64]),
     "ma_set_pair": (C.c_int, [_ctx_p, _f32p, C.c_uint64, C.c_float, _f32p, _f32p, C.c_uint64]),
     "ma_set_pair_f64": (C.c_int, [_ctx_p, _f64p, C.c_uint64, C.c_float, _f64p, _f64p, _f32p, C.c_uint64]),

@@ -280,6 +280,13 @@ class MapAligner:
                 "n_occupied": int(gi.n_occupied), "origin": np.array(list(gi.origin)) + self._shift,
                 "build_ms": float(gi.build_ms)}
 
+    def grid_box(self):
+        """The box the gold map's grid covers (world frame) and whether it is the box of the map's bulk only — stray
+        points far from the scene are then kept in the grid's boundary cells (``ma_grid_box_get``)."""
+        lo, hi, bulk = (C.c_double * 3)(), (C.c_double * 3)(), C.c_int(0)
+        self._chk(self._lib.ma_grid_box_get(self._ctx, lo, hi, C.byref(bulk)))
+        return {"lo": np.array(list(lo)) + self._shift, "hi": np.array(list(hi)) + self._shift, "bulk_only": bool(bulk.value)}
+
     def set_source(self, comparison_cloud, weights=None):
         """``comparison_cloud`` / ``weights``: host array-likes or arrays in this GPU's memory (as in
         :meth:`set_gold`).  fp64 clouds, host or device, are shifted and converted on the device;

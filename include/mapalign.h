@@ -123,6 +123,16 @@ int ma_sync(ma_ctx* ctx);
  * edge from the point density.  Invalidates a previously set source cloud. */
 int ma_set_gold(ma_ctx* ctx, const float* xyz, uint64_t m, float cell);
 int ma_grid_info_get(const ma_ctx* ctx, ma_grid_info* out);
+/* The box the gold map's grid covers (world frame) and whether that is the box of the map's BULK only (*bulk_only = 1).
+ * A grid is a dense table over a box; a few stray points far from the scene (reflections through windows, sensor noise —
+ * real RTAB-Map exports carry them; the reference reads its clouds with o3d.io.read_point_cloud, mapping.py:63-68, which
+ * removes NaN / infinite points but no strays) would blow a bounding box up until the table budget forces cells of
+ * decimetres or metres, and an alignment then takes 20 to 10 000 times longer.  When the budget binds, the build puts
+ * the grid over the central 90 % of the points per axis, widened by a quarter of its width and cut to the true bounds;
+ * the points beyond it are stored in the grid's boundary cells and found like any other — results are those of an
+ * exhaustive search either way, bit for bit; the box only decides how fast.  The comparison cloud's sort is treated
+ * the same way. */
+int ma_grid_box_get(const ma_ctx* ctx, double lo[3], double hi[3], int* bulk_only);
 
 /* Comparison ("maintenance") cloud: N x 3 fp32 points, optional per-point weights
  * (NULL = 1; each finite and >= 0, else MA_ERR_INVALID).  Needs the gold map first (points

@@ -281,6 +281,47 @@ int main() {
     ma::choose_shift(lo_g, hi_g, 1000.0, s1);
     std::printf("shift %.1f %.1f %.1f %.1f %.1f %.1f\n", s0[0], s0[1], s0[2], s1[0], s1[1], s1[2]);
   }
+  // ---- robust grid box: central interval of a histogram, the box of the bulk, and the inequality the clamped-query
+  // pruning rests on (per-axis distance between clamped points never exceeds the true one; a stored point clamped into
+  // the box lies in the cell its clamped index names)
+  {
+    // 1000 points uniform over [0, 10), 4 strays: one far below, three far above the range histogrammed
+    uint64_t h[ma::kAxisBins + 2] = {0};
+    for (int i = 0; i < 1000; ++i) h[1 + (int)(ma::kAxisBins * (i / 1000.0) * 0.1)] += 1;   // the scene fills the first tenth of [0, 100)
+    h[0] = 1; h[ma::kAxisBins + 1] = 3;
+    double a, b;
+    ma::central_interval(h, ma::kAxisBins, 0.0, 100.0, 1004, 0.05, &a, &b);
+    std::printf("central %.6f %.6f\n", a, b);
+    // nothing to cut: the whole range
+    uint64_t flat[ma::kAxisBins + 2] = {0};
+    for (int k = 0; k < ma::kAxisBins; ++k) flat[1 + k] = 100;
+    ma::central_interval(flat, ma::kAxisBins, -1.0, 1.0, 100ull * ma::kAxisBins, 0.05, &a, &b);
+    std::printf("central_flat %.6f %.6f\n", a, b);
+    // the box: a clean axis keeps its bounds, an axis with strays is cut to the widened central interval
+    const float lo[3] = {0.f, -1.5f, -2000.f}, hi[3] = {10.f, 900.f, 1.25f};
+    const double ca[3] = {0.5, -1.4, -1.0}, cb[3] = {9.5, 1.4, 1.0};
+    float rlo[3], rhi[3];
+    const bool smaller = ma::robust_box(ca, cb, lo, hi, rlo, rhi);
+    std::printf("rbox %d %.6f %.6f %.6f %.6f %.6f %.6f\n", smaller ? 1 : 0, rlo[0], rhi[0], rlo[1], rhi[1], rlo[2], rhi[2]);
+    const double cc[3] = {0.4, -1.5, -1.25}, cd[3] = {9.6, 1.5, 1.25};
+    const float lo2[3] = {0.f, -1.5f, -1.25f}, hi2[3] = {10.f, 1.5f, 1.25f};
+    std::printf("rbox_clean %d\n", ma::robust_box(cc, cd, lo2, hi2, rlo, rhi) ? 1 : 0);
+    // the pruning inequality, brute force: random grid, random stored points (inside and far outside), random queries
+    int bad = 0;
+    for (int it = 0; it < 20000; ++it) {
+      const double o = 3.0 * U(rng), c = 0.05 + 0.2 * std::fabs(U(rng));
+      const int n = 1 + (int)(40 * std::fabs(U(rng)));
+      const double top = o + c * n - 0.5 * c * std::fabs(U(rng));        // the box's upper end: inside the last cell
+      auto clampd = [&](double v) { return std::min(std::max(v, o), top); };
+      const double p = o + (it % 3 ? 60.0 * U(rng) : c * n * std::fabs(U(rng))), q = o + (it % 5 ? 30.0 * U(rng) : c * n * std::fabs(U(rng)));
+      const int ip = std::min(std::max((int)std::floor((p - o) / c), 0), n - 1);      // cell_of: clamped index
+      const double pc = clampd(p), qc = clampd(q);
+      if (!(pc >= o + c * ip - 1e-12 && pc <= o + c * (ip + 1) + 1e-12)) ++bad;      // the clamped point lies in its cell
+      const double gap = std::max({0.0, (o + c * ip) - qc, qc - (o + c * (ip + 1))});   // what a row / cell test computes from the clamped query
+      if (gap > std::fabs(q - p) + 1e-12) ++bad;                                          // ... never more than the true distance
+    }
+    std::printf("prune %d\n", bad);
+  }
   return 0;
 }
 """
@@ -378,3 +419,21 @@ def test_p2p_exchange_words_and_protocol_under_arbitrary_delays(report):
     iterations with every word delivered after its own random delay (in any order, long after its writer has moved on)
     never takes a word of another iteration for this one's and never deadlocks."""
     assert int(report["xchg"][0][0]) == 0
+
+
+def test_robust_box_central_interval_and_the_pruning_inequality(report):
+    """csrc/host_math.h "Robust grid box": where the bulk of a cloud lies along an axis, from a histogram with stray points
+    below and above its range; a clean axis keeps its bounds; and the inequality that keeps the search exact when stray
+    gold points are stored in the grid's boundary cells and the query is clamped into the grid's box for every test of
+    cell geometry (20 000 random cases, stored points and queries inside and far outside the box)."""
+    a, b = (float(v) for v in report["central"][0])
+    w = 100.0 / 128
+    assert a == 0.0 and 10.0 <= b <= 10.0 + w + 1e-9          # the scene's tenth of the range (to a bin), strays cut
+    assert [float(v) for v in report["central_flat"][0]] == [-1.0 + 6 * 2.0 / 128, 1.0 - 6 * 2.0 / 128]      # 5 % = 6.4 bins per side
+    smaller, x0, x1, y0, y1, z0, z1 = (float(v) for v in report["rbox"][0])
+    assert smaller == 1.0
+    assert (x0, x1) == (0.0, 10.0)                               # widened central interval reaches past the bounds: the bounds stay
+    assert y0 == -1.5 and abs(y1 - (1.4 + 0.25 * 2.8)) < 1e-5   # strays above only: cut above
+    assert abs(z0 - (-1.0 - 0.5)) < 1e-5 and z1 == 1.25
+    assert int(report["rbox_clean"][0][0]) == 0
+    assert int(report["prune"][0][0]) == 0
