@@ -221,6 +221,7 @@ inline float clamp_cell_to_budget(const float lo[3], const float hi[3], float c,
 // goes over the bounds of the points INSIDE that box.  Any box is correct — the choice only decides how fast the search runs.
 constexpr int kAxisBins = 128;                 // histogram bins per axis and pass (+ one count below, one above the range)
 constexpr double kRobustTail = 0.05, kRobustWiden = 0.25;
+constexpr double kRobustMaxOutside = 0.03;     // the box of the bulk is taken only if at most this share of the points lies outside it
 // One axis: the bin-edge interval [a, b] of [lo, hi] that leaves at most `tail` of the n points on either side.
 // h[0] = points below lo, h[1 .. bins] = the bins, h[bins + 1] = points above hi.
 inline void central_interval(const uint64_t* h, int bins, double lo, double hi, uint64_t n, double tail, double* a, double* b) {

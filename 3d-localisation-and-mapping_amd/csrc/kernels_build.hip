@@ -1151,7 +1151,9 @@ int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   float tlo[3], thi[3];
   double n_out = 0;
   if ((rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, tlo, thi, 3, false, nullptr, rlo, rhi, &n_out))) return rc;
-  if (!(n_out > 0) || !(thi[0] >= tlo[0])) break;
+  // (only for a FEW points out there — the boundary cells are not made to hold a tenth of the map: a scene whose density
+  // varies that much between its parts keeps its bounding box and pays for it with candidates, tools/shape_probe.py)
+  if (!(n_out > 0) || n_out > ma::kRobustMaxOutside * (double)n || !(thi[0] >= tlo[0])) break;
   for (int a = 0; a < 3; ++a) { lo[a] = tlo[a]; hi[a] = thi[a]; }
   // ... and, per axis, how near to that box the points outside it come along that axis (HaloBox)
   if ((rc = nearest_beyond(ctx, ctx->raw.as<float>(), n, lo, hi, wlo, whi))) return rc;
@@ -1357,7 +1359,7 @@ int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const f
       float tlo[3], thi[3];
       double n_out = 0;
       if ((rc = cloud_bounds(ctx, d_raw, n, tlo, thi, 3, false, &L, rlo, rhi, &n_out))) return rc;
-      if (n_out > 0 && thi[0] >= tlo[0]) {
+      if (n_out > 0 && n_out <= ma::kRobustMaxOutside * (double)n && thi[0] >= tlo[0]) {
         for (int a = 0; a < 3; ++a) { blo[a] = tlo[a]; bhi[a] = thi[a]; }
         c = clamp_cell_to_budget(blo, bhi, gold_cell, kMaxCells);
       }
