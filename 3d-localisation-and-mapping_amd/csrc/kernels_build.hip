@@ -569,13 +569,17 @@ __global__ __launch_bounds__(kBlock) void k_sum_u32(const uint32_t* __restrict__
 // axes need (N1) — 30 us on the device against 5-6 ms per million points for the same sums in NumPy.
 constexpr int kMomLen = 10;
 constexpr uint32_t kMomBlocks = 256;
-__global__ __launch_bounds__(kBlock) void k_moments(const float4* __restrict__ pts, const uint32_t n, double* __restrict__ out) {
+// `within`: only the points inside this box count (the box of a cloud's bulk where one was taken — a few stray points a
+// hundred scene-widths away would own the covariance; (-inf, +inf) otherwise).
+__global__ __launch_bounds__(kBlock) void k_moments(const float4* __restrict__ pts, const uint32_t n, double* __restrict__ out,
+                                                    const BoundsBox within) {
   double a[kMomLen];
 #pragma unroll
   for (int k = 0; k < kMomLen; ++k) a[k] = 0.0;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const float4 p = pts[i];
     if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) continue;
+    if (p.x < within.lo[0] || p.x > within.hi[0] || p.y < within.lo[1] || p.y > within.hi[1] || p.z < within.lo[2] || p.z > within.hi[2]) continue;
     const double x = p.x, y = p.y, z = p.z;
     a[0] += 1.0; a[1] += x; a[2] += y; a[3] += z;
     a[4] += x * x; a[5] += x * y; a[6] += x * z; a[7] += y * y; a[8] += y * z; a[9] += z * z;
@@ -1073,92 +1077,92 @@ int build_gold_from_raw(ma_ctx* ctx, uint32_t n, float cell) {
   // Two attempts at most: over the bounding box, and — when the table budget forced a coarser cell edge than the map's
   // density (or the caller) asked for — over the box that holds the bulk of the points (host_math.h "Robust grid box").
   for (int attempt = 0; attempt < 2; ++attempt) {
-  bool binding = false;         // the table budget decided the cell edge
-  // centring origin: the box's centre, rounded to fp32 so that (x - o) is exact-ish
-  for (int a = 0; a < 3; ++a) ctx->origin[a] = (double)(float)(0.5 * ((double)lo[a] + (double)hi[a]));
+    bool binding = false;         // the table budget decided the cell edge
+    // centring origin: the box's centre, rounded to fp32 so that (x - o) is exact-ish
+    for (int a = 0; a < 3; ++a) ctx->origin[a] = (double)(float)(0.5 * ((double)lo[a] + (double)hi[a]));
 
-  c = cell;
-  if (!(c > 0.f)) {
-    // density-driven cell edge: aim at ~4.5 points per occupied cell (measured optimum of
-    // table reads vs candidates on MI355X).  Scans are surfaces,
-    // so occupancy grows ~ c^2; two histogram probes estimate the exponent.
-    const double target = 4.5;
-    // table budget of the density-driven choice: at most 32 cells (128 B of table) per point,
-    // and at most 2^24 cells up to 4M points, 4 cells per point beyond, 2^25 from 8M points on
-    // (the level-0 table has to stay in the Infinity Cache, but a cloud that dense pays for coarse
-    // cells with candidates: 8M / 16M / 32M points, 50 iterations: 2.1 cm (2^24 cells) 20.9 / 59.4 /
-    // 188.5 ms, 1.7 cm (31M cells) 19.9 / 51.8 / 153.0, 1.4 cm (55M cells) 24.6 / 61.4 / 177.6,
-    // 1.1 cm (114M cells) - / 62.3 / 171.6 - tools/big_cell_sweep.py)
-    // The relaxed cap stops at 1.7 cm where it would cross it: a search sphere wider than 6 cells leaves the
-    // wavefront-cooperative search (wave_search: kWalk), and with the default 0.10 m gate that is every unmatched
-    // query once c < 1.67 cm (16M points: 1.75 / 1.70 / 1.66 / 1.60 cm -> 51.8 / 52.0 / 61.6 / 60.2 ms).
-    const uint64_t cap_hi = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 24, 4ull * n));
-    uint64_t cell_cap = 1ull << 24;
-    if (cap_hi > cell_cap) {
-      const double ext0 = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-6});
-      const float seed = (float)(ext0 / 4096.0);
-      const float c_lo = clamp_cell_to_budget(lo, hi, seed, cap_hi), c_hi = clamp_cell_to_budget(lo, hi, seed, cell_cap);
-      constexpr float kGateFloor = 0.017f;
-      if (c_lo >= kGateFloor || c_hi <= kGateFloor) {
-        cell_cap = cap_hi;                       // the whole relaxed range lies on one side of the floor
-      } else {                                   // the range brackets it: the cell count of a 1.7 cm grid
-        const GridP gf = make_grid(lo, hi, ctx->origin, kGateFloor);
-        cell_cap = std::min<uint64_t>(cap_hi, std::max<uint64_t>(cell_cap, (uint64_t)gf.nx * gf.ny * gf.nz));
+    c = cell;
+    if (!(c > 0.f)) {
+      // density-driven cell edge: aim at ~4.5 points per occupied cell (measured optimum of
+      // table reads vs candidates on MI355X).  Scans are surfaces,
+      // so occupancy grows ~ c^2; two histogram probes estimate the exponent.
+      const double target = 4.5;
+      // table budget of the density-driven choice: at most 32 cells (128 B of table) per point,
+      // and at most 2^24 cells up to 4M points, 4 cells per point beyond, 2^25 from 8M points on
+      // (the level-0 table has to stay in the Infinity Cache, but a cloud that dense pays for coarse
+      // cells with candidates: 8M / 16M / 32M points, 50 iterations: 2.1 cm (2^24 cells) 20.9 / 59.4 /
+      // 188.5 ms, 1.7 cm (31M cells) 19.9 / 51.8 / 153.0, 1.4 cm (55M cells) 24.6 / 61.4 / 177.6,
+      // 1.1 cm (114M cells) - / 62.3 / 171.6 - tools/big_cell_sweep.py)
+      // The relaxed cap stops at 1.7 cm where it would cross it: a search sphere wider than 6 cells leaves the
+      // wavefront-cooperative search (wave_search: kWalk), and with the default 0.10 m gate that is every unmatched
+      // query once c < 1.67 cm (16M points: 1.75 / 1.70 / 1.66 / 1.60 cm -> 51.8 / 52.0 / 61.6 / 60.2 ms).
+      const uint64_t cap_hi = std::min<uint64_t>(1ull << 25, std::max<uint64_t>(1ull << 24, 4ull * n));
+      uint64_t cell_cap = 1ull << 24;
+      if (cap_hi > cell_cap) {
+        const double ext0 = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-6});
+        const float seed = (float)(ext0 / 4096.0);
+        const float c_lo = clamp_cell_to_budget(lo, hi, seed, cap_hi), c_hi = clamp_cell_to_budget(lo, hi, seed, cell_cap);
+        constexpr float kGateFloor = 0.017f;
+        if (c_lo >= kGateFloor || c_hi <= kGateFloor) {
+          cell_cap = cap_hi;                       // the whole relaxed range lies on one side of the floor
+        } else {                                   // the range brackets it: the cell count of a 1.7 cm grid
+          const GridP gf = make_grid(lo, hi, ctx->origin, kGateFloor);
+          cell_cap = std::min<uint64_t>(cap_hi, std::max<uint64_t>(cell_cap, (uint64_t)gf.nx * gf.ny * gf.nz));
+        }
       }
-    }
-    const uint64_t auto_cells = std::min<uint64_t>(cell_cap, std::max<uint64_t>(1ull << 20, 32ull * n));
-    const double ext = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-6});
-    float c0 = clamp_cell_to_budget(lo, hi, (float)(ext / 256.0), auto_cells);
-    uint64_t occ = 0;
-    GridP g0 = make_grid(lo, hi, ctx->origin, c0);
-    if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g0, ctx->origin, &occ))) return rc;
-    double rho0 = (double)n / (double)std::max<uint64_t>(occ, 1);
-    double expo = 2.0;
-    float c1 = (float)(c0 * std::pow(target / rho0, 1.0 / expo));
-    c1 = std::min(std::max(c1, c0 / 16.f), c0 * 16.f);
-    float wanted = c1;
-    c1 = clamp_cell_to_budget(lo, hi, c1, auto_cells);
-    if (std::fabs(c1 / c0 - 1.f) > 0.05f) {
-      GridP g1 = make_grid(lo, hi, ctx->origin, c1);
-      if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g1, ctx->origin, &occ))) return rc;
-      const double rho1 = (double)n / (double)std::max<uint64_t>(occ, 1);
-      if (rho1 != rho0 && rho1 > 0 && rho0 > 0) {
-        const double e = std::log(rho1 / rho0) / std::log((double)c1 / c0);
-        if (e > 0.5 && e < 3.5) expo = e;
+      const uint64_t auto_cells = std::min<uint64_t>(cell_cap, std::max<uint64_t>(1ull << 20, 32ull * n));
+      const double ext = std::max({(double)hi[0] - lo[0], (double)hi[1] - lo[1], (double)hi[2] - lo[2], 1e-6});
+      float c0 = clamp_cell_to_budget(lo, hi, (float)(ext / 256.0), auto_cells);
+      uint64_t occ = 0;
+      GridP g0 = make_grid(lo, hi, ctx->origin, c0);
+      if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g0, ctx->origin, &occ))) return rc;
+      double rho0 = (double)n / (double)std::max<uint64_t>(occ, 1);
+      double expo = 2.0;
+      float c1 = (float)(c0 * std::pow(target / rho0, 1.0 / expo));
+      c1 = std::min(std::max(c1, c0 / 16.f), c0 * 16.f);
+      float wanted = c1;
+      c1 = clamp_cell_to_budget(lo, hi, c1, auto_cells);
+      if (std::fabs(c1 / c0 - 1.f) > 0.05f) {
+        GridP g1 = make_grid(lo, hi, ctx->origin, c1);
+        if ((rc = occupied_cells(ctx, ctx->raw.as<float>(), n, g1, ctx->origin, &occ))) return rc;
+        const double rho1 = (double)n / (double)std::max<uint64_t>(occ, 1);
+        if (rho1 != rho0 && rho1 > 0 && rho0 > 0) {
+          const double e = std::log(rho1 / rho0) / std::log((double)c1 / c0);
+          if (e > 0.5 && e < 3.5) expo = e;
+        }
+        float c2 = (float)(c1 * std::pow(target / rho1, 1.0 / expo));
+        c2 = std::min(std::max(c2, c1 / 4.f), c1 * 4.f);
+        wanted = c2;
+        c = clamp_cell_to_budget(lo, hi, c2, auto_cells);
+      } else {
+        c = c1;
       }
-      float c2 = (float)(c1 * std::pow(target / rho1, 1.0 / expo));
-      c2 = std::min(std::max(c2, c1 / 4.f), c1 * 4.f);
-      wanted = c2;
-      c = clamp_cell_to_budget(lo, hi, c2, auto_cells);
-    } else {
-      c = c1;
+      binding = c > 1.15f * wanted;
     }
-    binding = c > 1.15f * wanted;
-  }
-  {
-    const float fits = clamp_cell_to_budget(lo, hi, c, kMaxCells);
-    binding = binding || fits > 1.0001f * c;
-    c = fits;
-  }
-  if (!(c > 0.f) || !std::isfinite(c)) return ctx->fail(MA_ERR_INVALID, "could not choose a cell edge");
-  if (!binding || attempt == 1) break;
-  // The budget, not the map, decided the cell edge: is the bounding box that of a few stray points?
-  double ca[3], cb[3];
-  float rlo[3], rhi[3];
-  if ((rc = axis_central(ctx, ctx->raw.as<float>(), n, lo, hi, main_lane(ctx), ca, cb))) return rc;
-  if (!ma::robust_box(ca, cb, lo, hi, rlo, rhi)) break;      // no: a large or dense scene, the box stays
-  // yes: the grid goes over the bounds of the points INSIDE that box — the scene's own extent where the strays lie beyond it
-  float tlo[3], thi[3];
-  double n_out = 0;
-  if ((rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, tlo, thi, 3, false, nullptr, rlo, rhi, &n_out))) return rc;
-  // (only for a FEW points out there — the boundary cells are not made to hold a tenth of the map: a scene whose density
-  // varies that much between its parts keeps its bounding box and pays for it with candidates, tools/shape_probe.py)
-  if (!(n_out > 0) || n_out > ma::kRobustMaxOutside * (double)n || !(thi[0] >= tlo[0])) break;
-  for (int a = 0; a < 3; ++a) { lo[a] = tlo[a]; hi[a] = thi[a]; }
-  // ... and, per axis, how near to that box the points outside it come along that axis (HaloBox)
-  if ((rc = nearest_beyond(ctx, ctx->raw.as<float>(), n, lo, hi, wlo, whi))) return rc;
-  halo = true;
-  MA_PT("gold: robust box chosen");
+    {
+      const float fits = clamp_cell_to_budget(lo, hi, c, kMaxCells);
+      binding = binding || fits > 1.0001f * c;
+      c = fits;
+    }
+    if (!(c > 0.f) || !std::isfinite(c)) return ctx->fail(MA_ERR_INVALID, "could not choose a cell edge");
+    if (!binding || attempt == 1) break;
+    // The budget, not the map, decided the cell edge: is the bounding box that of a few stray points?
+    double ca[3], cb[3];
+    float rlo[3], rhi[3];
+    if ((rc = axis_central(ctx, ctx->raw.as<float>(), n, lo, hi, main_lane(ctx), ca, cb))) return rc;
+    if (!ma::robust_box(ca, cb, lo, hi, rlo, rhi)) break;      // no: a large or dense scene, the box stays
+    // yes: the grid goes over the bounds of the points INSIDE that box — the scene's own extent where the strays lie beyond it
+    float tlo[3], thi[3];
+    double n_out = 0;
+    if ((rc = cloud_bounds(ctx, ctx->raw.as<float>(), n, tlo, thi, 3, false, nullptr, rlo, rhi, &n_out))) return rc;
+    // (only for a FEW points out there — the boundary cells are not made to hold a tenth of the map: a scene whose density
+    // varies that much between its parts keeps its bounding box and pays for it with candidates, tools/shape_probe.py)
+    if (!(n_out > 0) || n_out > ma::kRobustMaxOutside * (double)n || !(thi[0] >= tlo[0])) break;
+    for (int a = 0; a < 3; ++a) { lo[a] = tlo[a]; hi[a] = thi[a]; }
+    // ... and, per axis, how near to that box the points outside it come along that axis (HaloBox)
+    if ((rc = nearest_beyond(ctx, ctx->raw.as<float>(), n, lo, hi, wlo, whi))) return rc;
+    halo = true;
+    MA_PT("gold: robust box chosen");
   }
   MA_PT("gold: cell edge chosen");
   if (ctx->pair_handoff) ctx->pair_handoff->set(1, c);     // ma_set_pair: the scan's sort may start (origin and cell edge are final)
@@ -1351,6 +1355,7 @@ int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const f
   // the box of the bulk of the points.  Points outside it get the keys of its boundary bricks (cell_of clamps) and
   // keep no candidate list (k_nn_accum, list-writing launch); they are queries like any other.
   float blo[3] = {lo[0], lo[1], lo[2]}, bhi[3] = {hi[0], hi[1], hi[2]};
+  bool bulk = false;
   if (c > 1.0001f * gold_cell) {
     double ca[3], cb[3];
     float rlo[3], rhi[3];
@@ -1360,6 +1365,7 @@ int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const f
       double n_out = 0;
       if ((rc = cloud_bounds(ctx, d_raw, n, tlo, thi, 3, false, &L, rlo, rhi, &n_out))) return rc;
       if (n_out > 0 && n_out <= ma::kRobustMaxOutside * (double)n && thi[0] >= tlo[0]) {
+        bulk = true;
         for (int a = 0; a < 3; ++a) { blo[a] = tlo[a]; bhi[a] = thi[a]; }
         c = clamp_cell_to_budget(blo, bhi, gold_cell, kMaxCells);
       }
@@ -1378,6 +1384,7 @@ int build_source_from_raw(ma_ctx* ctx, uint32_t n, const float* weights, const f
     }
     ctx->src_rs = (float)(std::sqrt(r2) * 1.001 + 1e-4);
     ctx->src_box_pending = false;
+    ctx->src_bulk_box = bulk;
   }
   HIPCHK(ctx->src.ensure((size_t)n * sizeof(float4)));
   HIPCHK(ctx->src_perm.ensure((size_t)n * 4));
@@ -1448,7 +1455,17 @@ int ma_cloud_moments(ma_ctx* ctx, int which, double out[13]) {
   const uint32_t nb = std::min<uint32_t>(div_up(n, kBlock), kMomBlocks);
   static_assert(kMomBlocks * kMomLen * sizeof(double) <= kMailProbe, "bounds region of the mailbox");
   double* rows = reinterpret_cast<double*>(ctx->mailbox);
-  hipLaunchKernelGGL(k_moments, dim3(nb), dim3(kBlock), 0, ctx->stream, pts, n, rows);
+  // the moments of the cloud's BULK where its grid / its sort took the box of the bulk (host_math.h "Robust grid box")
+  BoundsBox within{{-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+  if (which == 0 && ctx->grid_halo) {
+    for (int a = 0; a < 3; ++a) {
+      within.lo[a] = (float)((double)ctx->grid_lo[a] - ctx->origin[a] - (double)ctx->grid.c);
+      within.hi[a] = (float)((double)ctx->grid_hi[a] - ctx->origin[a] + (double)ctx->grid.c);
+    }
+  } else if (which == 1 && ctx->src_bulk_box) {
+    for (int a = 0; a < 3; ++a) { within.lo[a] = ctx->src_lo[a]; within.hi[a] = ctx->src_hi[a]; }
+  }
+  hipLaunchKernelGGL(k_moments, dim3(nb), dim3(kBlock), 0, ctx->stream, pts, n, rows, within);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   double a[kMomLen] = {0};

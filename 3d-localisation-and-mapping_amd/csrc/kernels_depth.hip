@@ -558,6 +558,7 @@ int ma_set_source_from_depth(ma_ctx* ctx, const void* depth, int dtype, int widt
   }
   ctx->src_rs = 0.f;                  // no bounds of this cloud are known yet: ma_icp finds them when a run is long enough for candidate lists
   ctx->src_box_pending = true;
+  ctx->src_bulk_box = false;
   ctx->have_src = true;
   return MA_OK;
   });

@@ -391,6 +391,7 @@ struct ma_ctx {
   DevBuf lists, listctl;      // lists: the five planes of ListPlanes, back to back
   float src_rs = 0.f;                          // largest distance of a corner of the source cloud's box from the centring origin; 0: unknown, no lists
   float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // that box (centred frame)
+  bool src_bulk_box = false;                   // src_lo / src_hi are the box of the cloud's bulk (stray points lie outside it)
   bool src_box_pending = false;                // source from a depth frame: the box is computed by the first run that can use it
   // exact sums (host_math.h): what bounds a correspondence's terms
   double src_wmax = 1.0;                       // largest weight of the source cloud (1 without weights)

@@ -81,6 +81,21 @@ def _principal_frame(points, max_points):
     p = np.ascontiguousarray(p, dtype=np.float64)
     c = (np.ones(len(p)) @ p) / max(len(p), 1)          # column sums as ONE matrix-vector product
     d = p - c
+    # Stray points far from the scene (reflections, sensor noise: the reference's ingest removes none) would own the
+    # covariance: 20 of them fifty scene-widths away outweigh a million points of the scene.  Where the bounding box
+    # reaches beyond six standard deviations of the mean (a filled box reaches 1.7, a shell less), the frame is that of
+    # the cloud's BULK — the rule of the engine's grid (csrc/host_math.h "Robust grid box"): per axis the central 90 % of
+    # the points, widened by a quarter of its width.
+    if len(p) >= 64:
+        sd = np.sqrt((d * d).sum(axis=0) / len(p))
+        if (np.abs(d).max(axis=0) > 6.0 * sd + 1e-12).any():
+            lo, hi = np.quantile(p, 0.05, axis=0), np.quantile(p, 0.95, axis=0)
+            pad = 0.25 * (hi - lo) + 1e-9
+            keep = ((p >= lo - pad) & (p <= hi + pad)).all(axis=1)
+            if 0.9 * len(p) <= keep.sum() < len(p):
+                p = p[keep]
+                c = (np.ones(len(p)) @ p) / len(p)
+                d = p - c
     w, v = np.linalg.eigh(d.T @ d / max(len(d) - 1, 1))
     order = np.argsort(w)[::-1]
     axes = v[:, order]

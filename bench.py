@@ -34,7 +34,8 @@ Extra objects on the JSON line (all measured in this run, outside the timed regi
                  of the same 1M-point pair (north_star tolerance: 1e-4 Frobenius / 1 mm)
   configs        c3 (1280x960 depth frame -> fused unprojection -> 50 iterations against the
                  1M gold map), c4 (batch-32 detector inference on PyTorch-ROCm + one-call box
-                 lift), c5_per_gpu (a 2M-point pair, the per-GPU size of configs[4]),
+                 lift), c5_per_gpu (a 2M-point pair, the per-GPU size of configs[4]), stray_points (the
+                 headline pair with stray points far from the scene in both clouds),
                  concurrent_pairs (1 / 2 / 4 independent alignments iterating at once on this GPU)
   config.end_to_end_*  the drop-in call itself from host arrays (first / warm / fp64 / device-resident
                  inputs / resident gold map / a stream of pairs through align_many) and the
@@ -524,6 +525,29 @@ def config_concurrent(gold, comp, device, R0):
     return out
 
 
+def config_strays(eng, gold, comp, R0, t0):
+    """The headline pair with 20 stray points over 50 times its extent in BOTH clouds (reflections, sensor noise: real
+    RTAB-Map exports carry them, the reference's ingest removes none).  The grid covers the bulk of the map, the strays
+    sit in its boundary cells (DESIGN.md 3 "Stray points"): the alignment took 2 400 times as long before that."""
+    rng = np.random.default_rng(13)
+    lo, hi = gold.min(0), gold.max(0)
+    ctr, ext = 0.5 * (lo + hi), float((hi - lo).max())
+    stray = lambda k: (ctr + rng.uniform(-0.5, 0.5, size=(k, 3)) * ext * 50.0).astype(np.float32)
+    g, c = np.concatenate([gold, stray(20)]), np.concatenate([comp, stray(20)])
+    grid = eng.set_gold(g)
+    eng.set_source(c)
+    for _ in range(2):
+        eng.icp(ITERS, 0.0, GATE)
+    ms = [eng.icp(ITERS, 0.0, GATE).gpu_ms for _ in range(5)]
+    res = eng.icp(ITERS, 0.0, GATE)
+    return {"workload": "configs[1] with 20 stray points over 50x the scene's extent in the gold map AND in the scan (not the headline configuration)",
+            "icp_ms": float(np.median(ms)), "it_per_s": ITERS / (float(np.median(ms)) * 1e-3), "grid_cell_m": grid["cell"],
+            "grid_dims": list(grid["dims"]), "grid_covers_bulk_only": bool(eng.grid_box()["bulk_only"]),
+            "list_launches": "".join("SWL"[int(v)] for v in eng.list_plan()),
+            "final_error_vs_truth": {"R_fro": float(np.linalg.norm(res.R - R0)), "t_m": float(np.linalg.norm(res.t - t0))},
+            "note": "the same pair took 5.3-7.9 s per alignment while the grid covered the bounding box (profiles/r05_stray_points.txt)"}
+
+
 def config_c5(eng, seed=0, cpu_iters=ITERS):
     """The per-GPU workload of configs[4] (8 pairs x 2M points, one pair per GPU): one 2M pair here — timed over its
     50 iterations, checked against the ground truth, and compared with the CPU oracle after the SAME `cpu_iters`
@@ -890,6 +914,7 @@ def main():
             if not args.no_extra_configs and args.points == N_POINTS:
                 for name, fn in (("c3", lambda: config_c3(eng, gold, 0 if args.no_cpu_baseline else ITERS)), ("c4", lambda: config_c4(eng, local_rank)),
                                  ("c5_per_gpu", lambda: config_c5(eng, cpu_iters=0 if args.no_cpu_baseline else ITERS)),
+                                 ("stray_points", lambda: config_strays(eng, gold, comp, R0, t0)),
                                  ("concurrent_pairs", lambda: config_concurrent(gold, comp, local_rank, R0))):
                     try:
                         extra[name] = fn()

@@ -460,3 +460,17 @@ def test_damage_labels_through_the_full_frame_crop_with_a_toy_classifier():
     preds = det(imgs)
     assert [len(preds[0][0]), preds[0][0][4], preds[1][0][4]] == [7, 0, 1]
     assert preds[1][0][:4] == [8.0, 8.0, 23.0, 23.0] and preds[1][0][5:] == [pytest.approx(0.9), 3]
+
+
+def test_host_side_principal_frame_ignores_stray_points():
+    """coarse.principal_frame (the host-side coarse stage, N1): 20 stray points 200 scene-widths away among 100 000 must
+    not move the frame — it is taken over the cloud's bulk, by the rule of the engine's grid box."""
+    from mapalign import coarse, synthetic as syn
+    rng = np.random.default_rng(22)
+    gold, _, _, _ = syn.make_pair(18, 100_000, 10)
+    lo, hi = gold.min(0), gold.max(0)
+    st = (0.5 * (lo + hi) + rng.uniform(-0.5, 0.5, size=(20, 3)) * float((hi - lo).max()) * 200.0).astype(np.float32)
+    c0, a0, w0 = coarse.principal_frame(gold)
+    c1, a1, w1 = coarse.principal_frame(np.concatenate([gold, st]))
+    assert np.linalg.norm(c1 - c0) < 0.05 and np.allclose(w1, w0, rtol=0.02)
+    assert np.abs(np.abs(np.sum(a0 * a1, axis=0)) - 1.0).max() < 1e-3          # the same axes (up to sign)
