@@ -896,7 +896,7 @@ def main():
                     # DESIGN.md 5 "List launches": the launches of the 50 that read per-query candidate lists instead of
                     # searching (another instantiation of the kernel); `frac`, `achieved`, `launch_us`, `bytes_per_launch`
                     # above are those of the search launches alone
-                    "kernel_instantiation": "k_nn_accum<false, 0, 0> (search launches)",
+                    "kernel_instantiation": "k_nn_accum<false, 0, 0, false> (search launches; the fourth parameter: a grid over the bulk of a map with stray points)",
                     "list_launches": lists,
                     "timed_loop_it_per_s": ITERS / (res_t.gpu_ms * 1e-3)}
         cpu = parity = e2e = None

@@ -11,7 +11,8 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=
         gaps.append((int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3)
     last = nn[-50:]
     print("nn last-run per-iteration us:", " ".join(f"{x:.0f}" for x in last))
-    kind = lambda nm: "L" if ", 0, 2>" in nm else ("W" if ", 0, 1>" in nm else "S")      # k_nn_accum<COUNT, MODE, LISTS>: search / search + write lists / list launch
+    # k_nn_accum<COUNT, MODE, LISTS, HALO>: search / search + write lists / list launch
+    kind = lambda nm: "L" if ", 0, 2," in nm or ", 0, 2>" in nm else ("W" if ", 0, 1," in nm or ", 0, 1>" in nm else "S")
     kinds = [kind(r["Kernel_Name"]) for r in rows if "k_nn_accum" in r["Kernel_Name"]][-50:]
     print("launch kinds (S search, W search + write lists, L list launch):", "".join(kinds))
     for kd in "SWL":

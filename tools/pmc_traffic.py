@@ -16,7 +16,7 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recu
         names[did] = r["Kernel_Name"]
         per.setdefault(did, collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
     for did, vals in list(per.items())[-50:]:       # the measured 50-iteration run ...
-        if "k_nn_accum<false, 0, 0>" not in names[did]:
+        if "k_nn_accum<false, 0, 0" not in names[did]:      # (<COUNT, MODE, LISTS, HALO>: the search launches, either HALO)
             continue                                # ... of which the SEARCH launches (the kernel bench.py grades; list launches are other instantiations)
         for c, v in vals.items():
             agg[c].append(v)
@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as _bench      # noqa: E402  (the same hash over the same files as bench.py's line)
 res = {
-    "kernel": "k_nn_accum<false, 0, 0> (the search launches of the run)", "kernel_source_sha": _bench.kernel_source_sha(), "launches_averaged": max((len(v) for v in agg.values()), default=0),
+    "kernel": "k_nn_accum<false, 0, 0, false> (the search launches of the run)", "kernel_source_sha": _bench.kernel_source_sha(), "launches_averaged": max((len(v) for v in agg.values()), default=0),
     "FETCH_SIZE_KB": m.get("FETCH_SIZE"), "WRITE_SIZE_KB": m.get("WRITE_SIZE"),
     "TCC_EA0_RDREQ": nreq, "RDREQ_32B": n32, "RDREQ_64B": n64, "RDREQ_128B": n128,
     "read_bytes_by_request_size": read_exact,
