@@ -26,7 +26,8 @@ if [ "$PART" = A ]; then
   step 300 $OUT/${TAG}_bench_n2_rehearsal_one_gpu.json python3 bench.py --gpus 2 --backend gloo --force-device 0 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs
   : > $OUT/${TAG}_p2p_rehearsals_one_gpu.jsonl
   for args in "--mode procs --ranks 2" "--mode procs --ranks 4" "--mode threads --ranks 2" "--mode threads --ranks 4" "--mode timeout" \
-              "--mode procs --ranks 2 --points 100000 --iters 60 --tol 1e-9 --reps 400"; do
+              "--mode procs --ranks 2 --points 100000 --iters 60 --tol 1e-9 --reps 400" \
+              "--mode mixed --ranks 8 --procs 4 --reps 2" "--mode mixed --ranks 16 --procs 4 --reps 2"; do
     step 300 $OUT/p2p.tmp python3 tools/p2p_rehearsal.py $args
     tail -1 $OUT/p2p.tmp >> $OUT/${TAG}_p2p_rehearsals_one_gpu.jsonl
   done
