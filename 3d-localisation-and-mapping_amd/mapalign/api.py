@@ -118,9 +118,10 @@ def align(gold_cloud, comparison_cloud, *, max_iter=DEFAULT_MAX_ITER, tol=DEFAUL
                       with_trace=return_info)
         mem = eng.mem_info() if return_info else None
         lists = eng.list_stats() if return_info else None     # launches that wrote / read the candidate lists
+        box = eng.grid_box() if return_info else None         # which box the gold map's grid covers (stray points: DESIGN.md 3)
     if return_info:
         info = {"iterations": res.iterations, "rmse": res.rmse, "inliers": res.inliers,
-                "converged": res.converged, "gpu_ms": res.gpu_ms, "grid": grid, "trace": res.trace,
+                "converged": res.converged, "gpu_ms": res.gpu_ms, "grid": grid, "grid_box": box, "trace": res.trace,
                 "T": res.T, "mem": mem, "gate_schedule": widened, "list_launches": lists}
         return res.R, res.t, info
     return res.R, res.t
