@@ -729,8 +729,7 @@ constexpr int kRedParts = 8;
 template <bool COUNT, typename WV>
 __device__ __forceinline__ void reduce_chunk(const unsigned long long (&acc)[kNAcc], WV* __restrict__ sh_w,
                                              unsigned long long (*sh_part)[kRedParts], long long* __restrict__ partials,
-                                             const uint32_t G, const uint32_t chunk, const int lane, const int wv,
-                                             const unsigned long long magic_lanes = (unsigned long long)kNNBlock) {
+                                             const uint32_t G, const uint32_t chunk, const int lane, const int wv) {
   constexpr int kNW = kNNBlock / kWave;
   constexpr int kLive = COUNT ? kNAcc : ma::kAccLen;
   constexpr int kVals = kNW * 16, kPer = kVals / kRedParts;
@@ -769,9 +768,8 @@ __device__ __forceinline__ void reduce_chunk(const unsigned long long (&acc)[kNA
     if (k < kLive) {
 #pragma unroll
       for (int t = 0; t < kRedParts; ++t) v += sh_part[k][t];
-      // every lane of the workgroup carried the magic constant once per point it held (matched or not; k_list_accum's
-      // lanes hold two): out it goes, modulo 2^64
-      if (k < ma::kAccLen) v -= magic_lanes * kSumMagicBits;
+      // every lane of the workgroup carried the magic constant once (matched or not): out it goes, modulo 2^64
+      if (k < ma::kAccLen) v -= (unsigned long long)kNNBlock * kSumMagicBits;
     }
     partials[(size_t)k * G + chunk] = (long long)v;
   }
@@ -1031,230 +1029,6 @@ __global__ __launch_bounds__(kNNBlock) MA_NN_ATTR void k_nn_accum(
   }
 #endif
 }
-
-// ---- a4 + a5, list launch with SEVERAL chunks per workgroup (the form in force; MA_LIST_PPT=1 keeps k_nn_accum<.., 2, ..>) ----
-// A list launch's work is uniform and short — three dependent trips (point + list plane, gathers, sums) and ~400 vector
-// instructions per wavefront, a third of them the workgroup reduction — so with one point per lane its 15 872 wavefronts
-// run as two generations of 8 192 resident ones and spend as long ramping up and down as working.  Here a lane holds the
-// SAME slot of PPT consecutive chunks (neighbours in one XCD's segment, so the schedule's locality is kept and every load
-// stays coalesced): the loads of its PPT queries are in flight together, the launch is ONE generation of wavefronts, and
-// the reduction is paid once per PPT x 256 points.  The sums are exact integers (pair_terms), so adding several chunks'
-// terms before the workgroup reduction changes no bit of any total: the partial goes to the first chunk, the others get
-// zeros.  An unmatched point enters with weight 0 on a finite dummy — each of its terms is then the bare magic constant,
-// which reduce_chunk takes out again (PPT x 256 of them per workgroup).
-#ifndef MA_LIST_PPT
-#define MA_LIST_PPT 4
-#endif
-#ifndef MA_LIST_WAVES
-#define MA_LIST_WAVES (MA_LIST_PPT >= 4 ? 4 : 7)      // waves per SIMD the allocator must make room for (A/B)
-#endif
-static_assert(MA_LIST_PPT == 1 || MA_LIST_PPT == 2 || MA_LIST_PPT == 4, "points per lane of a list launch");
-static_assert(kXcdSeg % 4u == 0u, "k_list_accum groups neighbouring chunks of one XCD segment");
-template <bool COUNT, bool HALO, int PPT>
-__global__ __launch_bounds__(kNNBlock) __attribute__((amdgpu_waves_per_eu(COUNT ? 2 : (HALO ? (MA_LIST_WAVES > 4 ? MA_LIST_WAVES - 1 : MA_LIST_WAVES) : MA_LIST_WAVES), 8)))
-void k_list_accum(const DevState* __restrict__ st, const float4* __restrict__ src, const uint32_t n, const int warm_hint,
-                  uint32_t* __restrict__ prev, const Sched sched, long long* __restrict__ partials, const float best2_init,
-                  const uint32_t* __restrict__ b0, const uint32_t* __restrict__ b1, const float* __restrict__ rad,
-                  const ListCtl* __restrict__ lc, const SumScale sc, const LevelSet S, const HaloBox hb) {
-  if (st->done) return;      // a stopped loop: nothing to do
-  const unsigned long long wg_start = wall_clock64();
-  constexpr int kNW = kNNBlock / kWave;
-  const uint32_t G = gridDim.x * (uint32_t)PPT;       // chunks (the partials' row length), PPT per workgroup
-  const bool warm = warm_hint >= 0 ? warm_hint != 0 : st->iter > 0;
-  // workgroup b of XCD b % 8 takes the slots PPT (b / 8) ... PPT (b / 8) + PPT - 1 of that XCD in k_nn_accum's numbering
-  const uint32_t chunk = xcd_chunk((blockIdx.x / 8u) * (8u * PPT) + blockIdx.x % 8u, sched, sched.order != nullptr && warm);
-  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-  struct WaveSums { unsigned long long v[kNAcc][16]; };
-  __shared__ WaveSums sh_w[kNW];
-  const float4* __restrict__ gold0 = S.gold[0];
-  uint32_t at[PPT];
-  bool has[PPT];
-  float4 s[PPT];
-  uint4 l[PPT];
-  float L[PPT];
-#pragma unroll
-  for (int p = 0; p < PPT; ++p) {
-    at[p] = (chunk + (uint32_t)p) * kNNBlock + threadIdx.x;
-    has[p] = at[p] < n;
-    const uint32_t j = min(at[p], n - 1u);      // (slots past the cloud read its last point and are dropped below: no load sits behind a branch)
-    s[p] = src[j];
-    l[p] = reinterpret_cast<const uint4*>(b0)[j];
-    L[p] = rad[j];
-  }
-  float px[PPT], py[PPT], pz[PPT];
-#pragma unroll
-  for (int p = 0; p < PPT; ++p) {
-    double X, Y, Z;
-    point_image(st, s[p], X, Y, Z);
-    px[p] = (float)X; py[p] = (float)Y; pz[p] = (float)Z;
-  }
-  // the gathers of every query (all four entries of a plane, whatever the list holds: free slots repeat the match)
-  float3 q[PPT][4];
-#pragma unroll
-  for (int p = 0; p < PPT; ++p) {
-    const uint32_t id[4] = {l[p].x, l[p].y, l[p].z, l[p].w};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) q[p][u] = ld_xyz(gold0, id[u]);
-  }
-  // how far a query has moved since its list was written: (R - Rb) s + (t - tb), wave-uniform differences
-  float moved[PPT];
-  {
-    float dRf[9], dtf[3];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dRf[k] = (float)(st->R[k] - lc->Rb[k]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) dtf[k] = (float)(st->t[k] - lc->tb[k]);
-    const float slack = lc->slack;
-#pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const float mx = dRf[0] * s[p].x + dRf[1] * s[p].y + dRf[2] * s[p].z + dtf[0];
-      const float my = dRf[3] * s[p].x + dRf[4] * s[p].y + dRf[5] * s[p].z + dtf[1];
-      const float mz = dRf[6] * s[p].x + dRf[7] * s[p].y + dRf[8] * s[p].z + dtf[2];
-      moved[p] = fast_sqrt(mx * mx + my * my + mz * mz) + slack;
-    }
-  }
-  // the nearest entry of a list under the tie rule: smallest (distance, position); selects, not branches; the winner's
-  // coordinates travel with the minimum (the very bits of the gold array)
-  unsigned long long key[PPT];
-  float wx[PPT], wy[PPT], wz[PPT];
-  auto consider = [&](const int p, const float3 c, const uint32_t pos) {
-    const float d = dist2(px[p], py[p], pz[p], c.x, c.y, c.z);
-    const unsigned long long ku = pack_best(d, pos);
-    const bool take = (d < best2_init) & (ku < key[p]);
-    key[p] = take ? ku : key[p];
-    wx[p] = take ? c.x : wx[p]; wy[p] = take ? c.y : wy[p]; wz[p] = take ? c.z : wz[p];
-  };
-  uint32_t nl[PPT];
-  bool any_long = false;
-#pragma unroll
-  for (int p = 0; p < PPT; ++p) {
-    key[p] = pack_best(best2_init, kNoMatch);
-    wx[p] = wy[p] = wz[p] = 0.f;
-    const uint32_t id[4] = {l[p].x, l[p].y, l[p].z, l[p].w};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) consider(p, q[p][u], id[u]);
-    nl[p] = __float_as_uint(L[p]) & 0xFu;      // entries on the list
-    any_long = any_long || nl[p] > 4u;
-  }
-  if (any_long) {      // the second plane, for the lanes that hold a long list (their other queries repeat a first entry)
-    float3 r[PPT][4];
-    uint32_t e[PPT][4];
-#pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const uint4 m = reinterpret_cast<const uint4*>(b1)[min(at[p], n - 1u)];
-      const bool lg = nl[p] > 4u;
-      e[p][0] = lg ? m.x : l[p].x; e[p][1] = lg ? m.y : l[p].x; e[p][2] = lg ? m.z : l[p].x; e[p][3] = lg ? m.w : l[p].x;
-    }
-#pragma unroll
-    for (int p = 0; p < PPT; ++p)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) r[p][u] = ld_xyz(gold0, e[p][u]);
-#pragma unroll
-    for (int p = 0; p < PPT; ++p)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) consider(p, r[p][u], e[p][u]);
-  }
-  float best2[PPT];
-  uint32_t bestj[PPT];
-  uint32_t nrows = 0, ncand = 0;
-  // The certificate, per query: (distance of the winner, capped at the gate) + (its movement) inside the radius the list
-  // is complete for.  A query that fails it searches (per-lane, exact); a point that is not finite has no match.
-  bool fin[PPT], fb[PPT];
-  bool any_fb = false;
-#pragma unroll
-  for (int p = 0; p < PPT; ++p) {
-    best2[p] = __uint_as_float((uint32_t)(key[p] >> 32));
-    bestj[p] = (uint32_t)key[p];
-    if (COUNT && has[p]) { ncand += nl[p]; nrows += nl[p] > 4u ? (uint32_t)kListLen : 4u; }      // entries; positions read from the planes
-    fin[p] = isfinite(px[p]) && isfinite(py[p]) && isfinite(pz[p]);
-    fb[p] = has[p] && fin[p] && !(fast_sqrt(best2[p]) + moved[p] < L[p]);
-    any_fb = any_fb || fb[p];
-  }
-  if (any_fb) {
-    // The cold path keeps next to nothing alive across the search: a failing query reads its point again and forms the
-    // image anew (the same operations) and starts from the list's winner — so that the hot path's registers are the hot
-    // path's alone.
-    uint32_t fbm = 0u;
-#pragma unroll
-    for (int u = 0; u < PPT; ++u) fbm |= fb[u] ? (1u << u) : 0u;
-#pragma unroll 1
-    for (int p = 0; p < PPT; ++p) {
-      if ((fbm >> p) & 1u) {
-        uint32_t slot = (chunk + (uint32_t)p) * kNNBlock + threadIdx.x;
-        asm volatile("" : "+v"(slot));
-        const float4 sq = src[min(slot, n - 1u)];
-        double X, Y, Z;
-        point_image(st, sq, X, Y, Z);
-        const float fx = (float)X, fy = (float)Y, fz = (float)Z;
-        uint32_t bj = kNoMatch;
-        float cx = 0.f, cy = 0.f, cz = 0.f;
-#pragma unroll
-        for (int u = 0; u < PPT; ++u)
-          if (u == p) { bj = bestj[u]; cx = wx[u]; cy = wy[u]; cz = wz[u]; }
-        float b2 = bj != kNoMatch ? dist2(fx, fy, fz, cx, cy, cz) : best2_init;      // (the bits consider() formed)
-        nn_find<COUNT, HALO>(fx, fy, fz, S, hb, b2, bj, nrows, ncand);
-        float3 c = make_float3(0.f, 0.f, 0.f);
-        if (bj != kNoMatch) c = ld_xyz(gold0, bj);
-#pragma unroll
-        for (int u = 0; u < PPT; ++u)
-          if (u == p) { bestj[u] = bj; wx[u] = c.x; wy[u] = c.y; wz[u] = c.z; }
-      }
-    }
-  }
-  // the 17 terms of every correspondence as integer bit patterns, added; an unmatched point: weight 0, finite dummies
-  // The points once more (lines this workgroup read a microsecond ago, all PPT loads in flight before the first is used)
-  // and their images formed anew, the very same operations: the search above then carries neither — ten registers per
-  // point less where the gathers need them.  (The index made opaque, or the compiler keeps the first copy instead.)
-  float4 sr[PPT];
-#pragma unroll
-  for (int p = 0; p < PPT; ++p) {
-    uint32_t slot = (chunk + (uint32_t)p) * kNNBlock + threadIdx.x;
-    asm volatile("" : "+v"(slot));
-    sr[p] = src[min(slot, n - 1u)];
-  }
-  unsigned long long acc[kNAcc];
-#pragma unroll
-  for (int p = 0; p < PPT; ++p) {
-    // (a point that is not finite, or a slot past the cloud, holds no match: consider() never takes a NaN distance, and
-    // neither searches)
-    const bool m = has[p] && fin[p] && bestj[p] != kNoMatch;
-#if MA_DEBUG_FETCH      // debug build (tools/tie_debug.py): list launches leave their matches behind too
-    if (prev && has[p]) prev[at[p]] = m ? bestj[p] : kNoMatch;
-#endif
-    const float4 sp = sr[p];
-    double X, Y, Z;
-    point_image(st, sp, X, Y, Z);
-    unsigned long long t[kNAcc];
-    pair_terms(t, m ? (double)sp.w : 0.0, m ? X : 0.0, m ? Y : 0.0, m ? Z : 0.0,
-               make_float3(m ? wx[p] : 0.f, m ? wy[p] : 0.f, m ? wz[p] : 0.f), sc);
-#pragma unroll
-    for (int k = 0; k < ma::kAccLen; ++k) acc[k] = p == 0 ? t[k] : acc[k] + t[k];
-  }
-#pragma unroll
-  for (int k = ma::kAccLen; k < kNAcc; ++k) acc[k] = 0ull;
-  if (COUNT) { acc[17] = nrows; acc[18] = ncand; }
-
-  __shared__ unsigned long long sh_part[kNAcc][kRedParts];
-  reduce_chunk<COUNT>(acc, sh_w, sh_part, partials, G, chunk, lane, wv, (unsigned long long)PPT * kNNBlock);
-  // (the other chunks of this workgroup: zero partials; 19 x (PPT - 1) <= 57 words, wavefronts 1-3)
-  if (threadIdx.x >= kWave && threadIdx.x < kWave + kNAcc * (PPT - 1)) {
-    const uint32_t w = threadIdx.x - kWave;
-    partials[(size_t)(w % kNAcc) * G + chunk + 1u + w / kNAcc] = 0ll;
-  }
-  if (threadIdx.x == 0 && sched.wg_cost) {      // (cost for a later search launch's schedule: the group's time on each of its chunks)
-    const uint32_t cost = (uint32_t)(wall_clock64() - wg_start);
-#pragma unroll
-    for (int p = 0; p < PPT; ++p) sched.wg_cost[chunk + (uint32_t)p] = cost;
-  }
-#if MA_WGTIMES
-  if (threadIdx.x == 0 && st->iter < 64 && blockIdx.x < 4096) {
-    g_wgt[st->iter][blockIdx.x][0] = wg_start;
-    g_wgt[st->iter][blockIdx.x][1] = wall_clock64();
-    g_wghw[st->iter][blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
-    g_wghw[st->iter][blockIdx.x][1] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) | (chunk << 4);   // XCC_ID, chunk
-  }
-#endif
-}
 }  // namespace
 
 namespace mai {
@@ -1295,15 +1069,7 @@ int launch_nn(ma_ctx* ctx, const int mode, bool count, float best2_init, uint32_
       if (count) args(k_nn_accum<true, 0, 1, H>);
       else args(k_nn_accum<false, 0, 1, H>);
     } else if (with_lists && list_kind == 2) {
-      if (kListInline == 0 && MA_LIST_PPT > 1 && ctx->n > 0) {      // several chunks per workgroup (G is a multiple of 8 * kXcdSeg)
-        auto largs = [&](auto kern) {
-          hipLaunchKernelGGL(kern, dim3(G / (uint32_t)MA_LIST_PPT), dim3(kNNBlock), 0, ctx->stream, ctx->state.as<DevState>(), ctx->src.as<float4>(),
-                             ctx->n, warm_hint, ctx->prev.as<uint32_t>(), sched, ctx->partials.as<long long>(), best2_init,
-                             lp.b0, lp.b1, lp.rad, ctx->listctl.as<ListCtl>(), sc, ctx->levels, ctx->halo_box);
-        };
-        if (count) largs(k_list_accum<true, H, MA_LIST_PPT>);
-        else largs(k_list_accum<false, H, MA_LIST_PPT>);
-      } else if (count) args(k_nn_accum<true, 0, 2, H>);
+      if (count) args(k_nn_accum<true, 0, 2, H>);
       else args(k_nn_accum<false, 0, 2, H>);
     } else {
       if (count) args(k_nn_accum<true, 0, 0, H>);
