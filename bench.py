@@ -932,7 +932,7 @@ def main():
                        + (f" - {args.pairs_per_gpu} independent pairs iterating at once per GPU (NOT the headline configuration)"
                           if args.pairs_per_gpu > 1 and not sharded else "")
                        + ("" if world == 1 else f" - one pair per GPU x{world}" if not sharded
-                          else f" - one pair sharded over {world} GPUs, RCCL all-reduce of 17 doubles/iteration inside the library"),
+                          else f" - one pair sharded over {world} GPUs, all-reduce of the 17 int64 fixed-point sums per iteration inside the library"),
                        "points_gold": len(gold), "points_comparison": len(comp), "iterations_per_step": ITERS,
                        "max_corr_dist_m": GATE, "grid_cell_m": grid["cell"], "grid_dims": list(grid["dims"]),
                        "grid_build_ms": grid["build_ms"], "grid_build_ms_first_build_of_context": grid_first["build_ms"],
