@@ -30,7 +30,8 @@ void pt_dump() {
 //
 // Candidate lists are a per-context setting (ma_list_config; MA_FLAG_NO_LISTS switches them off for one run).  The
 // environment only supplies the defaults a context is created with: MAPALIGN_LISTS=0 every launch searches,
-// MAPALIGN_SKIN_DIV=<d> skin = cell edge / d, MAPALIGN_MIN_USES=<n> (sweeps).  Nothing is read from the environment
+// MAPALIGN_SKIN_DIV=<d> skin = cell edge / d, MAPALIGN_MIN_USES=<n>, MAPALIGN_BUILD_FRAC / MAPALIGN_RHO_MIN (the planner's
+// prediction constants; sweeps).  Nothing is read from the environment
 // after ma_create.
 using ma::kSkinDivDefault;
 using ma::kMinUsesDefault;
@@ -43,6 +44,12 @@ void list_config_from_env(ma_ctx* ctx) {
   e = std::getenv("MAPALIGN_MIN_USES");
   const int u = e ? std::atoi(e) : 0;
   ctx->cfg_min_uses = u >= 1 && u <= 64 ? u : kMinUsesDefault;
+  e = std::getenv("MAPALIGN_BUILD_FRAC");
+  const double bf = e ? std::atof(e) : 0.0;
+  ctx->cfg_build_frac = bf >= 0.05 && bf <= 0.49 ? bf : ma::kBuildFracDefault;
+  e = std::getenv("MAPALIGN_RHO_MIN");
+  const double rm = e ? std::atof(e) : 0.0;
+  ctx->cfg_rho_min = rm >= 0.3 && rm <= 1.0 ? rm : ma::kRhoMinDefault;
   e = std::getenv("MAPALIGN_PLANNER_TIMEOUT_US");       // fault injection for the tests: make the planner's wait give up early
   const long t = e ? std::atol(e) : 0;
   if (t >= 1 && t <= 60L * 1000 * 1000) ctx->cfg_planner_timeout_us = (int)t;

@@ -210,7 +210,7 @@ int icp_loop(ma_ctx* ctx, const ma_params* params, const double init[16], double
   int launched = 0;
   const double skin = (double)ctx->grid.c / (double)list_skin_div(ctx);
   ma::ListPlanner planner;       // list_planner.h: the decisions themselves (CPU-tested by tests/test_list_planner.py)
-  planner.configure(skin, params->max_iter, ctx->src_lo, ctx->src_hi, ctx->cfg_min_uses);
+  planner.configure(skin, params->max_iter, ctx->src_lo, ctx->src_hi, ctx->cfg_min_uses, ctx->cfg_build_frac, ctx->cfg_rho_min);
   const DevState T_first = *ctx->host_state_in;     // the transform launch 0 runs with
   auto T_of = [&](int k) -> const DevState& {        // the transform launch k runs with (k <= the last slot read + 1)
     return k == 0 ? T_first : const_cast<const DevState&>(ctx->host_slots[k - 1].s);

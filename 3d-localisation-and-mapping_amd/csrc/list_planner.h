@@ -72,8 +72,12 @@ inline bool slot_ready(const volatile StateSlot* sl, int want) {
 constexpr int kPlan = 4;             // iterations per planning batch of ma_icp
 // Defaults of a context's list configuration (ma_list_config).  skin = cell edge / kSkinDivDefault; a launch writes
 // lists only when at least kMinUsesDefault reads are predicted to follow.
-constexpr float kSkinDivDefault = 7.f;
-constexpr int kMinUsesDefault = 5;
+constexpr float kSkinDivDefault = 12.f;
+constexpr int kMinUsesDefault = 3;
+// ... and of the two constants of the prediction: a launch writes lists only once a step is below kBuildFracDefault x skin, and
+// the decay of the steps is never assumed faster than kRhoMinDefault per iteration (MAPALIGN_BUILD_FRAC / MAPALIGN_RHO_MIN
+// at ma_create: sweeps, tools/planner_sweep.py)
+constexpr double kBuildFracDefault = 0.25, kRhoMinDefault = 0.85;
 
 // ---- Where a stopped loop stops ENQUEUEING (icp_loop; the same rule on every rank of a sharded loop) ------------------
 // Every solve up to and including the one that stops the loop writes its pinned slot; the one that stops it also stores
@@ -107,6 +111,7 @@ struct ListPlanner {
   // set once per run
   double use_max = 0.0;      // a query passes its check while it has moved less than skin / 2: 0.49 skin
   double build_max = 0.0;    // a cloud still moving faster than this per iteration is not worth a list: 0.25 skin
+  double rho_min = kRhoMinDefault;  // the steps' decay per iteration is never assumed faster than this
   int min_uses = kMinUsesDefault;   // a read saves a search launch's surplus over a list launch, a write costs about one search launch more
   int max_iter = 0;
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};      // box of the source cloud (stored, centred coordinates)
@@ -114,9 +119,11 @@ struct ListPlanner {
   bool lists_live = false;   // lists exist or are planned ...
   int built_at = -1;         // ... written by the launch of this iteration
 
-  void configure(double skin, int max_iterations, const float box_lo[3], const float box_hi[3], int min_uses_ = kMinUsesDefault) {
+  void configure(double skin, int max_iterations, const float box_lo[3], const float box_hi[3], int min_uses_ = kMinUsesDefault,
+                 double build_frac = kBuildFracDefault, double rho_min_ = kRhoMinDefault) {
     use_max = 0.49 * skin;
-    build_max = 0.25 * skin;
+    build_max = build_frac * skin;
+    rho_min = rho_min_;
     min_uses = min_uses_;
     max_iter = max_iterations;
     for (int a = 0; a < 3; ++a) { lo[a] = box_lo[a]; hi[a] = box_hi[a]; }
@@ -155,7 +162,7 @@ struct ListPlanner {
     const double step = moved(T_of(j + 1), T_of(j));
     const double step_old = moved(T_of(j + 2 - kPlan), T_of(j + 1 - kPlan));
     double rho = 1.0;
-    if (step_old > 0.0) rho = std::min(1.0, std::max(0.85, std::pow(step / step_old, 1.0 / (kPlan - 1))));
+    if (step_old > 0.0) rho = std::min(1.0, std::max(rho_min, std::pow(step / step_old, 1.0 / (kPlan - 1))));
     auto step_at = [&](int n) { return step * std::pow(rho, n); };                               // bound on the step of iteration j + n
     auto cum = [&](int n) { double a = 0; for (int i = 1; i <= n; ++i) a += step_at(i); return a; };   // motion over iterations j+1 .. j+n
     if (!std::isfinite(step) || step_at(k - j) > build_max) {

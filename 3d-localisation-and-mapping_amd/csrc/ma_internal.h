@@ -405,6 +405,7 @@ struct ma_ctx {
   bool cfg_lists = true;                       // ma_list_config: lists allowed at all; skin = cell edge / cfg_skin_div; a write must
   float cfg_skin_div = ma::kSkinDivDefault;    //   be followed by >= cfg_min_uses predicted uses
   int cfg_min_uses = ma::kMinUsesDefault;
+  double cfg_build_frac = ma::kBuildFracDefault, cfg_rho_min = ma::kRhoMinDefault;      // the planner's prediction constants (environment at ma_create: sweeps)
   int cfg_planner_timeout_us = 20 * 1000 * 1000;   // how long the planner waits for a slot before it falls back (MAPALIGN_PLANNER_TIMEOUT_US: tests)
   int32_t plan_diag[4] = {0, 0, 0, 0};         // last loop: planner waits, waits that left the spin for yields, timeouts, iterations enqueued
   ListCtl* host_lc = nullptr;                  // pinned: the control block a run starts from

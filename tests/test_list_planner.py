@@ -192,14 +192,15 @@ def test_box_motion_bound_is_the_maximum_over_the_box(shim):
 
 def test_a_cloud_at_rest_writes_once_and_reads_to_the_end(shim):
     use_max, build_max, min_uses = limits(shim)
-    assert use_max == pytest.approx(0.49 * SKIN) and build_max == pytest.approx(0.25 * SKIN) and min_uses == 5
+    assert use_max == pytest.approx(0.49 * SKIN) and build_max == pytest.approx(0.25 * SKIN) and min_uses == 3
     n = 50
     plan, seen = run(shim, translations(np.zeros(n)), n)
     assert plan.tolist() == [0] * 8 + [1] + [2] * (n - 9)
     assert seen[0] <= -K_PLAN and seen[1] >= 0                   # only transforms the host has when it plans the batch
     # too close to the end of the run for min_uses reads: no lists at all; one iteration more and they pay
-    assert run(shim, translations(np.zeros(13)), 13)[0].tolist() == [0] * 13
-    assert run(shim, translations(np.zeros(14)), 14)[0].tolist() == [0] * 8 + [1] + [2] * 5
+    short = 8 + min_uses
+    assert run(shim, translations(np.zeros(short)), short)[0].tolist() == [0] * short
+    assert run(shim, translations(np.zeros(short + 1)), short + 1)[0].tolist() == [0] * 8 + [1] + [2] * min_uses
 
 
 def test_a_cloud_that_keeps_moving_fast_only_searches(shim):
