@@ -72,7 +72,7 @@ inline bool slot_ready(const volatile StateSlot* sl, int want) {
 constexpr int kPlan = 4;             // iterations per planning batch of ma_icp
 // Defaults of a context's list configuration (ma_list_config).  skin = cell edge / kSkinDivDefault; a launch writes
 // lists only when at least kMinUsesDefault reads are predicted to follow.
-constexpr float kSkinDivDefault = 12.f;
+constexpr float kSkinDivDefault = 10.f;
 constexpr int kMinUsesDefault = 3;
 // ... and of the two constants of the prediction: a launch writes lists only once a step is below kBuildFracDefault x skin, and
 // the decay of the steps is never assumed faster than kRhoMinDefault per iteration (MAPALIGN_BUILD_FRAC / MAPALIGN_RHO_MIN

@@ -1,6 +1,6 @@
 """Sweep of the list planner's two settings (ma_list_config: skin = cell edge / skin_div, min_uses) on resident pairs.
 
-    python3 tools/planner_sweep.py [points=1000000] [seeds=0,1]
+    python3 tools/planner_sweep.py [points=1000000] [seeds=0,1]      (a seed "depth": configs[2], the depth frame against the gold map)
 
 The settings change speed only (a list launch proves every correspondence it takes from a list), so every row must show the
 same transform; what differs is when the lists start, how often they are rewritten and how long a list launch takes (a wider
@@ -18,16 +18,25 @@ import mapalign  # noqa: E402
 from mapalign import synthetic as syn  # noqa: E402
 
 points = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-seeds = [int(s) for s in (sys.argv[2] if len(sys.argv) > 2 else "0,1").split(",")]
+seeds = [s if s == "depth" else int(s) for s in (sys.argv[2] if len(sys.argv) > 2 else "0,1").split(",")]      # "depth": configs[2]
 SKINS = tuple(float(s) for s in os.environ.get("SWEEP_SKINS", "4,5,6,7,8,10").split(","))
 USES = tuple(int(s) for s in os.environ.get("SWEEP_USES", "2,3,5,8").split(","))
 KIND = "SWL"
 
 for seed in seeds:
-    g, c, R0, t0 = syn.make_pair(seed, points)
     eng = mapalign.MapAligner(0)
-    eng.set_gold(g, 0.0)
-    eng.set_source(c)
+    if seed == "depth":      # configs[2] as bench.py sets it up: the 1280 x 960 frame, pose 1 degree / 4.4 cm off, against the gold map of seed 0
+        g = syn.make_pair(0, points)[0]
+        depth, K, T = syn.make_depth_frame(0)
+        dT = np.eye(4)
+        dT[:3, :3] = syn.rotation_about_axis([0.2, 1.0, 0.3], np.deg2rad(1.0))
+        dT[:3, 3] = [0.03, -0.02, 0.025]
+        eng.set_gold(g, 0.0)
+        eng.set_source_from_depth(depth, K, dT @ T, 1000.0)
+    else:
+        g, c, R0, t0 = syn.make_pair(seed, points)
+        eng.set_gold(g, 0.0)
+        eng.set_source(c)
     ref = None
     print(f"== {points}-point pair, seed {seed}, 50 iterations, gate 0.10 m (default: skin_div 7, min_uses 5)", flush=True)
     for sd in SKINS:
