@@ -35,11 +35,13 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
     """north_star: "(R,t) must match the reference CPU path to <= 1e-4 Frobenius on R and
     <= 1 mm on t for identical inputs" — the 1M-point pair, all 50 iterations, tol = 0, gate
     0.10 m.  The oracle runs its 50 KD-tree iterations on the host cores
-    (1.2-4 s each on the 256-core GPU boxes, depending on their load).  Seed 0 always runs all 50 on the scikit-learn
-    backend north_star names.  Seeds 1 and 2 run on the oracle's cKDTree backend (the same nearest neighbours,
-    tests/test_oracle.py; 4-7 times faster), so all 50 fit the suite's budget on every box seen so far; should a host be
-    slower still, the budget (conftest.suite_seconds_left) shortens them — seed 1 never below 34, past the first list
-    launches of this pair at iteration 29, seed 2 never below 20 — with a warning, and the terminal summary says what ran."""
+    (1.2-4 s each on the 256-core GPU boxes, depending on their load).  Seed 0 runs on the scikit-learn backend
+    north_star names: all 50 iterations where the host allows (80 s on most boxes), and on a slow host (3.8 s per iteration
+    seen: 190 s, which took the later seeds' time) at least the first 10, the rest from the same state on the oracle's
+    cKDTree backend — the same nearest neighbours (tests/test_oracle.py), what bench.py's parity leg does — so that all 50
+    are still compared.  Seeds 1 and 2 run on cKDTree (4-7 times faster); should a host be slower still, the budget
+    (conftest.suite_seconds_left) shortens them — seed 1 never below 34, past the first list launches of this pair,
+    seed 2 never below 20 — with a warning, and the terminal summary says what ran."""
     from conftest import record_comparison, suite_seconds_left
     gold, comp, R0, t0 = syn.make_pair(seed, 1_000_000)
     engine.set_gold(gold)
@@ -49,6 +51,7 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
     R, t = np.eye(3), np.zeros(3)
     inliers, rmse = [], []
     iters = 50
+    n_sklearn = 50      # seed 0: iterations on the scikit-learn backend
     t_start = time.perf_counter()
     k = 0
     while k < iters:
@@ -57,6 +60,15 @@ def test_config2_1m_50_iterations_vs_oracle(engine, seed):
         inliers.append(acc[0])
         rmse.append(np.sqrt(acc[16] / acc[0]))
         k += 1
+        if seed == 0 and k == 5:
+            # does the scikit-learn backend fit all 50?  Otherwise it keeps what fits (>= 10), and cKDTree takes over
+            per_it = (time.perf_counter() - t_start) / 5
+            room = suite_seconds_left() - RESERVE_AFTER_HEADLINE_S - 40.0      # 40 s: seeds 1 and 2 in full on cKDTree
+            if (50 - k) * per_it > room:
+                n_sklearn = int(max(10, min(50, k + (room - (50 - k) * 0.3) / per_it)))
+        if seed == 0 and k == n_sklearn and k < iters:
+            index = orc.GoldIndex(gold, n_jobs=-1, backend="ckdtree")
+            backend = f"sklearn 0-{k - 1}, ckdtree {k}-49"
         if seed > 0 and k == 5:
             per_it = (time.perf_counter() - t_start) / 5
             # what is left for this seed: the budget minus the reserve of the later tests, minus (for seed 1) seed 2's floor
