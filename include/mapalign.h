@@ -182,7 +182,7 @@ int ma_get_list_stats(ma_ctx* ctx, int32_t out[2]);
 int ma_get_list_plan(ma_ctx* ctx, uint8_t* kinds, int max_iterations);
 /* Per-context configuration of the candidate lists.  enabled: 1 / 0, or -1 to keep; skin_div: the lists' skin is the
  * grid's cell edge / skin_div (2..64), 0 to keep; min_uses: a launch writes lists only if at least this many reads are
- * predicted to follow (1..64), 0 to keep.  A context is created with lists enabled, cell / 7 and 5 — or with what
+ * predicted to follow (1..64), 0 to keep.  A context is created with lists enabled, cell / 10 and 3 — or with what
  * MAPALIGN_LISTS (0 = off), MAPALIGN_SKIN_DIV and MAPALIGN_MIN_USES say in the environment AT ma_create; nothing is read
  * from the environment afterwards.  The settings change how fast the loop runs, never what it returns. */
 int ma_list_config(ma_ctx* ctx, int enabled, float skin_div, int min_uses);
